@@ -1,0 +1,71 @@
+"""ctypes binding of libswat_hip.so (include/swat_hip.h).  Fails loudly when the library is absent."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libswat_hip.so")
+_lib = None
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/swat_hip.h
+_PROTOS = {
+    "swat_version": [],
+    "swat_last_error": [],
+    "swat_sim_segmented": [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "swat_segment_topk": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int,
+                          c_void_p, c_void_p, c_void_p, c_void_p],
+}
+_RESTYPES = {"swat_last_error": ctypes.c_char_p}
+
+
+class SwatHipError(RuntimeError):
+    pass
+
+
+def build():
+    """Compile the HIP sources in swat_amd/csrc for gfx950 (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    subprocess.check_call(["bash", os.path.join(_HERE, "csrc", "build.sh")])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SwatHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(swat_amd has no CPU or PyTorch fallback)")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _PROTOS.items():
+            fn = getattr(h, name)  # AttributeError if the .so is stale: loud by design
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_int)
+        _lib = h
+    return _lib
+
+
+def exported_symbols():
+    return list(_PROTOS)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SwatHipError(f"{what} failed ({rc}): {lib().swat_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SwatHipError("swat_amd ops need GPU tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise SwatHipError("swat_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

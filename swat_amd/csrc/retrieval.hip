@@ -1,0 +1,233 @@
+// swat_amd/csrc/retrieval.hip — path B kernels for gfx950: similarity scan + filtered segmented top-k.
+//
+// ref (relative to the reference tree): retrieval/sample_retrieval.py:397-416, :335-353 (similarity),
+// :754/:807 + :439-482 / :492-540 (rank + filter).  Semantics are pinned by oracle/retrieval_oracle.c.
+#include "common.hpp"
+#include "../../include/swat_hip.h"
+
+namespace swat {
+
+// --------------------------------------------------------------------------------------------
+// B4: similarity scan.  HBM-bound: 4*d bytes per row in, 4 bytes out.
+//
+// Canonical arithmetic: ONE fp32 fma chain per row over k ascending.  To keep the chain on one
+// lane while the HBM reads stay coalesced, each wave stages a [64 rows x KC floats] chunk
+// through LDS: loads are 16 B/lane covering 4 rows x 256 B per wave-instruction, the LDS image
+// has rows padded by one 16-B slot so both the ds_write_b128 (8 contiguous lanes) and the
+// lane-per-row ds_read_b128 (16-lane groups -> 16 distinct slots) are conflict-free.
+// The next chunk's loads are issued before the current chunk is consumed (register staging).
+// Waves are independent (no workgroup barrier): 4 waves/block, 2 blocks/CU by LDS.
+// --------------------------------------------------------------------------------------------
+constexpr int KC = 64;              // floats per row per chunk (256 B)
+constexpr int ROW_F4 = KC / 4 + 1;  // padded row stride in float4
+
+__global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restrict__ feats, int64_t n_rows, int d,
+                                                            const float* __restrict__ queries,
+                                                            const int32_t* __restrict__ row_seg,
+                                                            float* __restrict__ sims) {
+    __shared__ float4 smem[4 * 64 * ROW_F4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float4* tile = smem + wave * 64 * ROW_F4;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (row0 >= n_rows) return;  // wave-uniform
+    const int64_t last = n_rows - 1;
+    const int64_t myrow = row0 + lane < last ? row0 + lane : last;
+    const float* q = queries + (row_seg ? (int64_t)row_seg[myrow] * d : 0);
+
+    const int lr = lane >> 4;    // row inside a 4-row load group
+    const int slot = lane & 15;  // 16-B slot inside the 256-B row chunk
+    const float* src[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        int64_t r = row0 + 4 * j + lr;
+        r = r < last ? r : last;
+        src[j] = feats + r * (int64_t)d + slot * 4;
+    }
+    float4 stage[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) stage[j] = *reinterpret_cast<const float4*>(src[j]);
+
+    float acc = 0.0f;
+    const int nchunk = d / KC;
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tile[(4 * j + lr) * ROW_F4 + slot] = stage[j];
+        if (c + 1 < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) stage[j] = *reinterpret_cast<const float4*>(src[j] + (c + 1) * KC);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float4* qc = reinterpret_cast<const float4*>(q + c * KC);
+#pragma unroll
+        for (int g = 0; g < KC / 4; ++g) {
+            const float4 x = tile[lane * ROW_F4 + g];
+            const float4 w = qc[g];
+            acc = fmaf(x.x, w.x, acc);
+            acc = fmaf(x.y, w.y, acc);
+            acc = fmaf(x.z, w.z, acc);
+            acc = fmaf(x.w, w.w, acc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (row0 + lane < n_rows) sims[row0 + lane] = acc;
+}
+
+// --------------------------------------------------------------------------------------------
+// B5: filtered segmented top-k.  One workgroup per class segment.
+//   key(row) = ordered(sim) << 32 | (0xFFFFFFFF - local_row)   (0 = filtered out)
+// so "larger key" == (sim desc, row asc): exactly CPython's stable sorted(reverse=True) order.
+// MSB-first radix select (8 x 8 bit) finds the k-th largest key, a collect pass gathers the
+// keys >= it into LDS, a bitonic sort orders them.  Keys are rebuilt from (sim, t2i, excluded)
+// on every pass instead of being materialised (9 B/row/pass, L2-resident for typical classes).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ordered_bits(float s) {
+    if (s == 0.0f) s = 0.0f;  // -0.0 == 0.0 for Python's sort: one key
+    uint32_t u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unordered_bits(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+constexpr int TOPK_MAX = 2048;
+
+__global__ __launch_bounds__(256) void segment_topk_kernel(const float* __restrict__ sims, const float* __restrict__ t2i,
+                                                           const uint8_t* __restrict__ excluded,
+                                                           const int64_t* __restrict__ seg_offsets, float thr,
+                                                           float t2i_thr, int k, int64_t* __restrict__ out_idx,
+                                                           float* __restrict__ out_val, int64_t* __restrict__ out_cnt) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long keys[TOPK_MAX];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned s_remaining, s_count, s_valid;
+
+    const int seg = blockIdx.x;
+    const int64_t b = seg_offsets[seg];
+    const int64_t n = seg_offsets[seg + 1] - b;
+    const int tid = threadIdx.x;
+
+    auto make_key = [&](int64_t i) -> unsigned long long {
+        const float s = sims[b + i];
+        bool ok = s >= thr;
+        if (t2i) ok = ok && (t2i[b + i] >= t2i_thr);
+        if (excluded) ok = ok && (excluded[b + i] == 0);
+        if (!ok) return 0ull;
+        return ((unsigned long long)ordered_bits(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+    };
+
+    // count valid rows
+    if (tid == 0) { s_valid = 0; s_count = 0; }
+    __syncthreads();
+    unsigned local = 0;
+    for (int64_t i = tid; i < n; i += 256) local += make_key(i) != 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += (unsigned)__shfl_xor((int)local, o, 64);
+    if ((tid & 63) == 0) atomicAdd(&s_valid, local);
+    __syncthreads();
+    const unsigned n_valid = s_valid;
+    const unsigned kk = n_valid < (unsigned)k ? n_valid : (unsigned)k;
+
+    unsigned long long kth = 1ull;  // n_valid <= k: every valid key qualifies
+    if (n_valid > (unsigned)k) {
+        unsigned long long prefix = 0ull, mask = 0ull;
+        unsigned remaining = (unsigned)k;
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int64_t i = tid; i < n; i += 256) {
+                const unsigned long long key = make_key(i);
+                if (key != 0ull && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned cum = 0;
+                int dsel = 0;
+                for (int dgt = 255; dgt >= 0; --dgt) {
+                    if (cum + hist[dgt] >= remaining) { dsel = dgt; break; }
+                    cum += hist[dgt];
+                }
+                s_remaining = remaining - cum;
+                s_prefix = prefix | ((unsigned long long)dsel << shift);
+            }
+            __syncthreads();
+            remaining = s_remaining;
+            prefix = s_prefix;
+            mask |= 0xFFull << shift;
+            __syncthreads();
+        }
+        kth = prefix;
+    }
+
+    // collect keys >= kth (exactly kk of them: keys are unique)
+    int npow2 = 1;
+    while (npow2 < (int)kk) npow2 <<= 1;
+    for (int i = tid; i < npow2; i += 256) keys[i] = 0ull;
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += 256) {
+        const unsigned long long key = make_key(i);
+        if (key != 0ull && key >= kth) {
+            const unsigned pos = atomicAdd(&s_count, 1u);
+            if (pos < (unsigned)TOPK_MAX) keys[pos] = key;
+        }
+    }
+    __syncthreads();
+
+    // bitonic sort, descending
+    for (int size = 2; size <= npow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < npow2 / 2; i += 256) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], c = keys[hi];
+                if ((a < c) == desc) { keys[lo] = c; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+
+    for (int r = tid; r < k; r += 256) {
+        int64_t idx = -1;
+        float val = -INFINITY;
+        if (r < (int)kk) {
+            const unsigned long long key = keys[r];
+            idx = b + (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+            val = unordered_bits((uint32_t)(key >> 32));
+        }
+        out_idx[(int64_t)seg * k + r] = idx;
+        if (out_val) out_val[(int64_t)seg * k + r] = val;
+    }
+    if (tid == 0) out_cnt[seg] = (int64_t)kk;
+}
+
+}  // namespace swat
+
+SWAT_API int swat_sim_segmented(const float* feats, int64_t n_rows, int d, const float* queries,
+                                const int32_t* row_seg, float* sims, swat_stream_t stream) {
+    SWAT_REQUIRE(d > 0 && d % swat::KC == 0, "swat_sim_segmented: d=%d must be a positive multiple of %d", d, swat::KC);
+    SWAT_REQUIRE(n_rows >= 0, "swat_sim_segmented: negative n_rows");
+    if (n_rows == 0) return 0;
+    SWAT_REQUIRE(feats && queries && sims, "swat_sim_segmented: null pointer");
+    const int64_t blocks = (n_rows + 255) / 256;
+    SWAT_REQUIRE(blocks < (1ll << 31), "swat_sim_segmented: too many rows for one launch");
+    hipLaunchKernelGGL(swat::sim_segmented_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, feats,
+                       n_rows, d, queries, row_seg, sims);
+    return swat::check_launch("swat_sim_segmented");
+}
+
+SWAT_API int swat_segment_topk(const float* sims, const float* t2i, const uint8_t* excluded,
+                               const int64_t* seg_offsets, int64_t n_seg, float thr, float t2i_thr, int k,
+                               int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream) {
+    SWAT_REQUIRE(k >= 1 && k <= swat::TOPK_MAX, "swat_segment_topk: k=%d outside [1,%d]", k, swat::TOPK_MAX);
+    SWAT_REQUIRE(n_seg >= 0 && n_seg < (1ll << 31), "swat_segment_topk: bad n_seg");
+    if (n_seg == 0) return 0;
+    SWAT_REQUIRE(sims && seg_offsets && out_idx && out_cnt, "swat_segment_topk: null pointer");
+    hipLaunchKernelGGL(swat::segment_topk_kernel, dim3((unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, sims, t2i,
+                       excluded, seg_offsets, thr, t2i_thr, k, out_idx, out_val, out_cnt);
+    return swat::check_launch("swat_segment_topk");
+}

@@ -1,0 +1,43 @@
+"""Path B device ops (thin wrappers over the C ABI; see include/swat_hip.h)."""
+import torch
+
+from .. import _lib
+
+
+def similarity_segmented(feats, queries, row_seg=None, out=None):
+    """sims[i] = <feats[i], queries[row_seg[i]]> — ONE fp32 fma chain over k ascending.
+
+    ref: retrieval/sample_retrieval.py:397-416 (t2t_similarity), :335-353 (cal_t2i_similarity).
+    feats [N,d] fp32 cuda, queries [S,d] fp32 cuda, row_seg [N] int32 cuda or None."""
+    assert feats.dtype == torch.float32 and queries.dtype == torch.float32
+    n, d = feats.shape
+    if row_seg is not None:
+        assert row_seg.dtype == torch.int32 and row_seg.numel() == n
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=feats.device)
+    rc = _lib.lib().swat_sim_segmented(_lib.ptr(feats), n, d, _lib.ptr(queries), _lib.ptr(row_seg), _lib.ptr(out),
+                                       _lib.stream())
+    _lib.check(rc, "swat_sim_segmented")
+    return out
+
+
+def segment_topk(sims, seg_offsets, k, thr=0.0, t2i=None, t2i_thr=0.25, excluded=None):
+    """Filtered segmented top-k in (sim desc, row asc) order.
+
+    ref: sorted(..., reverse=True) :754/:807 + add_to_split :439-482 / add_t2t_ranked_t2i_tshd_to_split :492-540.
+    Returns (idx [S,k] int64 (-1 padded), val [S,k] fp32, cnt [S] int64)."""
+    assert sims.dtype == torch.float32 and seg_offsets.dtype == torch.int64
+    n_seg = seg_offsets.numel() - 1
+    dev = sims.device
+    idx = torch.empty((n_seg, k), dtype=torch.int64, device=dev)
+    val = torch.empty((n_seg, k), dtype=torch.float32, device=dev)
+    cnt = torch.empty(n_seg, dtype=torch.int64, device=dev)
+    if t2i is not None:
+        assert t2i.dtype == torch.float32 and t2i.numel() == sims.numel()
+    if excluded is not None:
+        assert excluded.dtype == torch.uint8 and excluded.numel() == sims.numel()
+    rc = _lib.lib().swat_segment_topk(_lib.ptr(sims), _lib.ptr(t2i), _lib.ptr(excluded), _lib.ptr(seg_offsets), n_seg,
+                                      float(thr), float(t2i_thr), int(k), _lib.ptr(idx), _lib.ptr(val), _lib.ptr(cnt),
+                                      _lib.stream())
+    _lib.check(rc, "swat_segment_topk")
+    return idx, val, cnt

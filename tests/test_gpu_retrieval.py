@@ -1,0 +1,150 @@
+"""GPU: path B HIP kernels (through the C ABI) against the C oracle and the reference's golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import retrieval_oracle as orc
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _load(golden_dir, kind):
+    g = np.load(os.path.join(golden_dir, f"retrieval_{kind}.npz"), allow_pickle=False)
+    spec = json.loads(str(g["spec"]))
+    return g, spec, synth.retrieval_case(**spec)
+
+
+@pytest.mark.parametrize("kind", ["grid", "float"])
+def test_group_by_matches_reference(golden_dir, kind):
+    from swat_amd.retrieval import group_by_label
+    g, spec, case = _load(golden_dir, kind)
+    order, cls, off = group_by_label(torch.from_numpy(case["labels"]).to(_dev()))
+    assert np.array_equal(order.cpu().numpy(), g["group_order"])
+    assert np.array_equal(cls.cpu().numpy(), g["group_classes"])
+    assert np.array_equal(np.diff(off.cpu().numpy()), g["group_sizes"])
+
+
+@pytest.mark.parametrize("kind", ["grid", "float"])
+@pytest.mark.parametrize("name,kw", [("t2t", dict(rank_by="t2t", use_t2i_thr=False)),
+                                     ("t2t_t2i", dict(rank_by="t2t", use_t2i_thr=True)),
+                                     ("t2i", dict(rank_by="t2i"))])
+def test_samplers_match_reference_golden(golden_dir, kind, name, kw):
+    """Bit-exact kept rows / counts / <prefix>.txt bytes vs what the reference's own samplers produced."""
+    from swat_amd.retrieval import SegmentedIndex
+    g, spec, case = _load(golden_dir, kind)
+    dev = _dev()
+    index = SegmentedIndex(torch.from_numpy(case["img"]), torch.from_numpy(case["cap"]),
+                           torch.from_numpy(case["labels"]), case["paths"], device=dev)
+    excl = torch.from_numpy((case["excl_dup"] | case["excl_filt"]).astype(np.uint8)).to(dev)[index.order].contiguous()
+    q = torch.from_numpy(case["queries"]).to(dev)
+    idx, val, cnt, sims, t2i = index.sample(q, spec["k"], excluded=excl, **kw)
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    order = index.order.cpu().numpy()
+    rows = np.concatenate([order[idx[s, :cnt[s]]] for s in range(index.n_seg)])
+    assert np.array_equal(rows, g[f"{name}_rows"])
+    assert {str(int(c)): int(n) for c, n in zip(index.class_ids.tolist(), cnt)} == json.loads(str(g[f"{name}_counts"]))
+    assert orc.sample_file_list_text(index.filepath, index.class_ids.tolist(), idx, cnt) == str(g[f"{name}_txt"])
+    assert (idx[np.arange(idx.shape[1])[None, :] >= cnt[:, None]] == -1).all()
+    # similarities: bit-exact vs the oracle's canonical fma chain (and vs the reference on the exact-arithmetic grid)
+    src = case["img"] if kw["rank_by"] == "t2i" else case["cap"]
+    o_order, o_cls, o_off = orc.group_by_label(case["labels"])
+    _, _, o_sims, _ = orc.sample_index(case["cap"][o_order], case["img"][o_order], case["queries"], o_off, spec["k"],
+                                       return_sims=True, **kw)
+    assert np.array_equal(sims.cpu().numpy(), o_sims)
+    if kind == "grid":
+        ref = g["sims_t2i" if kw["rank_by"] == "t2i" else "sims_t2t"][order]
+        assert np.array_equal(sims.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n,d,nseg,k", [(1, 512, 1, 5), (63, 512, 1, 64), (64, 64, 2, 1), (65, 768, 3, 500),
+                                         (1000, 1024, 7, 2048), (20000, 512, 20, 500), (70000, 512, 3, 500)])
+def test_sim_and_topk_vs_oracle_seeded(n, d, nseg, k):
+    """Seeded random + ragged segments (incl. empty ones), ties, -0.0, masks: bit-exact vs the C oracle."""
+    from swat_amd.retrieval import ops
+    dev = _dev()
+    rs = np.random.RandomState(n * 7 + d)
+    feats = synth.unit_rows(rs, n, d)
+    img = synth.unit_rows(rs, n, d)
+    for _ in range(n // 10):  # exact ties
+        a, b = rs.randint(n), rs.randint(n)
+        feats[a] = feats[b]
+    queries = synth.unit_rows(rs, nseg, d)
+    cuts = np.sort(rs.randint(0, n + 1, size=nseg - 1)) if nseg > 1 else np.zeros(0, np.int64)
+    off = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    if nseg > 2:
+        off[2] = off[1]  # an empty segment
+    row_seg = np.repeat(np.arange(nseg, dtype=np.int32), np.diff(off))
+    excl = (rs.rand(n) < 0.1).astype(np.uint8)
+    o_idx, o_cnt, o_sims, o_t2i = orc.sample_index(feats, img, queries, off, k, use_t2i_thr=True, t2i_thr=0.0,
+                                                   excluded=excl, return_sims=True)
+    f = torch.from_numpy(feats).to(dev)
+    i = torch.from_numpy(img).to(dev)
+    q = torch.from_numpy(queries).to(dev)
+    rsg = torch.from_numpy(row_seg).to(dev)
+    sims = ops.similarity_segmented(f, q, rsg)
+    t2i = ops.similarity_segmented(i, q, rsg)
+    assert np.array_equal(sims.cpu().numpy(), o_sims)
+    assert np.array_equal(t2i.cpu().numpy(), o_t2i)
+    idx, val, cnt = ops.segment_topk(sims, torch.from_numpy(off).to(dev), k, thr=0.0, t2i=t2i, t2i_thr=0.0,
+                                     excluded=torch.from_numpy(excl).to(dev))
+    assert np.array_equal(cnt.cpu().numpy(), o_cnt)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    got_val = val.cpu().numpy()
+    for s in range(nseg):
+        assert np.array_equal(got_val[s, :o_cnt[s]], o_sims[o_idx[s, :o_cnt[s]]])
+
+
+def test_topk_negative_zero_and_all_filtered():
+    from swat_amd.retrieval import ops
+    dev = _dev()
+    s = torch.tensor([0.0, -0.0, 0.0, 1.0, -0.0, -1.0, -2.0], device=dev)
+    off = torch.tensor([0, 5, 7, 7], device=dev)
+    idx, val, cnt = ops.segment_topk(s, off, 5, thr=0.0)
+    assert idx.cpu().tolist() == [[3, 0, 1, 2, 4], [-1] * 5, [-1] * 5]
+    assert cnt.cpu().tolist() == [5, 0, 0]
+    idx, val, cnt = ops.segment_topk(s, off, 2, thr=-10.0)
+    assert idx.cpu().tolist() == [[3, 0], [5, 6], [-1, -1]]
+
+
+def test_full_size_properties():
+    """BASELINE-size shard (1.25 M x 512, the per-GPU share of 10 M rows): size-independent properties."""
+    from swat_amd.retrieval import ops
+    dev = _dev()
+    n, d, nseg, k = 1_250_000, 512, 125, 500
+    g = torch.Generator(device=dev).manual_seed(7)
+    feats = torch.randn(n, d, device=dev, generator=g)
+    feats /= feats.norm(dim=-1, keepdim=True)
+    q = torch.randn(nseg, d, device=dev, generator=g)
+    q /= q.norm(dim=-1, keepdim=True)
+    off = torch.arange(0, n + 1, n // nseg, device=dev, dtype=torch.int64)
+    row_seg = torch.repeat_interleave(torch.arange(nseg, device=dev, dtype=torch.int32), n // nseg)
+    sims = ops.similarity_segmented(feats, q, row_seg)
+    # linearity / agreement with an independent fp64 product on a slice
+    ref = (feats[:4096].double() * q[row_seg[:4096].long()].double()).sum(-1)
+    assert (sims[:4096].double() - ref).abs().max().item() < 1e-6
+    idx, val, cnt = ops.segment_topk(sims, off, k, thr=-2.0)
+    assert (cnt == k).all()
+    # sortedness (value desc, row asc on ties), membership in the right segment, idempotence
+    assert (val[:, 1:] <= val[:, :-1]).all()
+    ties = val[:, 1:] == val[:, :-1]
+    assert (idx[:, 1:][ties] > idx[:, :-1][ties]).all()
+    assert ((idx >= off[:-1, None]) & (idx < off[1:, None])).all()
+    assert torch.equal(sims[idx], val)
+    # the k-th value really is the k-th largest of its segment
+    seg_sims = sims.view(nseg, -1)
+    assert torch.equal(torch.topk(seg_sims, k, dim=1).values, val)
+    idx2, val2, _ = ops.segment_topk(sims, off, k, thr=-2.0)
+    assert torch.equal(idx, idx2) and torch.equal(val, val2)
+    # oracle on the first two segments (20 k rows: seconds on the CPU)
+    sub = feats[: 2 * (n // nseg)].cpu().numpy()
+    o_idx, o_cnt = orc.sample_index(sub, None, q[:2].cpu().numpy(), off[:3].cpu().numpy(), k, thr=-2.0)
+    assert np.array_equal(idx[:2].cpu().numpy(), o_idx)

@@ -52,6 +52,119 @@ int swat_segment_topk(const float* sims, const float* t2i, const uint8_t* exclud
                       const int64_t* seg_offsets, int64_t n_seg, float thr, float t2i_thr, int k,
                       int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Path A — OpenCLIP ViT finetuning step (ref: utils/training.py train_ce :326-347,
+ * train_cutmix :1452-1489; the ViT arithmetic is open_clip 2.26.1's VisionTransformer)
+ * ------------------------------------------------------------------------------------------ */
+
+/* A2a,c,e,f,h  bf16 MFMA GEMM, fp32 accumulate, fused epilogue.  layout 0 = NT (Y = X W^T, forward),
+ *     1 = NN (dX = dY W, dgrad), 2 = TN (dW = dY^T X, wgrad).  Replaces nn.Linear / conv1 /
+ *     nn.MultiheadAttention matmuls and their autograd (cuBLAS in the reference).
+ *     Batched: block z uses offsets (z / inner) * s?0 + (z % inner) * s?1 (elements).
+ *     Epilogue: v = alpha*acc (+bias[n]) (+residual[m,n] fp32, may alias C) (*act'(actin[m,n]));
+ *     C is bf16 or fp32 (out_f32); C2 (bf16, optional) = act(C) with act 1 = QuickGELU, 2 = erf-GELU.
+ *     lda/ldb multiples of 8, ldc multiple of 4 and >= roundup(N,4). */
+int swat_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda,
+                   int ldb, int ldc, int batch, int inner, int64_t sA0, int64_t sA1, int64_t sB0,
+                   int64_t sB1, int64_t sC0, int64_t sC1, const float* bias, const float* residual,
+                   const void* actin, int ldact, int act, void* C2, int out_f32, float alpha,
+                   swat_stream_t stream);
+
+/* A2b,f,g  LayerNorm (eps inside rsqrt, biased variance = torch.nn.LayerNorm). x fp32 with an explicit
+ *     row stride (so the cls rows of [B,T,d] can be normalised in place); y in bf16 and/or fp32. */
+int swat_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
+                       void* y_bf16, float* y_f32, float* mean, float* rstd, int rows, int d,
+                       float eps, swat_stream_t stream);
+int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d);
+/*     dx_out = (dx_add ? dx_add : 0) + LN'(dy); optional bf16 copy; dgamma/dbeta reduced in a fixed
+ *     order through `workspace` (deterministic). */
+int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float* x, int64_t x_stride,
+                       const float* gamma, const float* mean, const float* rstd, const float* dx_add,
+                       int64_t dxa_stride, float* dx_out, int64_t dxo_stride, void* dx_bf16,
+                       int64_t dxb_stride, float* dgamma, float* dbeta, void* workspace, int rows,
+                       int d, swat_stream_t stream);
+
+/* A2d  attention softmax over score rows (fp32 S, ld = padded T): P = softmax(scale*S[:, :T]) bf16,
+ *     pad columns zeroed; causal!=0 for the text tower.  Backward: dS = scale*P o (dP - rowsum(P o dP)). */
+int swat_softmax_fwd(const float* S, void* P_bf16, int64_t rows, int Tq, int T, int ld, float scale,
+                     int causal, swat_stream_t stream);
+int swat_softmax_bwd(const void* P_bf16, const float* dP, void* dS_bf16, int64_t rows, int T, int ld,
+                     float scale, swat_stream_t stream);
+
+/* A5 + A2a  CutMix box paste fused with patch extraction and the bf16 cast:
+ *     patches[b*g*g + p, k] = images[src(b,y,x), c, y, x], src = perm[b] inside [x1,x2) x [y1,y2)
+ *     (dims 2,3; ref utils/training.py:1466), k = c*ps*ps + (y%ps)*ps + (x%ps).  perm NULL = no mix. */
+int swat_patchify_cutmix(const float* images, const int64_t* perm, void* patches_bf16, int B, int H,
+                         int W, int patch, int ldp, int x1, int x2, int y1, int y2,
+                         swat_stream_t stream);
+/* A5  the paste alone (out of place; dst must not alias src). */
+int swat_cutmix_paste(const float* src, const int64_t* perm, float* dst, int B, int H, int W, int x1,
+                      int x2, int y1, int y2, swat_stream_t stream);
+/* A2b  x[b,0,:] = class_embedding + positional_embedding[0]. */
+int swat_cls_row(float* x, const float* cls, const float* pos, int B, int T, int d,
+                 swat_stream_t stream);
+
+/* A2h  bias gradients: out[n] = sum over rows of X[:, n] (bf16 or fp32), fixed summation order.
+ *     Optional row grouping (logical row r -> (r/group_rows)*group_stride_rows + r%group_rows + row_off). */
+int swat_colsum(const void* X, int dtype, int64_t rows, int n, int ld, float* out, int64_t group_rows,
+                int64_t group_stride_rows, int64_t row_off, swat_stream_t stream);
+int swat_gather_cast_bf16(const float* in, void* out_bf16, int64_t rows, int d, int64_t group_rows,
+                          int64_t group_stride_rows, int64_t row_off, swat_stream_t stream);
+int swat_cast_bf16(const float* in, void* out_bf16, int64_t n, swat_stream_t stream);
+
+/* A7  fused multi-group AdamW over one flat fp32 buffer (torch.optim.AdamW semantics, ref
+ *     utils/optimizers.py:131-146) + refresh of the bf16 shadow weights.  seg_begin: HOST array of
+ *     n_seg group start offsets (first = 0); lrs_dev [n_seg] and bias_corr_dev {1-b1^t, 1-b2^t} live
+ *     on the device so a captured step replays with new values. */
+int swat_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+               int64_t n, const int64_t* seg_begin, int n_seg, const float* lrs_dev, float beta1,
+               float beta2, float eps, float weight_decay, const float* bias_corr_dev,
+               float grad_scale, swat_stream_t stream);
+
+/* A3  L2 normalise rows, no eps (ref utils/training.py:333,1475) and its backward. */
+int swat_l2norm_fwd(const float* x, float* y, float* norms, int rows, int d, swat_stream_t stream);
+int swat_l2norm_bwd(const float* y, const float* norms, const float* dy, float* dx, int rows, int d,
+                    swat_stream_t stream);
+/* A4  small strided fp32 GEMM (head / proj and their gradients; M = batch):
+ *     C[m,n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+= if accumulate). */
+int swat_sgemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam,
+                     int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, float alpha, int accumulate,
+                     swat_stream_t stream);
+/* A6  mixed cross entropy on logits = z * exp(logit_scale) (ref mixup_criterion :1157-1158 over
+ *     nn.CrossEntropyLoss mean reduction): loss, d loss/d z, d loss/d logit_scale; lam = 1, yb = ya
+ *     gives plain CE (train_ce).  per_sample_ws: 2*B floats.  loss_accum (optional, float64) += loss. */
+int swat_ce_mixed(const float* z, const float* logit_scale_dev, const int64_t* ya, const int64_t* yb,
+                  float lam, float* per_sample_ws, float* loss, float* dlogit_scale, float* dz,
+                  float* logits_out, double* loss_accum, int B, int C, swat_stream_t stream);
+
+/* A2 (whole)  model.encode_image(images) as one call: CutMix-aware patch embed, cls/pos, ln_pre, L
+ *     pre-LN blocks, ln_post(cls), proj -> feats [B,E] fp32 (un-normalised).
+ *     dims (HOST int32[10]): B, image_size, patch, width d, layers L, heads H, mlp width, embed E,
+ *     act (1 QuickGELU / 2 erf-GELU), save_for_backward.
+ *     offs (HOST int64[8 + 12*L], elements into params / shadow): conv1.weight, class_embedding,
+ *     positional_embedding, ln_pre.{w,b}, ln_post.{w,b}, proj, then per block ln_1.{w,b},
+ *     attn.in_proj_{weight,bias}, attn.out_proj.{weight,bias}, ln_2.{w,b}, mlp.c_fc.{weight,bias},
+ *     mlp.c_proj.{weight,bias}.  params = fp32 master, shadow_bf16 = bf16 copy at the same offsets.
+ *     perm/x1..y2: CutMix permutation and box (ref utils/training.py:1462-1466), perm NULL = none. */
+int64_t swat_vit_workspace_bytes(const int32_t* dims);
+int swat_vit_forward(const int32_t* dims, const int64_t* offs, const float* params,
+                     const void* shadow_bf16, const float* images, const int64_t* perm, int x1, int x2,
+                     int y1, int y2, void* workspace, float* feats, swat_stream_t stream);
+/* A2h  backward of the above in stages (L+1: proj+ln_post, l+1: block l, 0: stem), run from stage_hi
+ *     down to stage_lo, so the host can reduce a stage's gradients while the next one runs.
+ *     Gradients are written (not accumulated) into `grads` at the parameters' offsets. */
+int swat_vit_backward(const int32_t* dims, const int64_t* offs, const float* params,
+                      const void* shadow_bf16, void* workspace, const float* dfeats, float* grads,
+                      int stage_hi, int stage_lo, swat_stream_t stream);
+/* A3+A4+A6 fused with their backward (ref utils/training.py:1475-1481): loss, d/dfeats, d/dW_head,
+ *     d/dlogit_scale.  want_grad = 0: forward only (validate, testing.py:430-447); z_out / feat_norm_out
+ *     optionally receive the un-scaled head output and the normalised features. */
+int64_t swat_head_loss_workspace_bytes(int B, int E, int C);
+int swat_head_loss(const float* feats, const float* W, const float* logit_scale_dev, const int64_t* ya,
+                   const int64_t* yb, float lam, void* workspace, float* loss, float* dfeats, float* dW,
+                   float* dlogit_scale, float* z_out, float* feat_norm_out, double* loss_accum, int B,
+                   int E, int C, int want_grad, swat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,15 +10,29 @@ _lib = None
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
-# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/swat_hip.h
-_PROTOS = {
-    "swat_version": [],
-    "swat_last_error": [],
-    "swat_sim_segmented": [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
-    "swat_segment_topk": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int,
-                          c_void_p, c_void_p, c_void_p, c_void_p],
-}
-_RESTYPES = {"swat_last_error": ctypes.c_char_p}
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "swat_hip.h")
+_CTYPES = {"int": c_int, "int64_t": c_int64, "float": c_float, "swat_stream_t": c_void_p}
+
+
+def _parse_header():
+    """Prototypes straight from include/swat_hip.h, so the binding cannot drift from the ABI."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    protos, restypes = {}, {}
+    for ret, name, args in re.findall(r"([A-Za-z_][\w\s\*]*?)\b(swat_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        ret = ret.strip()
+        argtypes = []
+        for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
+            if "*" in a:
+                argtypes.append(c_void_p)
+            else:
+                argtypes.append(_CTYPES[a.replace("const", "").split()[0]])
+        protos[name] = argtypes
+        restypes[name] = ctypes.c_char_p if "char" in ret else (c_int64 if "int64_t" in ret else c_int)
+    return protos, restypes
+
+
+_PROTOS, _RESTYPES = _parse_header()
 
 
 class SwatHipError(RuntimeError):
@@ -42,7 +56,7 @@ def lib():
         for name, argtypes in _PROTOS.items():
             fn = getattr(h, name)  # AttributeError if the .so is stale: loud by design
             fn.argtypes = argtypes
-            fn.restype = _RESTYPES.get(name, c_int)
+            fn.restype = _RESTYPES[name]
         _lib = h
     return _lib
 

@@ -1,0 +1,479 @@
+// swat_amd/csrc/elementwise.hip — HBM-bound kernels of path A for gfx950: LayerNorm fwd/bwd, row softmax
+// fwd/bwd (attention), CutMix paste + patchify, bias-gradient column sums, fused multi-group AdamW.
+//
+// ref: open_clip VisionTransformer pieces called through model.encode_image (utils/training.py:332,1474),
+// CutMix paste utils/training.py:1458-1472, AdamW + LR groups utils/optimizers.py:22-35,131-146.
+#include "common.hpp"
+#include "../../include/swat_hip.h"
+
+namespace swat {
+
+// --------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row; x fp32 [rows, d] -> y bf16 (and/or fp32), mean/rstd fp32.
+// Two-pass in registers (row cached: d <= 64*4*MAXV floats).
+// --------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 5;  // float4 per lane: d <= 1280
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t x_row_stride,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     unsigned short* __restrict__ y_bf, float* __restrict__ y_f32,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows, int d,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * x_row_stride);
+    const int nv = d >> 2;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
+            q += a * a + b * b + cc * cc + dd * dd;
+        }
+    }
+    const float var = wave_sum(q) / (float)d;
+    const float rs = rsqrtf(var + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
+            const float4 bt = reinterpret_cast<const float4*>(beta)[c];
+            const float o0 = (v[i].x - mu) * rs * gm.x + bt.x, o1 = (v[i].y - mu) * rs * gm.y + bt.y;
+            const float o2 = (v[i].z - mu) * rs * gm.z + bt.z, o3 = (v[i].w - mu) * rs * gm.w + bt.w;
+            if (y_bf)
+                reinterpret_cast<ushort4*>(y_bf + (int64_t)row * d)[c] = make_ushort4(f2bf(o0), f2bf(o1), f2bf(o2), f2bf(o3));
+            if (y_f32) reinterpret_cast<float4*>(y_f32 + (int64_t)row * d)[c] = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// LayerNorm backward.  dy fp32 [rows,d] (row stride dy_stride), x fp32 (row stride x_stride).
+//   dx_out[row] = (dx_add ? dx_add[row] : 0) + rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat))
+// dx_out fp32 (+ optional bf16 copy).  Per-block partial dgamma/dbeta go to part[blockIdx][2][d];
+// ln_bwd_reduce sums them in a fixed order (deterministic, no float atomics).
+// Each block = 4 waves; each wave walks rows  wave_global, wave_global + nwaves, ...
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int64_t dy_stride,
+                                                     const float* __restrict__ x, int64_t x_stride,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* dx_add,
+                                                     int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
+                                                     unsigned short* __restrict__ dx_bf, int64_t dxb_stride,
+                                                     float* __restrict__ part, int rows, int d) {
+    __shared__ float sh[2][4][64 * 4 * LN_MAXV];  // [dg/db][wave][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = d >> 2;
+    float4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[i] = dg[i];
+        const int c = lane + 64 * i;
+        gm[i] = c < nv ? reinterpret_cast<const float4*>(gamma)[c] : dg[i];
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * dy_stride);
+        const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * x_stride);
+        const float mu = mean[row], rs = rstd[row];
+        float4 dyv[LN_MAXV], xh[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                dyv[i] = dyr[c];
+                const float4 xv = xr[c];
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                const float a0 = dyv[i].x * gm[i].x, a1 = dyv[i].y * gm[i].y, a2 = dyv[i].z * gm[i].z, a3 = dyv[i].w * gm[i].w;
+                s1 += a0 + a1 + a2 + a3;
+                s2 += a0 * xh[i].x + a1 * xh[i].y + a2 * xh[i].z + a3 * xh[i].w;
+                dg[i].x += dyv[i].x * xh[i].x; dg[i].y += dyv[i].y * xh[i].y;
+                dg[i].z += dyv[i].z * xh[i].z; dg[i].w += dyv[i].w * xh[i].w;
+                db[i].x += dyv[i].x; db[i].y += dyv[i].y; db[i].z += dyv[i].z; db[i].w += dyv[i].w;
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float4 o;
+                o.x = rs * (dyv[i].x * gm[i].x - m1 - xh[i].x * m2);
+                o.y = rs * (dyv[i].y * gm[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (dyv[i].z * gm[i].z - m1 - xh[i].z * m2);
+                o.w = rs * (dyv[i].w * gm[i].w - m1 - xh[i].w * m2);
+                if (dx_add) {
+                    const float4 a = reinterpret_cast<const float4*>(dx_add + (int64_t)row * dxa_stride)[c];
+                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                }
+                if (dx_out) reinterpret_cast<float4*>(dx_out + (int64_t)row * dxo_stride)[c] = o;
+                if (dx_bf)
+                    reinterpret_cast<ushort4*>(dx_bf + (int64_t)row * dxb_stride)[c] = make_ushort4(f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w));
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            reinterpret_cast<float4*>(sh[0][wave])[c] = dg[i];
+            reinterpret_cast<float4*>(sh[1][wave])[c] = db[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        part[((int64_t)blockIdx.x * 2 + 0) * d + c] = ((sh[0][0][c] + sh[0][1][c]) + sh[0][2][c]) + sh[0][3][c];
+        part[((int64_t)blockIdx.x * 2 + 1) * d + c] = ((sh[1][0][c] + sh[1][1][c]) + sh[1][2][c]) + sh[1][3][c];
+    }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int d, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < nblk; ++i) {
+        a += part[((int64_t)i * 2 + 0) * d + c];
+        b += part[((int64_t)i * 2 + 1) * d + c];
+    }
+    dgamma[c] = a;
+    dbeta[c] = b;
+}
+
+// --------------------------------------------------------------------------------------------
+// Attention softmax over rows of S (bf16 or f32 scores, ld = lds): P = softmax(scale * S[:, :T]) in bf16,
+// columns T..lds-1 are written as ZERO (they pad the reduction of the P*V GEMM).  One wave per row.
+// causal != 0 masks j > (row % T_q) (text tower).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, unsigned short* __restrict__ P,
+                                                          int64_t rows, int Tq, int T, int ld, float scale, int causal) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + row * ld;
+    const int qi = (int)(row % Tq);
+    const int lim = causal ? (qi + 1 < T ? qi + 1 : T) : T;
+    float mx = -INFINITY;
+    for (int j = lane; j < lim; j += 64) mx = fmaxf(mx, s[j] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < lim; j += 64) sum += __expf(s[j] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    unsigned short* p = P + row * ld;
+    for (int j = lane; j < ld; j += 64) p[j] = j < lim ? f2bf(__expf(s[j] * scale - mx) * inv) : (unsigned short)0;
+}
+
+// dS = scale * P o (dP - rowsum(P o dP)); P bf16, dP f32, dS bf16; pad columns -> 0.
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short* __restrict__ P,
+                                                          const float* __restrict__ dP, unsigned short* __restrict__ dS,
+                                                          int64_t rows, int T, int ld, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const unsigned short* p = P + row * ld;
+    const float* dp = dP + row * ld;
+    float dot = 0.f;
+    for (int j = lane; j < T; j += 64) dot += bf2f(p[j]) * dp[j];
+    dot = wave_sum(dot);
+    unsigned short* ds = dS + row * ld;
+    for (int j = lane; j < ld; j += 64) ds[j] = j < T ? f2bf(scale * bf2f(p[j]) * (dp[j] - dot)) : (unsigned short)0;
+}
+
+// --------------------------------------------------------------------------------------------
+// CutMix paste + patchify + cast (A5 + the im2col of A2a): images fp32 [B,3,H,W] -> patches bf16
+// [B*gh*gw, ldp] with k = c*p*p + py*p + px (conv1.weight's own flattening); pixels inside the box
+// [x1,x2) x [y1,y2) (dims 2,3 — ref utils/training.py:1466) come from images[perm[b]].  Reads a gathered
+// copy, never permutes in place.  perm == nullptr or empty box -> plain patchify.
+// One thread per 8 consecutive k (16-B store); columns K..ldp-1 are zero.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_cutmix_kernel(const float* __restrict__ img, const int64_t* __restrict__ perm,
+                                                              unsigned short* __restrict__ out, int Bn, int H, int W,
+                                                              int ps, int ldp, int x1, int x2, int y1, int y2) {
+    const int gw = W / ps, gh = H / ps;
+    const int K = 3 * ps * ps;
+    const int chunks = ldp / 8;
+    const int64_t total = (int64_t)Bn * gh * gw * chunks;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ck = (int)(idx % chunks);
+        const int64_t prow = idx / chunks;
+        const int b = (int)(prow / (gh * gw));
+        const int pr = (int)(prow % (gh * gw));
+        const int py0 = (pr / gw) * ps, px0 = (pr % gw) * ps;
+        unsigned short v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ck * 8 + e;
+            float f = 0.f;
+            if (k < K) {
+                const int c = k / (ps * ps), rem = k % (ps * ps);
+                const int yy = py0 + rem / ps, xx = px0 + rem % ps;  // yy: dim 2, xx: dim 3
+                int sb = b;
+                if (perm && yy >= x1 && yy < x2 && xx >= y1 && xx < y2) sb = (int)perm[b];
+                f = img[(((int64_t)sb * 3 + c) * H + yy) * W + xx];
+            }
+            v[e] = f2bf(f);
+        }
+        *reinterpret_cast<uint4*>(out + prow * ldp + ck * 8) = *reinterpret_cast<const uint4*>(v);
+    }
+}
+
+// In-place CutMix paste on an fp32 image batch through a gathered copy of the box (for callers that
+// want the mixed images themselves, e.g. parity tests of A5): dst may not alias src.
+__global__ void cutmix_paste_kernel(const float* __restrict__ src, const int64_t* __restrict__ perm, float* __restrict__ dst,
+                                    int Bn, int H, int W, int x1, int x2, int y1, int y2) {
+    const int64_t total = (int64_t)Bn * 3 * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W), yy = (int)((i / W) % H);
+        const int64_t bc = i / ((int64_t)H * W);
+        const int b = (int)(bc / 3), c = (int)(bc % 3);
+        int sb = b;
+        if (yy >= x1 && yy < x2 && xx >= y1 && xx < y2) sb = (int)perm[b];
+        dst[i] = src[(((int64_t)sb * 3 + c) * H + yy) * W + xx];
+    }
+}
+
+// x[b, 0, :] = class_embedding + positional_embedding[0]   (A2b, cls row)
+__global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int Bn,
+                               int T, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bn * d) return;
+    const int b = i / d, c = i % d;
+    x[((int64_t)b * T) * d + c] = cls[c] + pos[c];
+}
+
+// --------------------------------------------------------------------------------------------
+// Column sums (bias gradients): out[n] = sum_m X[m, n], X bf16 or f32 [rows, ld].  Block = 64 columns x 4
+// row-lanes; rows are walked in a fixed order -> deterministic.
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t rows, int n, int ld,
+                                                     float* __restrict__ out, int64_t group_rows, int64_t group_stride_rows,
+                                                     int64_t row_off) {
+    // optional row grouping: logical row r -> physical (r / group_rows) * group_stride_rows + (r % group_rows) + row_off
+    __shared__ float sh[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (col < n) {
+        for (int64_t r = rl; r < rows; r += 4) {
+            const int64_t pr = group_rows > 0 ? (r / group_rows) * group_stride_rows + (r % group_rows) + row_off : r;
+            float v;
+            if constexpr (sizeof(T) == 2) v = bf2f(X[pr * ld + col]); else v = X[pr * ld + col];
+            acc += v;
+        }
+    }
+    sh[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && col < n) out[col] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
+// gather rows + cast fp32 -> bf16: out[r, :] = in[(r / g) * gs + (r % g) + off, :]
+__global__ void gather_cast_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int64_t rows, int d,
+                                   int64_t g, int64_t gs, int64_t off) {
+    const int64_t total = rows * (d / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (d / 4);
+        const int c = (int)(i % (d / 4));
+        const int64_t pr = g > 0 ? (r / g) * gs + (r % g) + off : r;
+        const float4 v = reinterpret_cast<const float4*>(in + pr * d)[c];
+        reinterpret_cast<ushort4*>(out + r * d)[c] = make_ushort4(f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w));
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Fused multi-group AdamW over ONE flat parameter buffer (A7).  torch.optim.AdamW semantics
+// (ref: utils/optimizers.py:131-146; decoupled decay, bias correction, eps outside the sqrt-correction):
+//   p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// Groups are contiguous segments [seg_begin[i], seg_begin[i+1]) with their own lr (device array so the
+// step is graph-capturable).  Also refreshes the bf16 shadow copy the GEMMs read.
+// --------------------------------------------------------------------------------------------
+struct AdamSegs {
+    int64_t begin[5];
+    int n;
+};
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, unsigned short* __restrict__ shadow, int64_t n,
+                                                    AdamSegs segs, const float* __restrict__ lrs, float beta1, float beta2,
+                                                    float eps, float wd, const float* __restrict__ bc /* [2]: 1-b1^t, 1-b2^t */,
+                                                    float grad_scale) {
+    const float bc1 = bc[0], sbc2 = sqrtf(bc[1]);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i << 2;
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+        float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int s = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) s += (q < segs.n && e + k >= segs.begin[q]) ? 1 : 0;
+            const float lr = lrs[s];
+            const float gg = ga[k] * grad_scale;
+            pa[k] *= 1.0f - lr * wd;
+            ma[k] = beta1 * ma[k] + (1.0f - beta1) * gg;
+            va[k] = beta2 * va[k] + (1.0f - beta2) * gg * gg;
+            const float denom = sqrtf(va[k]) / sbc2 + eps;
+            pa[k] -= (lr / bc1) * (ma[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
+        if (shadow) reinterpret_cast<ushort4*>(shadow)[i] = make_ushort4(f2bf(pa[0]), f2bf(pa[1]), f2bf(pa[2]), f2bf(pa[3]));
+    }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        reinterpret_cast<ushort4*>(out)[i] = make_ushort4(f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w));
+    }
+}
+
+static inline int grid_for(int64_t work, int per_block) {
+    int64_t b = (work + per_block - 1) / per_block;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace swat
+
+using namespace swat;
+
+SWAT_API int swat_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y_bf16,
+                                float* y_f32, float* mean, float* rstd, int rows, int d, float eps, swat_stream_t s) {
+    SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV, "swat_layernorm_fwd: d=%d unsupported", d);
+    SWAT_REQUIRE(x_row_stride % 4 == 0, "swat_layernorm_fwd: row stride must be a multiple of 4");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, x, x_row_stride, gamma, beta,
+                       (unsigned short*)y_bf16, y_f32, mean, rstd, rows, d, eps);
+    return check_launch("swat_layernorm_fwd");
+}
+
+SWAT_API int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d) {
+    (void)rows;
+    return (int64_t)256 * 2 * d * sizeof(float);
+}
+
+SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float* x, int64_t x_stride, const float* gamma,
+                                const float* mean, const float* rstd, const float* dx_add, int64_t dxa_stride,
+                                float* dx_out, int64_t dxo_stride, void* dx_bf16, int64_t dxb_stride, float* dgamma,
+                                float* dbeta, void* workspace, int rows, int d, swat_stream_t s) {
+    SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV, "swat_layernorm_bwd: d=%d unsupported", d);
+    if (rows <= 0) return 0;
+    int nblk = (rows + 3) / 4;
+    if (nblk > 256) nblk = 256;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
+                       dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float*)workspace,
+                       nblk, d, dgamma, dbeta);
+    return check_launch("swat_layernorm_bwd");
+}
+
+SWAT_API int swat_softmax_fwd(const float* S, void* P_bf16, int64_t rows, int Tq, int T, int ld, float scale, int causal,
+                              swat_stream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, S,
+                       (unsigned short*)P_bf16, rows, Tq, T, ld, scale, causal);
+    return check_launch("swat_softmax_fwd");
+}
+
+SWAT_API int swat_softmax_bwd(const void* P_bf16, const float* dP, void* dS_bf16, int64_t rows, int T, int ld, float scale,
+                              swat_stream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s,
+                       (const unsigned short*)P_bf16, dP, (unsigned short*)dS_bf16, rows, T, ld, scale);
+    return check_launch("swat_softmax_bwd");
+}
+
+SWAT_API int swat_patchify_cutmix(const float* images, const int64_t* perm, void* patches_bf16, int B, int H, int W,
+                                  int patch, int ldp, int x1, int x2, int y1, int y2, swat_stream_t s) {
+    SWAT_REQUIRE(H % patch == 0 && W % patch == 0, "swat_patchify_cutmix: image not divisible by patch");
+    SWAT_REQUIRE(ldp % 8 == 0 && ldp >= 3 * patch * patch, "swat_patchify_cutmix: bad ldp");
+    if (B <= 0) return 0;
+    const int64_t total = (int64_t)B * (H / patch) * (W / patch) * (ldp / 8);
+    hipLaunchKernelGGL(patchify_cutmix_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, images, perm,
+                       (unsigned short*)patches_bf16, B, H, W, patch, ldp, x1, x2, y1, y2);
+    return check_launch("swat_patchify_cutmix");
+}
+
+SWAT_API int swat_cutmix_paste(const float* src, const int64_t* perm, float* dst, int B, int H, int W, int x1, int x2,
+                               int y1, int y2, swat_stream_t s) {
+    SWAT_REQUIRE(src != dst, "swat_cutmix_paste: dst must not alias src (the paste reads a gathered copy)");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(cutmix_paste_kernel, dim3(grid_for((int64_t)B * 3 * H * W, 256)), dim3(256), 0, (hipStream_t)s, src,
+                       perm, dst, B, H, W, x1, x2, y1, y2);
+    return check_launch("swat_cutmix_paste");
+}
+
+SWAT_API int swat_cls_row(float* x, const float* cls, const float* pos, int B, int T, int d, swat_stream_t s) {
+    hipLaunchKernelGGL(cls_row_kernel, dim3((B * d + 255) / 256), dim3(256), 0, (hipStream_t)s, x, cls, pos, B, T, d);
+    return check_launch("swat_cls_row");
+}
+
+SWAT_API int swat_colsum(const void* X, int dtype, int64_t rows, int n, int ld, float* out, int64_t group_rows,
+                         int64_t group_stride_rows, int64_t row_off, swat_stream_t s) {
+    if (n <= 0) return 0;
+    if (dtype == SWAT_BF16)
+        hipLaunchKernelGGL((colsum_kernel<unsigned short>), dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)s,
+                           (const unsigned short*)X, rows, n, ld, out, group_rows, group_stride_rows, row_off);
+    else
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)s, (const float*)X, rows,
+                           n, ld, out, group_rows, group_stride_rows, row_off);
+    return check_launch("swat_colsum");
+}
+
+SWAT_API int swat_gather_cast_bf16(const float* in, void* out_bf16, int64_t rows, int d, int64_t group_rows,
+                                   int64_t group_stride_rows, int64_t row_off, swat_stream_t s) {
+    SWAT_REQUIRE(d % 4 == 0, "swat_gather_cast_bf16: d must be a multiple of 4");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(gather_cast_kernel, dim3(grid_for(rows * (d / 4), 256)), dim3(256), 0, (hipStream_t)s, in,
+                       (unsigned short*)out_bf16, rows, d, group_rows, group_stride_rows, row_off);
+    return check_launch("swat_gather_cast_bf16");
+}
+
+SWAT_API int swat_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
+                        const int64_t* seg_begin, int n_seg, const float* lrs_dev, float beta1, float beta2, float eps,
+                        float weight_decay, const float* bias_corr_dev, float grad_scale, swat_stream_t s) {
+    SWAT_REQUIRE(n % 4 == 0, "swat_adamw: flat size must be a multiple of 4");
+    SWAT_REQUIRE(n_seg >= 1 && n_seg <= 4, "swat_adamw: 1..4 lr groups");
+    AdamSegs segs{};
+    segs.n = n_seg;
+    for (int i = 0; i < n_seg; ++i) segs.begin[i] = seg_begin[i];
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)s, params, grads, exp_avg,
+                       exp_avg_sq, (unsigned short*)shadow_bf16, n, segs, lrs_dev, beta1, beta2, eps, weight_decay,
+                       bias_corr_dev, grad_scale);
+    return check_launch("swat_adamw");
+}
+
+SWAT_API int swat_cast_bf16(const float* in, void* out_bf16, int64_t n, swat_stream_t s) {
+    SWAT_REQUIRE(n % 4 == 0, "swat_cast_bf16: n must be a multiple of 4");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)s, in,
+                       (unsigned short*)out_bf16, n);
+    return check_launch("swat_cast_bf16");
+}

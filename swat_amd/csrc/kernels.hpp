@@ -1,0 +1,31 @@
+// swat_amd/csrc/kernels.hpp — internal declarations shared between the kernel files and the composite.
+#pragma once
+#include "common.hpp"
+
+namespace swat {
+
+enum { L_NT = 0, L_NN = 1, L_TN = 2 };
+
+struct GemmArgs {
+    const unsigned short* A;
+    const unsigned short* B;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int inner;  // batched: z = blockIdx.z ; off = (z / inner) * s0 + (z % inner) * s1   (elements)
+    int64_t sA0, sA1, sB0, sB1, sC0, sC1;
+    void* C;                       // primary output (bf16 or f32)
+    void* C2;                      // optional second output (bf16): act(C)
+    const float* bias;             // [N] fp32 or null
+    const float* residual;         // [M,N] fp32 (ld = ldc) or null (may alias C)
+    const unsigned short* actin;   // [M,N] bf16 (ld = ldact): dgrad through the activation
+    int ldact;
+    int act;                       // 0 none, 1 quick_gelu, 2 gelu(erf)
+    int out_f32;
+    float alpha;
+    int rpg, gstride, roff;        // output row remap: out_row = (m / rpg) * gstride + (m % rpg) + roff (rpg = 0: identity)
+    const float* rowbias;          // [.., N] fp32 added as rowbias[(m % rpg) + roff, n]
+};
+
+int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s);
+
+}  // namespace swat

@@ -1,0 +1,151 @@
+// swat_amd/csrc/tail.hip — the fp32 "tail" of path A on gfx950: L2-normalise (A3), MyLinear head + logit
+// scale (A4), (CutMix-)mixed cross entropy (A6) and their backward, plus the small strided fp32 GEMM they use.
+//
+// ref: utils/training.py:333-338,1475-1481 (normalise, head, scale, loss), :1157-1158 (mixup_criterion),
+//      utils/models.py:47-72 (MyLinear), utils/losses.py:10-11 (nn.CrossEntropyLoss, mean reduction).
+// M = batch (32..256) here, so these are latency-bound VALU kernels; everything stays fp32 (the master
+// weights of proj / head are read directly).
+#include "common.hpp"
+#include "../../include/swat_hip.h"
+
+namespace swat {
+
+// C[m,n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]  (+ C if accumulate); sequential fma over k.
+__global__ __launch_bounds__(256) void sgemm_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          float* __restrict__ C, int M, int N, int K, int64_t sam, int64_t sak,
+                                                          int64_t sbk, int64_t sbn, int64_t ldc, float alpha, int accumulate) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (m >= M || n >= N) return;
+    const float* a = A + (int64_t)m * sam;
+    const float* b = B + (int64_t)n * sbn;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(a[(int64_t)k * sak], b[(int64_t)k * sbk], acc);
+    float* c = C + (int64_t)m * ldc + n;
+    *c = accumulate ? *c + alpha * acc : alpha * acc;
+}
+
+// y = x / ||x||_2 per row (no eps — ref utils/training.py:333); one wave per row; norm saved.
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ nrm, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) { const float v = x[(int64_t)row * d + c]; s += v * v; }
+    const float n = sqrtf(wave_sum(s));
+    if (lane == 0 && nrm) nrm[row] = n;
+    for (int c = lane; c < d; c += 64) y[(int64_t)row * d + c] = x[(int64_t)row * d + c] / n;
+}
+
+// dx = (dy - y * <y, dy>) / ||x||
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ nrm,
+                                                         const float* __restrict__ dy, float* __restrict__ dx, int rows,
+                                                         int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += y[(int64_t)row * d + c] * dy[(int64_t)row * d + c];
+    s = wave_sum(s);
+    const float inv = 1.0f / nrm[row];
+    for (int c = lane; c < d; c += 64)
+        dx[(int64_t)row * d + c] = (dy[(int64_t)row * d + c] - y[(int64_t)row * d + c] * s) * inv;
+}
+
+// Mixed cross entropy on scaled logits.  z [B,C] = head output (un-scaled); logits = z * exp(ls).
+//   loss_b = lam * CE(logits_b, ya_b) + (1-lam) * CE(logits_b, yb_b)      (ref :1157-1158)
+//   dz_b   = exp(ls) * (softmax(logits_b) - lam*1[ya_b] - (1-lam)*1[yb_b]) / B        (mean reduction)
+//   dls_b  = sum_c dlogits_bc * logits_bc
+// One block (256 threads) per sample.  per_loss[b], per_dls[b] are reduced by ce_finish_kernel.
+__global__ __launch_bounds__(256) void ce_mixed_kernel(const float* __restrict__ z, const float* __restrict__ ls_ptr,
+                                                       const int64_t* __restrict__ ya, const int64_t* __restrict__ yb, float lam,
+                                                       float* __restrict__ per_loss, float* __restrict__ per_dls,
+                                                       float* __restrict__ dz, float* __restrict__ logits_out, int B, int C) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float sc = __expf(ls_ptr[0]);
+    const float* zr = z + (int64_t)b * C;
+    float mx = -INFINITY;
+    for (int c = tid; c < C; c += 256) mx = fmaxf(mx, zr[c] * sc);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < C; c += 256) s += __expf(zr[c] * sc - mx);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    const float lse = mx + __logf(s);
+    const int a_i = (int)ya[b], b_i = (int)yb[b];
+    float dls = 0.f;
+    const float invB = 1.0f / (float)B;
+    for (int c = tid; c < C; c += 256) {
+        const float l = zr[c] * sc;
+        if (logits_out) logits_out[(int64_t)b * C + c] = l;
+        float gl = __expf(l - lse);
+        if (c == a_i) gl -= lam;
+        if (c == b_i) gl -= (1.0f - lam);
+        gl *= invB;
+        dls += gl * l;
+        if (dz) dz[(int64_t)b * C + c] = gl * sc;
+    }
+    dls = wave_sum(dls);
+    if (lane == 0) red[wave] = dls;
+    __syncthreads();
+    if (tid == 0) {
+        per_dls[b] = (red[0] + red[1]) + (red[2] + red[3]);
+        per_loss[b] = lam * (lse - zr[a_i] * sc) + (1.0f - lam) * (lse - zr[b_i] * sc);
+    }
+}
+
+__global__ void ce_finish_kernel(const float* __restrict__ per_loss, const float* __restrict__ per_dls, int B,
+                                 float* __restrict__ loss, float* __restrict__ dls, double* __restrict__ loss_accum) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float l = 0.f, d = 0.f;
+        for (int i = 0; i < B; ++i) { l += per_loss[i]; d += per_dls[i]; }
+        l /= (float)B;
+        loss[0] = l;
+        if (dls) dls[0] = d;
+        if (loss_accum) loss_accum[0] += (double)l;  // running float64 sum for the per-epoch loss.csv row (ONE host sync per epoch)
+    }
+}
+
+}  // namespace swat
+using namespace swat;
+
+SWAT_API int swat_sgemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak,
+                              int64_t sbk, int64_t sbn, int64_t ldc, float alpha, int accumulate, swat_stream_t s) {
+    if (M <= 0 || N <= 0) return 0;
+    hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 63) / 64, (M + 3) / 4), dim3(256), 0, (hipStream_t)s, A, B, C, M, N, K,
+                       sam, sak, sbk, sbn, ldc, alpha, accumulate);
+    return check_launch("swat_sgemm_small");
+}
+
+SWAT_API int swat_l2norm_fwd(const float* x, float* y, float* norms, int rows, int d, swat_stream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, x, y, norms, rows, d);
+    return check_launch("swat_l2norm_fwd");
+}
+
+SWAT_API int swat_l2norm_bwd(const float* y, const float* norms, const float* dy, float* dx, int rows, int d,
+                             swat_stream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, y, norms, dy, dx, rows, d);
+    return check_launch("swat_l2norm_bwd");
+}
+
+SWAT_API int swat_ce_mixed(const float* z, const float* logit_scale_dev, const int64_t* ya, const int64_t* yb, float lam,
+                           float* per_sample_ws /* [2*B] */, float* loss, float* dlogit_scale, float* dz,
+                           float* logits_out, double* loss_accum, int B, int C, swat_stream_t s) {
+    SWAT_REQUIRE(B > 0 && C > 0, "swat_ce_mixed: bad shape");
+    hipLaunchKernelGGL(ce_mixed_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, z, logit_scale_dev, ya, yb, lam,
+                       per_sample_ws, per_sample_ws + B, dz, logits_out, B, C);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const float*)per_sample_ws,
+                       (const float*)(per_sample_ws + B), B, loss, dlogit_scale, loss_accum);
+    return check_launch("swat_ce_mixed");
+}

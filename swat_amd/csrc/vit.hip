@@ -1,0 +1,375 @@
+// swat_amd/csrc/vit.hip — the open_clip VisionTransformer forward/backward as ONE host call each: the C++
+// composite sequences the gfx950 kernels (gemm.hip, elementwise.hip, tail.hip) on a single stream with no
+// allocation and no synchronisation, so the Python host pays one ctypes call per pass.
+//
+// ref: model.encode_image(images) — utils/training.py:332,1474, testing.py:430, utils/features.py:134;
+// arithmetic per SURVEY Appendix A (conv1 patch embed, cls + positional embedding, ln_pre, L pre-LN blocks with
+// packed-QKV MHA and a (Quick)GELU MLP, ln_post on the class token, bias-free proj).
+//
+// Numerics: fp32 master weights + bf16 shadow weights; GEMMs read bf16 operands and accumulate in fp32; the
+// residual stream, LayerNorm statistics, softmax, proj and everything after it are fp32.
+#include "kernels.hpp"
+#include "../../include/swat_hip.h"
+
+namespace swat {
+
+__global__ void pad_cast_rows_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int rows, int k, int ld) {
+    const int64_t total = (int64_t)rows * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ld), c = (int)(i % ld);
+        out[i] = c < k ? f2bf(in[(int64_t)r * k + c]) : (unsigned short)0;
+    }
+}
+
+struct VitDims {
+    int B, img, patch, d, L, H, mlp, E, act, save;
+    int g, T, M, Kp, ldk, dh, ldp;
+};
+
+static int parse_dims(const int32_t* v, VitDims& D) {
+    D.B = v[0]; D.img = v[1]; D.patch = v[2]; D.d = v[3]; D.L = v[4]; D.H = v[5]; D.mlp = v[6]; D.E = v[7]; D.act = v[8];
+    D.save = v[9];
+    if (D.B <= 0 || D.patch <= 0 || D.img % D.patch || D.d % 64 || D.H <= 0 || D.d % D.H || D.L <= 0 || D.L > 64) return -1;
+    D.g = D.img / D.patch; D.T = D.g * D.g + 1; D.M = D.B * D.T; D.Kp = 3 * D.patch * D.patch; D.ldk = (D.Kp + 7) / 8 * 8;
+    D.dh = D.d / D.H; D.ldp = (D.T + 7) / 8 * 8;
+    if (D.dh % 8) return -1;
+    return 0;
+}
+
+// parameter offsets (elements) into the flat fp32 / bf16 buffers — order documented in include/swat_hip.h
+struct VitOffs {
+    int64_t conv1, cls, pos, lnpre_w, lnpre_b, lnpost_w, lnpost_b, proj;
+    const int64_t* layer;  // 12 per layer: ln1_w ln1_b qkv_w qkv_b out_w out_b ln2_w ln2_b fc_w fc_b proj_w proj_b
+};
+static VitOffs parse_offs(const int64_t* o) {
+    VitOffs r{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o + 8};
+    return r;
+}
+enum { LN1W = 0, LN1B, QKVW, QKVB, OUTW, OUTB, LN2W, LN2B, FCW, FCB, PRW, PRB };
+
+// activation / scratch workspace carve-up (same function for sizing, forward and backward)
+struct VitWs {
+    unsigned short* patches;  // [B*g*g, ldk]
+    unsigned short* convw;    // [d, ldk] padded conv weight (only when Kp % 8)
+    float* xpre;              // [M, d] conv + cls + pos (ln_pre input)
+    float *mean_pre, *rstd_pre, *mean_post, *rstd_post;
+    float* u;                 // [B, d] ln_post(cls)
+    // per layer (index l*save)
+    float* xs;                // (L+1) x [M,d] residual stream at block boundaries (xs[0] = ln_pre out)
+    float* x1;                // L x [M,d] mid-block residual
+    unsigned short *h1, *h2, *a;  // L x [M,d]
+    unsigned short* qkv;      // L x [M,3d]
+    unsigned short* P;        // L x [B*H,T,ldp]
+    unsigned short *f, *gact; // L x [M,mlp]
+    float *mean1, *rstd1, *mean2, *rstd2;  // L x [M]
+    // scratch
+    float* S;                 // [B*H,T,ldp] scores / dP
+    unsigned short* dS;       // [B*H,T,ldp]
+    float* dx;                // [M,d] residual-stream gradient
+    unsigned short* dxb;      // [M,d] its bf16 copy
+    float* dh;                // [M,d] LN-input gradient
+    unsigned short* dfb;      // [M,mlp]
+    unsigned short* dab;      // [M,d]
+    unsigned short* dqkv;     // [M,3d]
+    float* du;                // [B,d]
+    void* lnws;
+    int64_t total;
+};
+
+static VitWs carve(const VitDims& D, void* base) {
+    VitWs w{};
+    char* p = (char*)base;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) -> void* {
+        void* r = p ? (void*)(p + off) : nullptr;
+        off += (bytes + 255) / 256 * 256;
+        return r;
+    };
+    const int64_t M = D.M, d = D.d, Ls = D.save ? D.L : 1;
+    const int64_t pbytes = (int64_t)D.B * D.H * D.T * D.ldp;
+    w.patches = (unsigned short*)take((int64_t)D.B * D.g * D.g * D.ldk * 2);
+    w.convw = (unsigned short*)take((int64_t)d * D.ldk * 2);
+    w.xpre = (float*)take(M * d * 4);
+    w.mean_pre = (float*)take(M * 4); w.rstd_pre = (float*)take(M * 4);
+    w.mean_post = (float*)take(D.B * 4); w.rstd_post = (float*)take(D.B * 4);
+    w.u = (float*)take((int64_t)D.B * d * 4);
+    w.xs = (float*)take((D.save ? D.L + 1 : 2) * M * d * 4);
+    w.x1 = (float*)take(Ls * M * d * 4);
+    w.h1 = (unsigned short*)take(Ls * M * d * 2);
+    w.h2 = (unsigned short*)take(Ls * M * d * 2);
+    w.a = (unsigned short*)take(Ls * M * d * 2);
+    w.qkv = (unsigned short*)take(Ls * M * 3 * d * 2);
+    w.P = (unsigned short*)take(Ls * pbytes * 2);
+    w.f = (unsigned short*)take(Ls * M * D.mlp * 2);
+    w.gact = (unsigned short*)take(Ls * M * D.mlp * 2);
+    w.mean1 = (float*)take(Ls * M * 4); w.rstd1 = (float*)take(Ls * M * 4);
+    w.mean2 = (float*)take(Ls * M * 4); w.rstd2 = (float*)take(Ls * M * 4);
+    w.S = (float*)take(pbytes * 4);
+    if (D.save) {
+        w.dS = (unsigned short*)take(pbytes * 2);
+        w.dx = (float*)take(M * d * 4);
+        w.dxb = (unsigned short*)take(M * d * 2);
+        w.dh = (float*)take(M * d * 4);
+        w.dfb = (unsigned short*)take(M * D.mlp * 2);
+        w.dab = (unsigned short*)take(M * d * 2);
+        w.dqkv = (unsigned short*)take(M * 3 * d * 2);
+        w.du = (float*)take((int64_t)D.B * d * 4);
+        w.lnws = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
+    }
+    w.total = off;
+    return w;
+}
+
+static GemmArgs G(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_f32) {
+    GemmArgs a{};
+    a.A = (const unsigned short*)A; a.B = (const unsigned short*)B; a.C = C;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.inner = 1; a.out_f32 = out_f32; a.alpha = 1.0f;
+    return a;
+}
+
+#define TRY(x)              \
+    do {                    \
+        int rc__ = (x);     \
+        if (rc__) return rc__; \
+    } while (0)
+
+// multi-head attention forward on the packed qkv buffer of one layer
+static int attn_forward(const VitDims& D, const unsigned short* qkv, float* S, unsigned short* P, unsigned short* out,
+                        hipStream_t s) {
+    const int T = D.T, d = D.d, dh = D.dh, H = D.H, ldp = D.ldp;
+    GemmArgs a = G(qkv, qkv + d, S, T, T, dh, 3 * d, 3 * d, ldp, 1);
+    a.inner = H; a.sA0 = (int64_t)T * 3 * d; a.sA1 = dh; a.sB0 = a.sA0; a.sB1 = dh; a.sC0 = (int64_t)H * T * ldp; a.sC1 = (int64_t)T * ldp;
+    TRY(gemm_dispatch(L_NT, a, D.B * H, s));
+    TRY(swat_softmax_fwd(S, P, (int64_t)D.B * H * T, T, T, ldp, 1.0f / sqrtf((float)dh), 0, s));
+    GemmArgs b = G(P, qkv + 2 * d, out, T, dh, T, ldp, 3 * d, d, 0);
+    b.inner = H; b.sA0 = (int64_t)H * T * ldp; b.sA1 = (int64_t)T * ldp; b.sB0 = (int64_t)T * 3 * d; b.sB1 = dh; b.sC0 = (int64_t)T * d; b.sC1 = dh;
+    return gemm_dispatch(L_NN, b, D.B * H, s);
+}
+
+static int attn_backward(const VitDims& D, const unsigned short* qkv, const unsigned short* P, const unsigned short* dout,
+                         float* dP, unsigned short* dS, unsigned short* dqkv, hipStream_t s) {
+    const int T = D.T, d = D.d, dh = D.dh, H = D.H, ldp = D.ldp, BH = D.B * D.H;
+    const int64_t sP0 = (int64_t)H * T * ldp, sP1 = (int64_t)T * ldp, sQ0 = (int64_t)T * 3 * d, sO0 = (int64_t)T * d;
+    {   // dV = P^T dO
+        GemmArgs a = G(P, dout, dqkv + 2 * d, T, dh, T, ldp, d, 3 * d, 0);
+        a.inner = H; a.sA0 = sP0; a.sA1 = sP1; a.sB0 = sO0; a.sB1 = dh; a.sC0 = sQ0; a.sC1 = dh;
+        TRY(gemm_dispatch(L_TN, a, BH, s));
+    }
+    {   // dP = dO V^T
+        GemmArgs a = G(dout, qkv + 2 * d, dP, T, T, dh, d, 3 * d, ldp, 1);
+        a.inner = H; a.sA0 = sO0; a.sA1 = dh; a.sB0 = sQ0; a.sB1 = dh; a.sC0 = sP0; a.sC1 = sP1;
+        TRY(gemm_dispatch(L_NT, a, BH, s));
+    }
+    TRY(swat_softmax_bwd(P, dP, dS, (int64_t)BH * T, T, ldp, 1.0f / sqrtf((float)dh), s));
+    {   // dQ = dS K
+        GemmArgs a = G(dS, qkv + d, dqkv, T, dh, T, ldp, 3 * d, 3 * d, 0);
+        a.inner = H; a.sA0 = sP0; a.sA1 = sP1; a.sB0 = sQ0; a.sB1 = dh; a.sC0 = sQ0; a.sC1 = dh;
+        TRY(gemm_dispatch(L_NN, a, BH, s));
+    }
+    {   // dK = dS^T Q
+        GemmArgs a = G(dS, qkv, dqkv + d, T, dh, T, ldp, 3 * d, 3 * d, 0);
+        a.inner = H; a.sA0 = sP0; a.sA1 = sP1; a.sB0 = sQ0; a.sB1 = dh; a.sC0 = sQ0; a.sC1 = dh;
+        TRY(gemm_dispatch(L_TN, a, BH, s));
+    }
+    return 0;
+}
+
+}  // namespace swat
+using namespace swat;
+
+SWAT_API int64_t swat_vit_workspace_bytes(const int32_t* dims) {
+    VitDims D;
+    if (parse_dims(dims, D)) return -1;
+    return carve(D, nullptr).total;
+}
+
+SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const float* params, const void* shadow_bf16,
+                              const float* images, const int64_t* perm, int x1, int x2, int y1, int y2, void* workspace,
+                              float* feats, swat_stream_t stream) {
+    VitDims D;
+    SWAT_REQUIRE(parse_dims(dims, D) == 0, "swat_vit_forward: bad dims");
+    SWAT_REQUIRE(params && shadow_bf16 && images && workspace && feats, "swat_vit_forward: null pointer");
+    const VitOffs O = parse_offs(offs);
+    VitWs w = carve(D, workspace);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned short* sh = (const unsigned short*)shadow_bf16;
+    const int M = D.M, d = D.d, T = D.T, np = D.B * D.g * D.g;
+    const float eps = 1e-5f;
+
+    // A5 + A2a: CutMix paste fused into patch extraction, then the patch-embed GEMM with cls/pos epilogue
+    TRY(swat_patchify_cutmix(images, perm, w.patches, D.B, D.img, D.img, D.patch, D.ldk, x1, x2, y1, y2, s));
+    const unsigned short* convw = sh + O.conv1;
+    if (D.Kp % 8) {
+        hipLaunchKernelGGL(pad_cast_rows_kernel, dim3(256), dim3(256), 0, s, params + O.conv1, w.convw, d, D.Kp, D.ldk);
+        convw = w.convw;
+    }
+    {
+        GemmArgs a = G(w.patches, convw, w.xpre, np, d, D.Kp, D.ldk, D.ldk, d, 1);
+        a.rpg = D.g * D.g; a.gstride = T; a.roff = 1; a.rowbias = params + O.pos;
+        TRY(gemm_dispatch(L_NT, a, 1, s));
+    }
+    TRY(swat_cls_row(w.xpre, params + O.cls, params + O.pos, D.B, T, d, s));
+    // A2b: ln_pre -> residual stream xs[0]
+    TRY(swat_layernorm_fwd(w.xpre, d, params + O.lnpre_w, params + O.lnpre_b, nullptr, w.xs, w.mean_pre, w.rstd_pre, M, d, eps, s));
+
+    for (int l = 0; l < D.L; ++l) {
+        const int64_t* lo = O.layer + 12 * l;
+        const int64_t li = D.save ? l : 0;
+        float* xin = w.xs + (D.save ? (int64_t)l : (int64_t)(l & 1)) * M * d;
+        float* xout = w.xs + (D.save ? (int64_t)(l + 1) : (int64_t)((l + 1) & 1)) * M * d;
+        float* x1 = w.x1 + li * M * d;
+        unsigned short* h1 = w.h1 + li * M * d;
+        unsigned short* h2 = w.h2 + li * M * d;
+        unsigned short* at = w.a + li * M * d;
+        unsigned short* qkv = w.qkv + li * M * 3 * d;
+        unsigned short* P = w.P + li * (int64_t)D.B * D.H * T * D.ldp;
+        unsigned short* f = w.f + li * (int64_t)M * D.mlp;
+        unsigned short* ga = w.gact + li * (int64_t)M * D.mlp;
+        // A2c: ln_1 -> packed QKV projection
+        TRY(swat_layernorm_fwd(xin, d, params + lo[LN1W], params + lo[LN1B], h1, nullptr, w.mean1 + li * M, w.rstd1 + li * M, M, d, eps, s));
+        {
+            GemmArgs a = G(h1, sh + lo[QKVW], qkv, M, 3 * d, d, d, d, 3 * d, 0);
+            a.bias = params + lo[QKVB];
+            TRY(gemm_dispatch(L_NT, a, 1, s));
+        }
+        // A2d: attention
+        TRY(attn_forward(D, qkv, w.S, P, at, s));
+        // A2e: out_proj + residual
+        {
+            GemmArgs a = G(at, sh + lo[OUTW], x1, M, d, d, d, d, d, 1);
+            a.bias = params + lo[OUTB]; a.residual = xin;
+            TRY(gemm_dispatch(L_NT, a, 1, s));
+        }
+        // A2f: ln_2 -> c_fc (+act) -> c_proj + residual
+        TRY(swat_layernorm_fwd(x1, d, params + lo[LN2W], params + lo[LN2B], h2, nullptr, w.mean2 + li * M, w.rstd2 + li * M, M, d, eps, s));
+        {
+            GemmArgs a = G(h2, sh + lo[FCW], f, M, D.mlp, d, d, d, D.mlp, 0);
+            a.bias = params + lo[FCB]; a.act = D.act; a.C2 = ga;
+            TRY(gemm_dispatch(L_NT, a, 1, s));
+        }
+        {
+            GemmArgs a = G(ga, sh + lo[PRW], xout, M, d, D.mlp, D.mlp, D.mlp, d, 1);
+            a.bias = params + lo[PRB]; a.residual = x1;
+            TRY(gemm_dispatch(L_NT, a, 1, s));
+        }
+    }
+    // A2g: ln_post on the class token only, then the bias-free projection (fp32)
+    const float* xl = w.xs + (D.save ? (int64_t)D.L : (int64_t)(D.L & 1)) * M * d;
+    TRY(swat_layernorm_fwd(xl, (int64_t)T * d, params + O.lnpost_w, params + O.lnpost_b, nullptr, w.u, w.mean_post, w.rstd_post, D.B, d, eps, s));
+    TRY(swat_sgemm_small(w.u, params + O.proj, feats, D.B, D.E, d, d, 1, D.E, 1, D.E, 1.0f, 0, s));
+    return 0;
+}
+
+// Backward in stages so the host can overlap gradient reduction with the remaining backward:
+//   stage L+1 : proj + ln_post (needs dfeats);  stage l+1 : block l;  stage 0 : ln_pre + embeddings + conv1.
+// Call with stage_hi >= stage_lo; stages run from stage_hi down to stage_lo.  Gradients are WRITTEN (not
+// accumulated) into `grads` at the parameters' own offsets.
+SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const float* params, const void* shadow_bf16,
+                               void* workspace, const float* dfeats, float* grads, int stage_hi, int stage_lo,
+                               swat_stream_t stream) {
+    VitDims D;
+    SWAT_REQUIRE(parse_dims(dims, D) == 0 && D.save, "swat_vit_backward: bad dims or forward ran without save");
+    SWAT_REQUIRE(stage_hi <= D.L + 1 && stage_lo >= 0 && stage_hi >= stage_lo, "swat_vit_backward: bad stage range");
+    const VitOffs O = parse_offs(offs);
+    VitWs w = carve(D, workspace);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned short* sh = (const unsigned short*)shadow_bf16;
+    const int M = D.M, d = D.d, T = D.T, np = D.B * D.g * D.g, mlp = D.mlp;
+
+    for (int stage = stage_hi; stage >= stage_lo; --stage) {
+        if (stage == D.L + 1) {
+            SWAT_REQUIRE(dfeats, "swat_vit_backward: dfeats is null");
+            // dproj[c,e] = sum_b u[b,c] df[b,e] ; du[b,c] = sum_e df[b,e] proj[c,e]
+            TRY(swat_sgemm_small(w.u, dfeats, grads + O.proj, d, D.E, D.B, 1, d, D.E, 1, D.E, 1.0f, 0, s));
+            TRY(swat_sgemm_small(dfeats, params + O.proj, w.du, D.B, d, D.E, D.E, 1, 1, D.E, d, 1.0f, 0, s));
+            hipMemsetAsync(w.dx, 0, (size_t)M * d * 4, s);
+            hipMemsetAsync(w.dxb, 0, (size_t)M * d * 2, s);
+            const float* xl = w.xs + (int64_t)D.L * M * d;
+            TRY(swat_layernorm_bwd(w.du, d, xl, (int64_t)T * d, params + O.lnpost_w, w.mean_post, w.rstd_post, nullptr, 0, w.dx,
+                                   (int64_t)T * d, w.dxb, (int64_t)T * d, grads + O.lnpost_w, grads + O.lnpost_b, w.lnws, D.B, d, s));
+        } else if (stage >= 1) {
+            const int l = stage - 1;
+            const int64_t* lo = O.layer + 12 * l;
+            const float* xin = w.xs + (int64_t)l * M * d;
+            const float* x1 = w.x1 + (int64_t)l * M * d;
+            const unsigned short* h1 = w.h1 + (int64_t)l * M * d;
+            const unsigned short* h2 = w.h2 + (int64_t)l * M * d;
+            const unsigned short* at = w.a + (int64_t)l * M * d;
+            const unsigned short* qkv = w.qkv + (int64_t)l * M * 3 * d;
+            const unsigned short* P = w.P + (int64_t)l * D.B * D.H * T * D.ldp;
+            const unsigned short* f = w.f + (int64_t)l * M * mlp;
+            const unsigned short* ga = w.gact + (int64_t)l * M * mlp;
+            // c_proj: dW = dx^T g, db = colsum(dx), dF = (dx W) * act'(F)
+            TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, M, d, mlp, mlp, 1), 1, s));
+            TRY(swat_colsum(w.dxb, SWAT_BF16, M, d, d, grads + lo[PRB], 0, 0, 0, s));
+            {
+                GemmArgs a = G(w.dxb, sh + lo[PRW], w.dfb, M, mlp, d, d, mlp, mlp, 0);
+                a.actin = f; a.ldact = mlp; a.act = D.act;
+                TRY(gemm_dispatch(L_NN, a, 1, s));
+            }
+            // c_fc: dW = dF^T h2, db = colsum(dF), dh2 = dF W
+            TRY(gemm_dispatch(L_TN, G(w.dfb, h2, grads + lo[FCW], mlp, d, M, mlp, d, d, 1), 1, s));
+            TRY(swat_colsum(w.dfb, SWAT_BF16, M, mlp, mlp, grads + lo[FCB], 0, 0, 0, s));
+            TRY(gemm_dispatch(L_NN, G(w.dfb, sh + lo[FCW], w.dh, M, d, mlp, mlp, d, d, 1), 1, s));
+            // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
+            TRY(swat_layernorm_bwd(w.dh, d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
+                                   w.dx, d, w.dxb, d, grads + lo[LN2W], grads + lo[LN2B], w.lnws, M, d, s));
+            // out_proj: dW = dx1^T a, db = colsum(dx1), da = dx1 W
+            TRY(gemm_dispatch(L_TN, G(w.dxb, at, grads + lo[OUTW], d, d, M, d, d, d, 1), 1, s));
+            TRY(swat_colsum(w.dxb, SWAT_BF16, M, d, d, grads + lo[OUTB], 0, 0, 0, s));
+            TRY(gemm_dispatch(L_NN, G(w.dxb, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
+            // attention backward -> dqkv
+            TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s));
+            // in_proj: dW = dqkv^T h1, db = colsum(dqkv), dh1 = dqkv W
+            TRY(gemm_dispatch(L_TN, G(w.dqkv, h1, grads + lo[QKVW], 3 * d, d, M, 3 * d, d, d, 1), 1, s));
+            TRY(swat_colsum(w.dqkv, SWAT_BF16, M, 3 * d, 3 * d, grads + lo[QKVB], 0, 0, 0, s));
+            TRY(gemm_dispatch(L_NN, G(w.dqkv, sh + lo[QKVW], w.dh, M, d, 3 * d, 3 * d, d, d, 1), 1, s));
+            // ln_1 backward: dx0 = dx1 + LN'(dh1)
+            TRY(swat_layernorm_bwd(w.dh, d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
+                                   w.dx, d, w.dxb, d, grads + lo[LN1W], grads + lo[LN1B], w.lnws, M, d, s));
+        } else {
+            // stem: ln_pre backward, positional / class embedding, conv1 weight
+            TRY(swat_layernorm_bwd(w.dx, d, w.xpre, d, params + O.lnpre_w, w.mean_pre, w.rstd_pre, nullptr, 0, w.dh, d, nullptr, 0,
+                                   grads + O.lnpre_w, grads + O.lnpre_b, w.lnws, M, d, s));
+            TRY(swat_colsum(w.dh, SWAT_F32, D.B, T * d, T * d, grads + O.pos, 0, 0, 0, s));  // dpos[t,:] = sum_b
+            TRY(swat_colsum(w.dh, SWAT_F32, D.B, d, T * d, grads + O.cls, 0, 0, 0, s));      // dcls = sum_b row 0
+            TRY(swat_gather_cast_bf16(w.dh, w.dxb, np, d, D.g * D.g, T, 1, s));              // drop the cls rows
+            TRY(gemm_dispatch(L_TN, G(w.dxb, w.patches, grads + O.conv1, d, D.Kp, np, d, D.ldk, D.Kp, 1), 1, s));
+        }
+    }
+    return 0;
+}
+
+// A3 + A4 + A6 and their backward in one call: feats [B,E] -> loss, dfeats, dW_head, dlogit_scale.
+//   fn = feats/||feats|| ; z = fn W^T ; logits = z*exp(ls) ; loss = lam*CE(logits,ya) + (1-lam)*CE(logits,yb)
+// workspace: (B*E + B + B*C + B*C + B*E + 2*B) floats.  want_grad = 0 -> forward only (validate).
+SWAT_API int64_t swat_head_loss_workspace_bytes(int B, int E, int C) {
+    return ((int64_t)2 * B * E + (int64_t)2 * B * C + 3 * B) * 4 + 1024;
+}
+
+SWAT_API int swat_head_loss(const float* feats, const float* W, const float* logit_scale_dev, const int64_t* ya,
+                            const int64_t* yb, float lam, void* workspace, float* loss, float* dfeats, float* dW,
+                            float* dlogit_scale, float* z_out, float* feat_norm_out, double* loss_accum, int B, int E,
+                            int C, int want_grad, swat_stream_t s) {
+    SWAT_REQUIRE(feats && W && logit_scale_dev && ya && yb && workspace && loss, "swat_head_loss: null pointer");
+    float* fn = (float*)workspace;
+    float* nrm = fn + (int64_t)B * E;
+    float* z = nrm + B;
+    float* dz = z + (int64_t)B * C;
+    float* dfn = dz + (int64_t)B * C;
+    float* ps = dfn + (int64_t)B * E;
+    if (feat_norm_out) fn = feat_norm_out;
+    if (z_out) z = z_out;
+    TRY(swat_l2norm_fwd(feats, fn, nrm, B, E, s));
+    TRY(swat_sgemm_small(fn, W, z, B, C, E, E, 1, 1, E, C, 1.0f, 0, s));  // z[b,c] = sum_e fn[b,e] W[c,e]
+    TRY(swat_ce_mixed(z, logit_scale_dev, ya, yb, lam, ps, loss, dlogit_scale, want_grad ? dz : nullptr, nullptr, loss_accum,
+                      B, C, s));
+    if (want_grad) {
+        SWAT_REQUIRE(dfeats && dW && dlogit_scale, "swat_head_loss: gradient outputs are null");
+        TRY(swat_sgemm_small(dz, fn, dW, C, E, B, 1, C, E, 1, E, 1.0f, 0, s));   // dW[c,e]  = sum_b dz[b,c] fn[b,e]
+        TRY(swat_sgemm_small(dz, W, dfn, B, E, C, C, 1, E, 1, E, 1.0f, 0, s));   // dfn[b,e] = sum_c dz[b,c] W[c,e]
+        TRY(swat_l2norm_bwd(fn, nrm, dfn, dfeats, B, E, s));
+    }
+    return 0;
+}

@@ -1,0 +1,88 @@
+"""One fused finetuning step on gfx950: CutMix paste -> encode_image -> L2-norm -> head -> scaled mixed CE ->
+backward -> (data-parallel gradient reduction) -> AdamW, with no autograd graph and four host calls.
+
+ref: the body of the hot loops utils/training.py:326-347 (train_ce) and :1452-1489 (train_cutmix).
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class FusedTrainStep:
+    def __init__(self, model, classifier_head, logit_scale, optimizer, world_size=None):
+        self.visual = model.visual
+        self.head = classifier_head
+        self.logit_scale = logit_scale
+        self.opt = optimizer
+        self.arena = optimizer.arena
+        W = classifier_head.linear.weight
+        self.C, self.E = W.shape
+        self.off_head = self.arena.offset_of(W)
+        self.off_ls = self.arena.offset_of(logit_scale)
+        self.train_visual = any(g.get('swat_tower') is self.visual for g in optimizer.param_groups)
+        dev = self.arena.flat.device
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)  # per-epoch running sum: ONE host sync per epoch
+        self._ws = {}
+        self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.opt.grad_scale = 1.0 / self.world
+        # contiguous gradient slices per backward stage (the tower is laid out stage by stage in the arena)
+        self._stage_slices = []
+        if self.train_visual:
+            for s in range(self.visual.layers + 2):
+                ps = self.visual.stage_params(s)
+                lo = self.arena.offset_of(ps[0])
+                hi = self.arena.offset_of(ps[-1]) + (ps[-1].numel() + 63) // 64 * 64
+                self._stage_slices.append((lo, hi))
+
+    def _head_ws(self, B, dev):
+        ws = self._ws.get(B)
+        if ws is None:
+            n = _lib.lib().swat_head_loss_workspace_bytes(B, self.E, self.C)
+            ws = (torch.empty(n, dtype=torch.uint8, device=dev), torch.empty((B, self.E), dtype=torch.float32, device=dev))
+            self._ws[B] = ws
+        return ws
+
+    def __call__(self, images, target_a, target_b=None, lam=1.0, perm=None, box=None):
+        """images fp32 [B,3,H,W] (GPU), targets int64 [B].  Returns the device scalar holding this step's loss."""
+        a = self.arena
+        B = images.shape[0]
+        dev = images.device
+        if target_b is None:
+            target_b = target_a
+        ws, dfeats = self._head_ws(B, dev)
+        pending = []
+        if self.train_visual:
+            feats = self.visual.forward_raw(images, save=True, perm=perm, box=box)
+        else:
+            feats = images  # pre-extracted, already normalised features (train_probing)
+        g = a.grad
+        rc = _lib.lib().swat_head_loss(_lib.ptr(feats), a.flat.data_ptr() + 4 * self.off_head, a.flat.data_ptr() + 4 * self.off_ls,
+                                       _lib.ptr(target_a), _lib.ptr(target_b), float(lam), _lib.ptr(ws), _lib.ptr(self.loss),
+                                       _lib.ptr(dfeats), g.data_ptr() + 4 * self.off_head, g.data_ptr() + 4 * self.off_ls, None,
+                                       None, _lib.ptr(self.loss_accum), B, self.E, self.C, 1, _lib.stream())
+        _lib.check(rc, "swat_head_loss")
+        if self.world > 1:
+            lo = min(self.off_head, self.off_ls)
+            hi = max(self.off_head + self.C * self.E, self.off_ls + 1)
+            pending.append(dist.all_reduce(g[lo:hi], async_op=True))
+        if self.train_visual:
+            L = self.visual.layers
+            if self.world > 1:
+                # stage by stage: reduce a stage's slice (RCCL, its own stream) while the next stage's kernels run
+                for s in range(L + 1, -1, -1):
+                    self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
+                    lo, hi = self._stage_slices[s]
+                    pending.append(dist.all_reduce(g[lo:hi], async_op=True))
+            else:
+                self.visual.backward_raw(dfeats)
+        for w in pending:
+            w.wait()
+        self.opt.step()
+        return self.loss
+
+    def pop_loss_sum(self):
+        v = self.loss_accum.item()
+        self.loss_accum.zero_()
+        return v

@@ -1,0 +1,173 @@
+"""`--method` plug-ins: the finetuning loops of SWAT on the fused gfx950 step
+(mirror of the reference's utils/training.py: same names, signatures, return values and loss.csv rows).
+
+ref: set_training_seed :10-20, run_zeroshot :23-44, train_probing :47-161, train_ce :296-412, mixup_criterion
+     :1157-1158, rand_bbox :1404-1420, train_cutmix :1422-1556.
+
+Differences from the reference that do not change results:
+  * the whole step runs in swat_amd.step.FusedTrainStep (no autograd graph, no per-step .item()): the loss is
+    accumulated on the device and read once per epoch for the loss.csv row;
+  * the CutMix paste is fused into patch extraction (the input batch is not modified in place);
+  * host RNG consumption order per iteration is the reference's: np.random.rand(1) ->
+    [np.random.beta] -> torch.randperm(B) (global CPU generator) -> np.random.randint(W) -> np.random.randint(H).
+"""
+import copy
+import random
+
+import numpy as np
+import torch
+
+from .step import FusedTrainStep
+from .testing import validate, calculate_scores, load_model
+from .models import save_model_ckpt
+
+
+def set_training_seed(args):
+    random.seed(args.training_seed)
+    torch.manual_seed(args.training_seed)
+    np.random.seed(args.training_seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(args.training_seed)
+
+
+def run_zeroshot(args, test_loader, model, logger, loss, logit_scale, classifier_head):
+    zs_test_acc, zs_loss, zs_confusion_matrix = validate(args, data_loader=test_loader, model=model, logger=logger, loss=loss,
+                                                         logit_scale=logit_scale, classifier_head=classifier_head,
+                                                         show_confusion_matrix=True, dataset=args.dataset,
+                                                         output_dir=args.output_dir, device=args.device,
+                                                         pre_extracted=args.pre_extracted)
+    logger.info(f"+++++ Zero-shot Test Acc: {round(zs_test_acc, 3)}")
+    return zs_test_acc
+
+
+def mixup_criterion(criterion, pred, y_a, y_b, lam):
+    return lam * criterion(pred, y_a) + (1.0 - lam) * criterion(pred, y_b)
+
+
+def rand_bbox(size, lam):
+    """ref :1404-1420 (W = size[2], H = size[3]; both 224 here)."""
+    W = size[2]
+    H = size[3]
+    cut_rat = np.sqrt(1. - lam)
+    cut_w = int(W * cut_rat)
+    cut_h = int(H * cut_rat)
+    cx = np.random.randint(W)
+    cy = np.random.randint(H)
+    bbx1 = np.clip(cx - cut_w // 2, 0, W)
+    bby1 = np.clip(cy - cut_h // 2, 0, H)
+    bbx2 = np.clip(cx + cut_w // 2, 0, W)
+    bby2 = np.clip(cy + cut_h // 2, 0, H)
+    return bbx1, bby1, bbx2, bby2
+
+
+def cutmix_draw(args, size):
+    """The host-side draws of one train_cutmix iteration (ref :1458-1472) -> (lam, rand_index|None, box|None)."""
+    r = np.random.rand(1)
+    if args.cutmix_beta > 0 and r < args.mix_prob:
+        lam = np.random.beta(args.cutmix_beta, args.cutmix_beta)
+        rand_index = torch.randperm(size[0])
+        bbx1, bby1, bbx2, bby2 = rand_bbox(size, lam)
+        lam = 1 - ((bbx2 - bbx1) * (bby2 - bby1) / (size[-1] * size[-2]))
+        return float(lam), rand_index, (int(bbx1), int(bby1), int(bbx2), int(bby2))
+    return 1.0, None, None
+
+
+def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader, val_loader, test_loader, use_cutmix):
+    model.eval() if args.freeze_visual else model.train()
+    classifier_head.train()
+    logit_scale = args.logit_scale
+    optimizer = args.optimizer
+    scheduler = args.scheduler
+    step = FusedTrainStep(model, classifier_head, logit_scale, optimizer)
+
+    val_loss = -1
+    val_acc = -1
+    test_acc = -1
+    best_val_acc = -1
+    best_epoch = -1
+    best_iter = -1
+    best_model = model
+    best_head = classifier_head
+    best_logit_scale = logit_scale
+    best_records = {}
+    num_iter = 0
+    for epoch in range(1, args.epochs + 1):
+        for inputs, labels, text, source in train_loader:
+            num_iter += 1
+            images = inputs.to(args.device, non_blocking=True)
+            labels = labels.to(args.device, non_blocking=True).long()
+            if use_cutmix:
+                lam, rand_index, box = cutmix_draw(args, images.size())
+            else:
+                lam, rand_index, box = 1.0, None, None
+            if rand_index is not None:
+                rand_index = rand_index.to(args.device)
+                step(images, labels, labels[rand_index], lam, perm=rand_index, box=box)
+            else:
+                step(images, labels, labels, 1.0)
+            scheduler.step()  # update learning rate for each iteration
+
+        train_loss_sum = step.pop_loss_sum()  # the only host sync of the epoch
+
+        if args.early_stop or epoch == args.epochs:
+            val_acc, val_loss, confusion_matrix = validate(args, data_loader=val_loader, model=model, logger=logger,
+                                                           loss=args.loss, logit_scale=logit_scale,
+                                                           classifier_head=classifier_head, show_confusion_matrix=True,
+                                                           dataset=args.dataset, output_dir=args.output_dir,
+                                                           device=args.device, pre_extracted=args.pre_extracted)
+            scores = calculate_scores(confusion_matrix)
+
+        if (args.early_stop or epoch == args.epochs) and val_acc >= best_val_acc:
+            best_val_acc = val_acc
+            best_logit_scale = copy.deepcopy(logit_scale)
+            best_epoch = epoch
+            best_iter = num_iter
+            best_scores = copy.deepcopy(scores)
+            best_confusion_matrix = copy.deepcopy(confusion_matrix)
+            best_head = copy.deepcopy(classifier_head)
+            best_model = copy.deepcopy(model)
+            best_records['best_val_acc'] = best_val_acc
+            best_records['best_logit_scale'] = best_logit_scale
+            best_records['best_epoch'] = best_epoch
+            best_records['best_iter'] = best_iter
+            best_records['best_scores'] = best_scores
+            best_records['best_confusion_matrix'] = best_confusion_matrix
+
+        if args.early_stop or epoch == args.epochs:
+            test_acc, _, _ = validate(args, data_loader=test_loader, model=model, logger=logger, loss=args.loss,
+                                      logit_scale=logit_scale, classifier_head=classifier_head, dataset=args.dataset,
+                                      output_dir=args.output_dir, device=args.device, pre_extracted=args.pre_extracted)
+
+        train_loss_avg = train_loss_sum / len(train_loader)
+        loss_logger.write(f'{epoch},{num_iter},{round(train_loss_avg, 6)},{round(val_loss, 6)},{round(val_acc, 6)},{round(test_acc, 6)}\n')
+        loss_logger.flush()
+        logger.info(f"Epoch {int(epoch)}, Iter {num_iter}, Trn Loss: {round(train_loss_avg, 6)}, Val Loss: {round(val_loss, 6)}, "
+                    f"Val Acc: {round(val_acc, 3)}, Test Acc: {round(test_acc, 3)}")
+        if logger.handlers:
+            logger.handlers[0].flush()
+
+        if args.save_ckpt and (num_iter % args.save_freq == 0 or epoch == args.epochs):
+            model_path = save_model_ckpt(args, best_records, model, classifier_head, optimizer, scheduler, logit_scale,
+                                         val_acc, epoch, num_iter)
+            logger.info(f'Model ckpt saved to: {model_path}')
+
+        if epoch == args.stop_epochs:
+            break
+
+    logger.info('Training done.')
+    logger.info(f'Best val Acc: {round(best_val_acc, 3)} at epoch {best_epoch}, iter {best_iter}')
+    return best_model, best_head, best_records, best_logit_scale
+
+
+def train_ce(args, logger, loss_logger, model, classifier_head, train_loader, val_loader, test_loader, reload_model=False):
+    """Cross-entropy finetuning of the visual encoder + head (ref :296-412)."""
+    logger.info("Start standard finetuning ......")
+    if reload_model:
+        load_model(args, logger, model, None, classifier_head)
+    return _train_loop(args, logger, loss_logger, model, classifier_head, train_loader, val_loader, test_loader, False)
+
+
+def train_cutmix(args, logger, loss_logger, model, classifier_head, train_loader, val_loader, test_loader):
+    """CutMix finetuning (ref :1422-1556)."""
+    logger.info("Start Training cutmix ......")
+    return _train_loop(args, logger, loss_logger, model, classifier_head, train_loader, val_loader, test_loader, True)

@@ -1,0 +1,250 @@
+"""GPU: each path A HIP kernel (through the C ABI) against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=F32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev()).to(dtype)
+
+
+# bf16 inputs are exact in fp32, products exact, fp32 accumulation: the only differences vs an fp32 matmul of
+# the same bf16 inputs are summation order (~1e-6 rel) and the bf16 rounding of a bf16 output (2^-9 rel).
+def close(got, ref, bf16_out, k):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    tol = (2.0 ** -8 if bf16_out else 1e-5) * ref.abs().max().item() + 1e-5 * math.sqrt(k)
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"max err {err} > {tol}"
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (1600, 2304, 768), (1600, 768, 3072), (100, 72, 96), (1568, 768, 3072),
+                                   (33, 200, 64), (257, 1024, 1024), (50, 50, 64)])
+@pytest.mark.parametrize("out_dtype", [BF, F32])
+def test_gemm_nt(M, N, K, out_dtype):
+    from swat_amd import ops
+    x, w = rnd(M, K, seed=1, dtype=BF), rnd(N, K, seed=2, scale=0.05, dtype=BF)
+    b = rnd(N, seed=3) if N % 4 == 0 else None
+    if N % 4:
+        pytest.skip("N%4 handled via padded ldc in the attention tests")
+    y = ops.linear_fwd(x, w, bias=b, out_dtype=out_dtype)
+    ref = x.float() @ w.float().t() + b
+    close(y, ref, out_dtype == BF, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(1600, 768, 2304), (1600, 3072, 768), (100, 72, 96), (257, 1024, 4096), (50, 64, 50)])
+def test_gemm_nn_dgrad(M, N, K):
+    """dx[M,K'] = dy[M,N'] @ w[N',K'] — here (M, N, K) = (rows, reduction, out cols)."""
+    from swat_amd import ops
+    if N % 8:
+        pytest.skip("reduction ld must be a multiple of 8; ragged reductions are covered by the attention test")
+    dy, w = rnd(M, N, seed=4, dtype=BF), rnd(N, K, seed=5, scale=0.05, dtype=BF)
+    if K % 4:
+        pytest.skip("ragged")
+    dx = ops.linear_dgrad(dy, w, out_dtype=F32)
+    close(dx, dy.float() @ w.float(), False, N)
+    dxb = ops.linear_dgrad(dy, w, out_dtype=BF)
+    close(dxb, dy.float() @ w.float(), True, N)
+
+
+@pytest.mark.parametrize("M,N,K", [(1600, 768, 768), (1600, 2304, 768), (1568, 768, 3072), (100, 72, 96), (8224, 1024, 1024),
+                                   (96, 64, 64)])
+def test_gemm_tn_wgrad(M, N, K):
+    from swat_amd import ops
+    dy, x = rnd(M, N, seed=6, dtype=BF), rnd(M, K, seed=7, dtype=BF)
+    dw = ops.linear_wgrad(dy, x)
+    close(dw, dy.float().t() @ x.float(), False, M)
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_gemm_epilogues(act):
+    from swat_amd import ops
+    M, N, K = 200, 3072, 768
+    x, w, b = rnd(M, K, seed=1, dtype=BF), rnd(N, K, seed=2, scale=0.05, dtype=BF), rnd(N, seed=3)
+    pre, post = ops.linear_fwd(x, w, bias=b, act=act, want_act=True)
+    ref_pre = x.float() @ w.float().t() + b
+    close(pre, ref_pre, True, K)
+    f = pre.float()
+    ref_post = f * torch.sigmoid(1.702 * f) if act == "quick_gelu" else torch.nn.functional.gelu(f)
+    close(post, ref_post, True, 1)
+    # residual (in place, fp32)
+    res = rnd(M, K, seed=9)
+    w2 = rnd(K, N, seed=10, scale=0.02, dtype=BF)
+    expect = res + post.float() @ w2.float().t() + b[:K]
+    out = res.clone()
+    ops.gemm(ops.NT, post, w2, M, K, N, N, N, out, K, bias=b[:K].contiguous(), residual=out)
+    close(out, expect, False, N)
+    # dgrad through the activation: dF = (dG @ W) * act'(F)
+    dg = rnd(M, K, seed=11, dtype=BF)
+    df = ops.linear_dgrad(dg, w2, actin=pre, act=act)
+    fr = pre.float().requires_grad_(True)
+    (fr * torch.sigmoid(1.702 * fr) if act == "quick_gelu" else torch.nn.functional.gelu(fr)).backward(dg.float() @ w2.float())
+    close(df, fr.grad, True, K)
+
+
+@pytest.mark.parametrize("B,H,T,dh", [(2, 12, 50, 64), (1, 16, 257, 64), (3, 8, 77, 64), (2, 12, 197, 64)])
+def test_attention_as_batched_gemms(B, H, T, dh):
+    """softmax(QK^T/sqrt(dh)) V from the packed qkv buffer through batched NT / NN GEMMs + the softmax kernel,
+    and its backward through TN / NT / NN GEMMs, vs torch autograd in fp32."""
+    from swat_amd import attention
+    d = H * dh
+    qkv = rnd(B * T, 3 * d, seed=12, dtype=BF)
+    do = rnd(B * T, d, seed=13, dtype=BF)
+    out, P = attention.attn_fwd(qkv, B, T, H, dh)
+    q, k, v = [t.reshape(B, T, H, dh).permute(0, 2, 1, 3).float().requires_grad_(True) for t in qkv.float().split(d, dim=1)]
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+    assert (out.float() - o).abs().max().item() <= 2.0 ** -7 * o.abs().max().item() + 1e-3
+    o.backward(do.float())
+    dqkv = attention.attn_bwd(qkv, P, do, B, T, H, dh)
+    ref = torch.cat([g.grad.permute(0, 2, 1, 3).reshape(B * T, d) for g in (q, k, v)], dim=1)
+    got, ref = dqkv.float().cpu(), ref.cpu()
+    assert (got - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_softmax_kernels(causal):
+    from swat_amd import ops
+    BH, T, ld = 5, 50, 64
+    S = rnd(BH, T, ld, seed=14, scale=3.0)
+    P = ops.softmax_fwd(S, T, T, 0.125, causal=causal)
+    s = S[..., :T] * 0.125
+    if causal:
+        s = s.masked_fill(torch.ones(T, T, device=dev()).triu(1).bool(), float("-inf"))
+    ref = torch.softmax(s, -1)
+    assert (P[..., :T].float() - ref).abs().max().item() < 4e-3
+    assert (P[..., T:] == 0).all()
+    dP = rnd(BH, T, ld, seed=15)
+    dS = ops.softmax_bwd(P, dP, T, 0.125)
+    p = P[..., :T].float()
+    refd = 0.125 * p * (dP[..., :T] - (p * dP[..., :T]).sum(-1, keepdim=True))
+    assert (dS[..., :T].float() - refd).abs().max().item() < 2e-3
+    assert (dS[..., T:] == 0).all()
+
+
+@pytest.mark.parametrize("rows,d", [(1600, 768), (7, 1024), (8224, 1024), (33, 512)])
+def test_layernorm_fwd_bwd(rows, d):
+    from swat_amd import ops
+    x = rnd(rows, d, seed=16, scale=2.0) + 0.5
+    g, b = rnd(d, seed=17) * 0.1 + 1.0, rnd(d, seed=18) * 0.1
+    y_bf, y_f, mean, rstd = ops.layernorm_fwd(x, g, b, out_f32=True)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5)
+    assert (y_f - ref).abs().max().item() < 2e-5
+    assert (y_bf.float() - ref).abs().max().item() < 2.0 ** -7 * ref.abs().max().item()
+    dy = rnd(rows, d, seed=19)
+    add = rnd(rows, d, seed=20)
+    ref.backward(dy)
+    dx, dx_bf, dg, db = ops.layernorm_bwd(dy, x, g, mean, rstd, dx_add=add, want_bf16=True)
+    assert (dx - (xr.grad + add)).abs().max().item() < 1e-4
+    assert (dx_bf.float() - dx).abs().max().item() <= 2.0 ** -8 * dx.abs().max().item()
+    assert (dg - gr.grad).abs().max().item() < 2e-3 * max(1.0, gr.grad.abs().max().item())
+    assert (db - br.grad).abs().max().item() < 2e-3 * max(1.0, br.grad.abs().max().item())
+
+
+def test_layernorm_strided_cls_rows():
+    from swat_amd import ops
+    B, T, d = 6, 50, 768
+    x = rnd(B, T, d, seed=21)
+    g, b = rnd(d, seed=22) + 1.0, rnd(d, seed=23)
+    _, y, mean, rstd = ops.layernorm_fwd(x, g, b, rows=B, row_stride=T * d, out_bf16=False, out_f32=True)
+    ref = torch.nn.functional.layer_norm(x[:, 0], (d,), g, b, 1e-5)
+    assert (y - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("ps,H", [(32, 224), (16, 224), (14, 224)])
+def test_patchify_cutmix(ps, H):
+    from swat_amd import ops
+    B = 5
+    img = rnd(B, 3, H, H, seed=24)
+    perm = torch.tensor([3, 0, 4, 1, 2], device=dev())
+    box = (17, 40, 130, 201)  # bbx1, bby1, bbx2, bby2 as rand_bbox returns them
+    mixed = img.clone()
+    mixed[:, :, box[0]:box[2], box[1]:box[3]] = img[perm][:, :, box[0]:box[2], box[1]:box[3]]  # ref utils/training.py:1466
+    g = H // ps
+    K = 3 * ps * ps
+    for use_mix, src in ((True, mixed), (False, img)):
+        out = ops.patchify_cutmix(img, ps, perm if use_mix else None, box if use_mix else None)
+        ref = src.reshape(B, 3, g, ps, g, ps).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, K)  # conv1 im2col
+        assert torch.equal(out[:, :K], ref.to(BF))
+        assert (out[:, K:] == 0).all()
+    assert torch.equal(ops.cutmix_paste(img, perm, box), mixed)
+
+
+def test_colsum_and_cast():
+    from swat_amd import ops
+    X = rnd(1600, 2304, seed=25, dtype=BF)
+    got = ops.colsum(X)
+    assert (got - X.float().sum(0)).abs().max().item() < 2e-3
+    Xf = rnd(6 * 50, 768, seed=26)
+    got = ops.colsum(Xf, rows=6 * 49, n=768, ld=768, group=(49, 50, 1))
+    ref = Xf.reshape(6, 50, 768)[:, 1:].reshape(-1, 768).sum(0)
+    assert (got - ref).abs().max().item() < 1e-4
+    assert torch.equal(ops.cast_bf16(Xf), Xf.to(BF))
+
+
+def test_tail_kernels():
+    from swat_amd import ops
+    B, E, C = 32, 512, 200
+    f = rnd(B, E, seed=27)
+    W = rnd(C, E, seed=28, scale=0.05)
+    ls = torch.tensor([math.log(1 / 0.07)], device=dev())
+    ya = torch.randint(0, C, (B,), device=dev())
+    yb = ya[torch.randperm(B, device=dev())]
+    lam = 0.37
+    fr, Wr, lsr = f.clone().requires_grad_(True), W.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    fn_ref = fr / fr.norm(dim=-1, keepdim=True)
+    logits_ref = (fn_ref @ Wr.t()) * lsr.exp()
+    ce = torch.nn.CrossEntropyLoss()
+    loss_ref = lam * ce(logits_ref, ya) + (1.0 - lam) * ce(logits_ref, yb)  # mixup_criterion
+    loss_ref.backward()
+    fn, nrm = ops.l2norm_fwd(f)
+    assert (fn - fn_ref).abs().max().item() < 1e-6
+    z = ops.sgemm_small(fn, W, B, C, E, E, 1, 1, E)
+    loss, dz, dls, logits = ops.ce_mixed(z, ls, ya, yb, lam, want_logits=True)
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    assert (logits - logits_ref).abs().max().item() < 1e-4
+    assert abs(dls.item() - lsr.grad.item()) < 1e-5
+    dW = ops.sgemm_small(dz, fn, C, E, B, 1, C, E, 1)  # dW[c,e] = sum_b dz[b,c] fn[b,e]
+    assert (dW - Wr.grad).abs().max().item() < 1e-6
+    dfn = ops.sgemm_small(dz, W, B, E, C, C, 1, E, 1)  # dfn[b,e] = sum_c dz[b,c] W[c,e]
+    df = ops.l2norm_bwd(fn, nrm, dfn)
+    assert (df - fr.grad).abs().max().item() < 1e-6
+    # plain CE = lam 1, yb = ya
+    loss1, _, _, _ = ops.ce_mixed(z, ls, ya, ya, 1.0)
+    assert abs(loss1.item() - ce(logits_ref.detach(), ya).item()) < 1e-5
+
+
+def test_adamw_matches_torch():
+    from swat_amd import ops
+    n = 4096 * 3 + 4
+    segs = [0, 4096, 4096 * 3]
+    lrs = [1e-4, 1e-6, 1e-4]
+    p0 = rnd(n, seed=29)
+    tp = [p0[segs[i]:(segs + [n])[i + 1]].clone().requires_grad_(True) for i in range(3)]
+    opt = torch.optim.AdamW([{"params": [t], "lr": lr, "betas": (0.9, 0.999), "weight_decay": 1e-2} for t, lr in zip(tp, lrs)])
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    shadow = torch.empty(n, dtype=BF, device=dev())
+    lrs_dev = torch.tensor(lrs, device=dev())
+    for step in range(1, 6):
+        g = rnd(n, seed=100 + step, scale=0.1)
+        for i, t in enumerate(tp):
+            t.grad = g[segs[i]:(segs + [n])[i + 1]].clone()
+        opt.step()
+        bc = torch.tensor([1 - 0.9 ** step, 1 - 0.999 ** step], device=dev())
+        ops.adamw_step(p, g, m, v, shadow, segs, lrs_dev, bc)
+        ref = torch.cat([t.detach() for t in tp])
+        assert (p - ref).abs().max().item() < 3e-6
+    assert torch.equal(shadow, p.to(BF))

@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of swat_amd on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): ViT-B/32 (open_clip ViT-B-32-quickgelu, random init) finetuning,
+B = 32 images / GPU, 200 classes, synthetic N(0,1) 224x224 images resident in HBM, one "step" = CutMix + encode_image +
+normalise + head + scaled mixed CE + backward + (gradient all-reduce over RCCL) + fused AdamW + LR step.
+bf16 MFMA operands, fp32 accumulation / residual stream / master weights.
+
+Prints ONE JSON line (rank 0): whole-job img/s, the MFMA roofline of the GEMM kernels (HIP events around every GEMM
+launch in an instrumented replay of the same steps), a CPU baseline (the fp32 oracle on the host cores, N = 1 only) and,
+as a secondary record, the retrieval scan (path B).
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMG_STEP = 26.453  # ViT-B/32 fwd+bwd, SURVEY §8(d) / BASELINE.md §2
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+class _Lg:
+    handlers = []
+
+    def info(self, *a):
+        pass
+
+
+def build_job(dev, world, bsz=32, n_cls=200, arch="ViT-B-32-quickgelu", total_iter=10000):
+    from swat_amd import optimizers
+    from swat_amd.clip_model import CLIP
+    from swat_amd.models import MyLinear
+    from swat_amd.step import FusedTrainStep
+    torch.manual_seed(0)
+    model = CLIP(arch).to(dev)
+    W = torch.randn(n_cls, model.visual.output_dim)
+    W /= W.norm(dim=-1, keepdim=True)
+    head = MyLinear(weights=W).to(dev)
+    args = types.SimpleNamespace(method="cutmix", device=dev, lr_classifier=1e-4, lr_backbone=1e-6, temperature=0.07,
+                                 optim="AdamW", wd=1e-2, epochs=1, cutmix_beta=1.0, mix_prob=0.5, loss_name="CE")
+    params, logit_scale = optimizers.set_params(args, model, head, _Lg())
+    opt, sched, _ = optimizers.set_optimizer(args, params, [None] * total_iter)
+    step = FusedTrainStep(model, head, logit_scale, opt, world_size=world)
+    return args, model, head, step, sched
+
+
+def run_steps(args, step, sched, images, labels, n):
+    from swat_amd.training import cutmix_draw
+    for _ in range(n):
+        lam, perm, box = cutmix_draw(args, images.size())
+        if perm is not None:
+            perm = perm.to(images.device, non_blocking=True)
+            step(images, labels, labels[perm], lam, perm=perm, box=box)
+        else:
+            step(images, labels, labels, 1.0)
+        sched.step()
+
+
+def gemm_roofline(args, step, sched, images, labels, n_steps, bsz):
+    from swat_amd import _lib
+    lib = _lib.lib()
+    lib.swat_gemm_prof_begin(400 * n_steps)
+    run_steps(args, step, sched, images, labels, n_steps)
+    torch.cuda.synchronize()
+    ms = (ctypes.c_double * 6)()
+    cnt = (ctypes.c_int64 * 6)()
+    fl = (ctypes.c_double * 6)()
+    n = lib.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
+    names = ["NT_64", "NT_128", "NN_64", "NN_128", "TN_64", "TN_128"]
+    total_ms = sum(ms) / n_steps
+    algo_flops = GFLOP_PER_IMG_STEP * 1e9 * bsz
+    achieved = algo_flops / (total_ms * 1e-3) / 1e12
+    per_kind = {names[i]: {"launches_per_step": cnt[i] / n_steps, "avg_us": (1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0,
+                           "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0} for i in range(6)}
+    return {"bound": "mfma", "kernel": "gemm_bf16_kernel<layout,tile> (all instantiations)", "achieved": round(achieved, 2),
+            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "gemm_ms_per_step": round(total_ms, 4), "gemm_launches_per_step": n / n_steps,
+            "algorithmic_gflop_per_step": round(algo_flops / 1e9, 1), "per_instantiation": per_kind}
+
+
+def cpu_baseline(bsz=32, n_cls=200, budget_s=20.0):
+    """The fp32 oracle (plain PyTorch on the host cores): same step, B = 32; 1 warm-up + as many steps as fit ~20 s."""
+    from oracle import vit_oracle as vo
+    torch.manual_seed(0)
+    clip = vo.OracleCLIP("ViT-B-32-quickgelu", with_text=False)
+    head = torch.nn.Linear(512, n_cls, bias=False)
+    ls = torch.nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
+    opt = torch.optim.AdamW([{"params": head.parameters(), "lr": 1e-4}, {"params": clip.visual.parameters(), "lr": 1e-6},
+                             {"params": [ls], "lr": 1e-4}], weight_decay=1e-2)
+    x = torch.randn(bsz, 3, 224, 224)
+    y = torch.randint(0, n_cls, (bsz,))
+    perm = torch.randperm(bsz)
+
+    def one():
+        xm = vo.cutmix_paste(x, perm, (30, 40, 130, 160))
+        loss, _ = vo.head_loss(clip.visual(xm), head.weight, ls, y, y[perm], 0.7)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    one()
+    t0 = time.time()
+    n = 0
+    while n < 2 or time.time() - t0 < budget_s:
+        one()
+        n += 1
+        if n >= 30:
+            break
+    dt = time.time() - t0
+    return {"value": round(bsz * n / dt, 2), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steps of the fp32 oracle (oracle/vit_oracle.py, torch CPU) at B={bsz}, ViT-B/32, after 1 warm-up"}
+
+
+def retrieval_secondary(dev, steps=5):
+    """Path B on one shard (1.25 M x 512 fp32 = the per-GPU share of 10 M rows): T2T-rank + T2I-threshold sampler,
+    1000 class queries, k = 500.  HBM roofline of the similarity scan (2048 B/row/matrix)."""
+    from swat_amd.retrieval import ops
+    n, d, nseg, k = 1_250_000, 512, 1000, 500
+    g = torch.Generator(device=dev).manual_seed(7)
+    cap = torch.randn(n, d, device=dev, generator=g)
+    cap /= cap.norm(dim=-1, keepdim=True)
+    img = torch.randn(n, d, device=dev, generator=g)
+    img /= img.norm(dim=-1, keepdim=True)
+    q = torch.randn(nseg, d, device=dev, generator=g)
+    q /= q.norm(dim=-1, keepdim=True)
+    per = n // nseg
+    off = torch.arange(0, n + 1, per, device=dev, dtype=torch.int64)
+    row_seg = torch.repeat_interleave(torch.arange(nseg, device=dev, dtype=torch.int32), per)
+    s1 = torch.empty(n, device=dev)
+    s2 = torch.empty(n, device=dev)
+
+    def once():
+        ops.similarity_segmented(cap, q, row_seg, out=s1)
+        ops.similarity_segmented(img, q, row_seg, out=s2)
+        return ops.segment_topk(s1, off, k, thr=0.0, t2i=s2, t2i_thr=0.0)
+
+    once()
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record()
+    for _ in range(steps):
+        once()
+    e[1].record()
+    e[2].record()
+    for _ in range(steps):
+        ops.similarity_segmented(cap, q, row_seg, out=s1)
+    e[3].record()
+    torch.cuda.synchronize()
+    ms_all = e[0].elapsed_time(e[1]) / steps
+    ms_sim = e[2].elapsed_time(e[3]) / steps
+    gbs = n * d * 4 / 1e9 / (ms_sim * 1e-3)
+    return {"metric": "retrieval top-k queries/s (T2T-rank-T2I-tshd, per-class queries)", "value": round(nseg / (ms_all * 1e-3), 1),
+            "unit": "queries/s", "config": {"workload": f"{n} x {d} fp32 rows x 2 matrices, {nseg} class segments, k={k}"},
+            "ms_per_pass": round(ms_all, 3),
+            "roofline": {"bound": "hbm", "kernel": "sim_segmented_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(ms_sim, 4)}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--bsz", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: swat_amd has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    args, model, head, step, sched = build_job(dev, world, a.bsz)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(a.bsz, 3, 224, 224, device=dev, generator=g)
+    labels = torch.randint(0, 200, (a.bsz,), device=dev, generator=g)
+    np.random.seed(1)      # same CutMix scalars (r, lam, box) on every rank; the permutation is over the local shard
+    torch.manual_seed(1)
+
+    run_steps(args, step, sched, images, labels, a.warmup)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    run_steps(args, step, sched, images, labels, a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = step.loss.item()
+    assert math.isfinite(loss), "training diverged"
+
+    out = None
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        out = {"metric": "finetune img/s (ViT-B/32 bsz=32)", "value": round(world * a.bsz * a.steps / dt, 1), "unit": "img/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "ViT-B/32 (open_clip ViT-B-32-quickgelu, random init) --method cutmix finetune step, "
+                                      "200 classes, AdamW 3 LR groups, fp32 master + bf16 MFMA", "per_gpu_batch": a.bsz,
+                          "global_batch": a.bsz * world, "image": "3x224x224 fp32 resident in HBM",
+                          "parallelism": f"dp{world}" if world > 1 else "single"},
+               "final_loss": round(loss, 4),
+               "step_mfma_frac": round(GFLOP_PER_IMG_STEP * 1e9 * a.bsz / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    if world == 1:
+        out["roofline"] = gemm_roofline(args, step, sched, images, labels, min(a.steps, 10), a.bsz)
+        if not a.no_cpu_baseline:
+            del step, model
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(a.bsz)
+        if not a.no_secondary:
+            out["secondary"] = [retrieval_secondary(dev)]
+    elif rank == 0:
+        out["roofline"] = None
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,12 @@ int swat_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int
                    const void* actin, int ldact, int act, void* C2, int out_f32, float alpha,
                    swat_stream_t stream);
 
+/*     Measurement hooks (bench.py roofline leg): time every GEMM launch with hipEvents recorded on the
+ *     launch stream.  end() synchronises and fills 6 slots indexed layout*2 + (128x128 tile ? 1 : 0)
+ *     with total milliseconds, launch counts and 2*M*N*K*batch flops; returns the launches seen. */
+int swat_gemm_prof_begin(int max_launches);
+int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind);
+
 /* A2b,f,g  LayerNorm (eps inside rsqrt, biased variance = torch.nn.LayerNorm). x fp32 with an explicit
  *     row stride (so the cls rows of [B,T,d] can be normalised in place); y in bf16 and/or fp32. */
 int swat_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,

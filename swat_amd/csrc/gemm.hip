@@ -270,16 +270,70 @@ static int launch_gemm(const GemmArgs& a, int batch, int tile, hipStream_t s) {
     return check_launch("swat_gemm_bf16");
 }
 
+// ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around every GEMM ----
+struct GemmProf {
+    bool on = false;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;  // 2 per launch
+    int* kind = nullptr;       // layout * 2 + (tile == 128)
+    double* flops = nullptr;
+};
+static GemmProf g_prof;
+
 int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     // tile choice: 128x128 only when it still yields >= ~1.5 waves of blocks over 256 CUs
     const int64_t big = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
     const int tile = (big >= 384 && a.M >= 128 && a.N >= 128) ? 128 : 64;
-    if (layout == L_NT) return launch_gemm<L_NT>(a, batch, tile, s);
-    if (layout == L_NN) return launch_gemm<L_NN>(a, batch, tile, s);
-    return launch_gemm<L_TN>(a, batch, tile, s);
+    const bool prof = g_prof.on && g_prof.n < g_prof.cap;
+    if (prof) hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+    int rc;
+    if (layout == L_NT) rc = launch_gemm<L_NT>(a, batch, tile, s);
+    else if (layout == L_NN) rc = launch_gemm<L_NN>(a, batch, tile, s);
+    else rc = launch_gemm<L_TN>(a, batch, tile, s);
+    if (prof) {
+        hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
+        g_prof.kind[g_prof.n] = layout * 2 + (tile == 128);
+        g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
+        ++g_prof.n;
+    }
+    return rc;
 }
 
 }  // namespace swat
+
+// Start timing every GEMM launch (up to max_launches) with hipEvents on its own stream; not graph-capturable.
+SWAT_API int swat_gemm_prof_begin(int max_launches) {
+    using swat::g_prof;
+    if (g_prof.ev) {
+        for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+        delete[] g_prof.ev; delete[] g_prof.kind; delete[] g_prof.flops;
+    }
+    g_prof.cap = max_launches; g_prof.n = 0;
+    g_prof.ev = new hipEvent_t[2 * max_launches];
+    g_prof.kind = new int[max_launches];
+    g_prof.flops = new double[max_launches];
+    for (int i = 0; i < 2 * max_launches; ++i) hipEventCreate(&g_prof.ev[i]);
+    g_prof.on = true;
+    return 0;
+}
+
+// Stop, synchronise the events and report per kind (layout*2 + is128; 6 kinds): total ms, launches, flops launched.
+SWAT_API int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind) {
+    using swat::g_prof;
+    g_prof.on = false;
+    for (int k = 0; k < 6; ++k) { ms_by_kind[k] = 0; count_by_kind[k] = 0; flops_by_kind[k] = 0; }
+    for (int i = 0; i < g_prof.n; ++i) {
+        hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        ms_by_kind[g_prof.kind[i]] += ms;
+        count_by_kind[g_prof.kind[i]] += 1;
+        flops_by_kind[g_prof.kind[i]] += g_prof.flops[i];
+    }
+    const int n = g_prof.n;
+    g_prof.n = 0;
+    return n;
+}
 
 // Generic entry (tests, attention as batched GEMMs).  See include/swat_hip.h.
 SWAT_API int swat_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,

@@ -73,6 +73,11 @@ int swat_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int
 /*     Measurement hooks (bench.py roofline leg): time every GEMM launch with hipEvents recorded on the
  *     launch stream.  end() synchronises and fills 6 slots indexed layout*2 + (128x128 tile ? 1 : 0)
  *     with total milliseconds, launch counts and 2*M*N*K*batch flops; returns the launches seen. */
+/*     swat_gemm_set_tile: pin one tile configuration (0 64x64x32, 1 128x128x64, 2 64x64x64, 3 128x128x32,
+ *     4 128x64x64, 5 64x128x64; -1 = automatic) — tests and tuning. */
+int swat_gemm_set_tile(int cfg);
+int swat_gemm_set_exp(int bits); /* tuning only: ablate loads / MFMA / epilogue of the LDS-DMA kernel (results wrong) */
+int swat_gemm_set_swizzle(int mode); /* 0 = plain 2-D grid, -1 = XCD-aware tile order (default) */
 int swat_gemm_prof_begin(int max_launches);
 int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind);
 
@@ -114,6 +119,10 @@ int swat_cls_row(float* x, const float* cls, const float* pos, int B, int T, int
  *     Optional row grouping (logical row r -> (r/group_rows)*group_stride_rows + r%group_rows + row_off). */
 int swat_colsum(const void* X, int dtype, int64_t rows, int n, int ld, float* out, int64_t group_rows,
                 int64_t group_stride_rows, int64_t row_off, swat_stream_t stream);
+/*     two-stage form for the large bias gradients (rows = B*T): workspace of swat_colsum_bf16_workspace_bytes(n). */
+int64_t swat_colsum_bf16_workspace_bytes(int n);
+int swat_colsum_bf16(const void* X_bf16, int64_t rows, int n, int ld, float* out, void* workspace,
+                     swat_stream_t stream);
 int swat_gather_cast_bf16(const float* in, void* out_bf16, int64_t rows, int d, int64_t group_rows,
                           int64_t group_stride_rows, int64_t row_off, swat_stream_t stream);
 int swat_cast_bf16(const float* in, void* out_bf16, int64_t n, swat_stream_t stream);

@@ -144,17 +144,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int d, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d) return;
+// block = 64 columns x 4 partial-lanes; lane j sums partials j, j+4, ... then the 4 lanes combine in a fixed order
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int d,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sh[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = threadIdx.x >> 6;
     float a = 0.f, b = 0.f;
-    for (int i = 0; i < nblk; ++i) {
-        a += part[((int64_t)i * 2 + 0) * d + c];
-        b += part[((int64_t)i * 2 + 1) * d + c];
+    if (c < d) {
+        for (int i = j; i < nblk; i += 4) {
+            a += part[((int64_t)i * 2 + 0) * d + c];
+            b += part[((int64_t)i * 2 + 1) * d + c];
+        }
     }
-    dgamma[c] = a;
-    dbeta[c] = b;
+    sh[0][j][threadIdx.x & 63] = a;
+    sh[1][j][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (j == 0 && c < d) {
+        const int t = threadIdx.x;
+        dgamma[c] = ((sh[0][0][t] + sh[0][1][t]) + sh[0][2][t]) + sh[0][3][t];
+        dbeta[c] = ((sh[1][0][t] + sh[1][1][t]) + sh[1][2][t]) + sh[1][3][t];
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -285,6 +295,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
     if (rl == 0 && col < n) out[col] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
 }
 
+// Two-stage bf16 column sum for the bias gradients of the big GEMMs (rows = B*T): stage 1 — grid (n/256, R):
+// each thread owns 4 adjacent columns (8-B loads) and one of 4 row lanes inside its row chunk; stage 2 sums
+// the R partials in chunk order.  Fixed order -> deterministic.
+constexpr int COLSUM_R = 32;
+__global__ __launch_bounds__(256) void colsum2_stage1_kernel(const unsigned short* __restrict__ X, int64_t rows, int n, int ld,
+                                                             float* __restrict__ part) {
+    __shared__ float4 sh[4][64];
+    const int cg = blockIdx.x * 64 + (threadIdx.x & 63);  // 4-column group
+    const int rl = threadIdx.x >> 6;
+    const int64_t per = (rows + COLSUM_R - 1) / COLSUM_R;
+    const int64_t r0 = (int64_t)blockIdx.y * per;
+    const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cg * 4 < n) {
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            const ushort4 v = *reinterpret_cast<const ushort4*>(X + r * ld + cg * 4);
+            acc.x += bf2f(v.x); acc.y += bf2f(v.y); acc.z += bf2f(v.z); acc.w += bf2f(v.w);
+        }
+    }
+    sh[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && cg * 4 < n) {
+        const int t = threadIdx.x;
+        float4 o;
+        o.x = ((sh[0][t].x + sh[1][t].x) + sh[2][t].x) + sh[3][t].x;
+        o.y = ((sh[0][t].y + sh[1][t].y) + sh[2][t].y) + sh[3][t].y;
+        o.z = ((sh[0][t].z + sh[1][t].z) + sh[2][t].z) + sh[3][t].z;
+        o.w = ((sh[0][t].w + sh[1][t].w) + sh[2][t].w) + sh[3][t].w;
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * n + cg * 4) = o;
+    }
+}
+__global__ void colsum2_stage2_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float a = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < COLSUM_R; ++r) a += part[(int64_t)r * n + c];
+    out[c] = a;
+}
+
 // gather rows + cast fp32 -> bf16: out[r, :] = in[(r / g) * gs + (r % g) + off, :]
 __global__ void gather_cast_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int64_t rows, int d,
                                    int64_t g, int64_t gs, int64_t off) {
@@ -389,7 +439,7 @@ SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float*
     if (nblk > 256) nblk = 256;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
                        dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d);
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float*)workspace,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta);
     return check_launch("swat_layernorm_bwd");
 }
@@ -445,6 +495,19 @@ SWAT_API int swat_colsum(const void* X, int dtype, int64_t rows, int n, int ld, 
         hipLaunchKernelGGL((colsum_kernel<float>), dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)s, (const float*)X, rows,
                            n, ld, out, group_rows, group_stride_rows, row_off);
     return check_launch("swat_colsum");
+}
+
+SWAT_API int64_t swat_colsum_bf16_workspace_bytes(int n) { return (int64_t)COLSUM_R * n * sizeof(float); }
+
+SWAT_API int swat_colsum_bf16(const void* X_bf16, int64_t rows, int n, int ld, float* out, void* workspace,
+                              swat_stream_t s) {
+    SWAT_REQUIRE(n % 4 == 0 && ld % 4 == 0, "swat_colsum_bf16: n and ld must be multiples of 4");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(colsum2_stage1_kernel, dim3((n / 4 + 63) / 64, COLSUM_R), dim3(256), 0, (hipStream_t)s,
+                       (const unsigned short*)X_bf16, rows, n, ld, (float*)workspace);
+    hipLaunchKernelGGL(colsum2_stage2_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float*)workspace, n,
+                       out);
+    return check_launch("swat_colsum_bf16");
 }
 
 SWAT_API int swat_gather_cast_bf16(const float* in, void* out_bf16, int64_t rows, int d, int64_t group_rows,

@@ -8,14 +8,23 @@
 //   layout NN: A[M,K] (k contiguous)  B[K,N] (n contiguous)      dgrad     dX = dY W
 //   layout TN: A[K,M] (m contiguous)  B[K,N] (n contiguous)      wgrad     dW = dY^T X
 //
-// Structure: 256 threads = 4 waves (2x2), block tile BMxBN (128x128 or 64x64), BK = 32, register-staged
-// global->LDS with two LDS buffers (loads for step t+1 are issued before the MFMAs of step t).
-// Operands whose reduction index is contiguous live in LDS as [rows][32] with a 16-B-slot XOR swizzle and
-// are read with ds_read_b64; operands whose reduction index is strided live as [32][rows+16] and are read
-// with ds_read_b64_tr_b16 (hardware transpose).  Both use ONE logical-k assignment per fragment element
-// (j<4 -> k=4g+j, j>=4 -> k=16+4g+j-4, g = lane>>4) so that every LDS read is bank-conflict-free.
-// The MFMA is issued as mfma(Bfrag, Afrag) so each lane ends up with 4 CONSECUTIVE n of one row m:
-// epilogue loads/stores are 8-16 B per lane.
+// 256 threads = 4 waves (2 x 2), block tile BM x BN, 64-deep k-steps.  Two kernels share ONE LDS image:
+//   * gemm_glds_kernel  (K % 64 == 0): tiles go global -> LDS by global_load_lds_dwordx4 (no VGPR staging, no
+//     ds_write), NSTAGE buffers, NSTAGE-1 stages in flight behind a counted s_waitcnt vmcnt(N) + raw s_barrier.
+//     The finetuning GEMMs are small (M = B*T = 1600, ~1 block per CU): latency has to be hidden by prefetch
+//     depth inside the wave, not by occupancy.
+//   * gemm_stage_kernel (any K): same image filled through registers with zero-filled K tails (attention's
+//     T-deep products, ViT-L/14's 588-wide patch rows).
+// LDS image (LINEAR, because an LDS-DMA instruction writes wave-uniform base + lane*16; the bank-conflict swizzle
+// is applied to the per-lane SOURCE address and again on the read):
+//   k-contiguous tile [rows][64]: 16-B slot t of row r lives at slot t ^ ((r >> 1) & 7); fragments are ONE
+//       ds_read_b128 per lane (k = 32 ks + 8 g + j, g = lane >> 4) — conflict-free for b128's 16-lane groups.
+//   k-strided tile [64][R]: 32-B column group c of k-row k lives at group c ^ f(k); fragments are two
+//       ds_read_b64_tr_b16 (hardware transpose) — f() makes the 8 k-rows a half-wave touches hit distinct banks.
+//   (Two ds_read_b64 per fragment would be fused by hipcc into ds_read2st64_b64, whose 32-bank / 4x16-lane
+//   grouping conflicts heavily on these images: measured 15x slower LDS phase.  Hence b128 + tr_b64 only.)
+// The MFMA is issued as mfma(Bfrag, Afrag) so each lane ends up with 4 CONSECUTIVE n of one row m: epilogue
+// loads/stores are 8-16 B per lane.
 #include "kernels.hpp"
 #include "../../include/swat_hip.h"
 
@@ -44,173 +53,52 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
     return 1.0f;
 }
 
-template <int LAYOUT, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
-    constexpr bool A_KC = (LAYOUT != L_TN);  // A reduction index contiguous
-    constexpr bool B_KC = (LAYOUT == L_NT);
-    constexpr int BK = 32;
-    constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
-    constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int RSA = 2 * BM + 32, RSB = 2 * BN + 32;          // strided-tile row stride (bytes)
-    constexpr int A_BYTES = A_KC ? BM * 64 : 32 * RSA;
-    constexpr int B_BYTES = B_KC ? BN * 64 : 32 * RSB;
-    constexpr int A_CH = BM * BK / 8 / 256;  // 16-B chunks per thread per step
-    constexpr int B_CH = BN * BK / 8 / 256;
-    static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
+// ---- the shared LDS image --------------------------------------------------------------------------------------
+template <int TILE_ROWS>
+__device__ __forceinline__ int st_f(int k) {  // column-group swizzle of a k-strided tile
+    if constexpr (TILE_ROWS == 128) return (k & 3) | ((k >> 1) & 4);
+    else return ((k >> 1) & 1) | ((k >> 2) & 2);
+}
+// byte offset of 16-B chunk (row, slot t) of a k-contiguous tile
+__device__ __forceinline__ int kc_off(int row, int t) { return row * 128 + ((t ^ ((row >> 1) & 7)) << 4); }
+// byte offset of 16-B chunk (k-row, 16-B column chunk c16) of a k-strided tile with TILE_ROWS columns
+template <int TILE_ROWS>
+__device__ __forceinline__ int st_off(int k, int c16) {
+    return k * (TILE_ROWS * 2) + ((((c16 >> 1) ^ st_f<TILE_ROWS>(k)) << 5) | ((c16 & 1) << 4));
+}
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm0 = (wave >> 1) * WM;
-    const int wn0 = (wave & 1) * WN;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int z = blockIdx.z;
-    const int zo = z / p.inner, zi = z % p.inner;
-    const unsigned short* __restrict__ A = p.A + zo * p.sA0 + zi * p.sA1;
-    const unsigned short* __restrict__ B = p.B + zo * p.sB0 + zi * p.sB1;
-    const int M = p.M, N = p.N, K = p.K;
-
-    // ---- staging: per-thread chunk coordinates ----
-    s16x8_t ra[A_CH], rb[B_CH];
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int c = tid + 256 * i;
-            if constexpr (A_KC) {
-                const int row = c >> 2, t = c & 3;
-                int gm = m0 + row; gm = gm < M ? gm : M - 1;
-                const int gk = k0 + 8 * t;
-                s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (gk < K) {
-                    v = *reinterpret_cast<const s16x8_t*>(A + (int64_t)gm * p.lda + gk);
-                    if (gk + 8 > K) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) if (gk + e >= K) v[e] = 0;
-                    }
-                }
-                ra[i] = v;
-            } else {
-                const int krow = c / (BM / 8), c8 = c % (BM / 8);
-                const int gk = k0 + krow;
-                int gm = m0 + 8 * c8; gm = gm + 8 <= p.lda ? gm : 0;  // keep the 16-B load inside the row
-                s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (gk < K) v = *reinterpret_cast<const s16x8_t*>(A + (int64_t)gk * p.lda + gm);
-                ra[i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            const int c = tid + 256 * i;
-            if constexpr (B_KC) {
-                const int row = c >> 2, t = c & 3;
-                int gn = n0 + row; gn = gn < N ? gn : N - 1;
-                const int gk = k0 + 8 * t;
-                s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (gk < K) {
-                    v = *reinterpret_cast<const s16x8_t*>(B + (int64_t)gn * p.ldb + gk);
-                    if (gk + 8 > K) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) if (gk + e >= K) v[e] = 0;
-                    }
-                }
-                rb[i] = v;
-            } else {
-                const int krow = c / (BN / 8), c8 = c % (BN / 8);
-                const int gk = k0 + krow;
-                int gn = n0 + 8 * c8; gn = gn + 8 <= p.ldb ? gn : 0;
-                s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (gk < K) v = *reinterpret_cast<const s16x8_t*>(B + (int64_t)gk * p.ldb + gn);
-                rb[i] = v;
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
-        unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int c = tid + 256 * i;
-            if constexpr (A_KC) {
-                const int row = c >> 2, t = c & 3;
-                *reinterpret_cast<s16x8_t*>(sa + row * 64 + ((t ^ ((row >> 2) & 3)) << 4)) = ra[i];
-            } else {
-                const int krow = c / (BM / 8), c8 = c % (BM / 8);
-                *reinterpret_cast<s16x8_t*>(sa + krow * RSA + c8 * 16) = ra[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            const int c = tid + 256 * i;
-            if constexpr (B_KC) {
-                const int row = c >> 2, t = c & 3;
-                *reinterpret_cast<s16x8_t*>(sb + row * 64 + ((t ^ ((row >> 2) & 3)) << 4)) = rb[i];
-            } else {
-                const int krow = c / (BN / 8), c8 = c % (BN / 8);
-                *reinterpret_cast<s16x8_t*>(sb + krow * RSB + c8 * 16) = rb[i];
-            }
-        }
-    };
-
-    // ---- fragment read (8 bf16 per lane) ----
+// fragment of 8 bf16 for the 32-deep sub-step ks: lane (r16 = lane & 15, g = lane >> 4) gets k = 32 ks + 8 g + 0..7
+template <bool KCONTIG, int TILE_ROWS>
+__device__ __forceinline__ bf16x8_t read_frag(const unsigned char* tile, int base_row, int ks, int lane) {
     const int r16 = lane & 15, g = lane >> 4;
-    auto read_frag = [&](const unsigned char* tile, bool kcontig, int base_row, int rs) -> bf16x8_t {
-        s16x4_t lo, hi;
-        if (kcontig) {
-            const int row = base_row + r16;
-            const int sw = (row >> 2) & 3;
-            const unsigned char* rp = tile + row * 64 + (g & 1) * 8;
-            lo = *reinterpret_cast<const s16x4_t*>(rp + ((((g >> 1)) ^ sw) << 4));
-            hi = *reinterpret_cast<const s16x4_t*>(rp + (((2 + (g >> 1)) ^ sw) << 4));
-        } else {
-            const int q = r16 >> 2, pp = r16 & 3;
-            const unsigned char* rp = tile + (4 * g + q) * rs + (base_row + 4 * pp) * 2;
-            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4_t*)(rp));
-            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4_t*)(rp + 16 * rs));
-        }
-        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if constexpr (KCONTIG) {
+        const s16x8_t v = *reinterpret_cast<const s16x8_t*>(tile + kc_off(base_row + r16, 4 * ks + g));
         return __builtin_bit_cast(bf16x8_t, v);
-    };
-
-    f32x4_t acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nk) load_tiles((t + 1) * BK);
-        const unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
-        const unsigned char* sb = sa + A_BYTES;
-        bf16x8_t af[FM], bfr[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = read_frag(sa, A_KC, wm0 + 16 * i, RSA);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bfr[j] = read_frag(sb, B_KC, wn0 + 16 * j, RSB);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        if (t + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
+    } else {
+        constexpr int RS = TILE_ROWS * 2;
+        const int q = r16 >> 2, pp = r16 & 3;
+        const int k = 32 * ks + 8 * g + q;
+        const int c32 = base_row >> 4;
+        const unsigned char* lo_p = tile + k * RS + ((c32 ^ st_f<TILE_ROWS>(k)) << 5) + 8 * pp;
+        const unsigned char* hi_p = tile + (k + 4) * RS + ((c32 ^ st_f<TILE_ROWS>(k + 4)) << 5) + 8 * pp;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lo_p));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(hi_p));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, v);
     }
+}
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = ..+(lane&15), n = ..+4*(lane>>4) ----
+// ---- epilogue shared by both kernels: lane holds C[m][n..n+3], m = mbase + 16 i + (lane & 15), n = nbase + 16 j + 4 (lane >> 4)
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int mbase, int nbase, int lane,
+                                              int zo, int zi) {
+    const int M = p.M, N = p.N;
+    const int r16 = lane & 15, g = lane >> 4;
     const int Np4 = (N + 3) & ~3;
     const int64_t coff = zo * p.sC0 + zi * p.sC1;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm0 + 16 * i + r16;
+        const int m = mbase + 16 * i + r16;
         if (m >= M) continue;
         int orow = m;
         int brow = 0;
@@ -220,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn0 + 16 * j + 4 * g;
+            const int n = nbase + 16 * j + 4 * g;
             if (n >= Np4) continue;
             float v[4];
 #pragma unroll
@@ -258,16 +146,312 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     }
 }
 
-template <int LAYOUT>
-static int launch_gemm(const GemmArgs& a, int batch, int tile, hipStream_t s) {
-    if (tile == 128) {
-        dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, batch);
-        hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, 128, 128>), grid, dim3(256), 0, s, a);
-    } else {
-        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, batch);
-        hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, 64, 64>), grid, dim3(256), 0, s, a);
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, speed only — never correctness).
+// Give each XCD a CONTIGUOUS chunk of the tile list, ordered so its tiles share A-row / B-column panels.
+__device__ __forceinline__ void tile_coords(const GemmArgs& p, int& bx, int& by) {
+    if (p.swz == 0) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int lb = blockIdx.x;
+    const int xcd = lb & 7, q = nblk >> 3, r = nblk & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lb >> 3);  // bijective for any nblk
+    if (p.swz == 1) { by = id % p.tiles_m; bx = id / p.tiles_m; }
+    else { bx = id % p.tiles_n; by = id / p.tiles_n; }
+}
+
+template <int FM, int FN, bool A_KC, bool B_KC, int BM, int BN, bool NOMFMA = false>
+__device__ __forceinline__ void mma_stage(const unsigned char* sa, const unsigned char* sb, int wm0, int wn0, int lane,
+                                          f32x4_t (&acc)[FM][FN]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = read_frag<A_KC, BM>(sa, wm0 + 16 * i, ks, lane);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = read_frag<B_KC, BN>(sb, wn0 + 16 * j, ks, lane);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                if constexpr (NOMFMA) acc[i][j][0] += (float)af[i][0] + (float)bfr[j][0];
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// register-staged kernel (any K; zero-filled K tail), 2 LDS buffers
+// --------------------------------------------------------------------------------------------
+template <int LAYOUT, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_stage_kernel(const GemmArgs p) {
+    constexpr bool A_KC = (LAYOUT != L_TN);
+    constexpr bool B_KC = (LAYOUT == L_NT);
+    constexpr int BK = 64;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int A_CH = A_BYTES / 16 / 256, B_CH = B_BYTES / 16 / 256;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM;
+    const int wn0 = (wave & 1) * WN;
+    int bx, by;
+    tile_coords(p, bx, by);
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int zo = z / p.inner, zi = z % p.inner;
+    const unsigned short* __restrict__ A = p.A + zo * p.sA0 + zi * p.sA1;
+    const unsigned short* __restrict__ B = p.B + zo * p.sB0 + zi * p.sB1;
+    const int M = p.M, N = p.N, K = p.K;
+
+    s16x8_t ra[A_CH], rb[B_CH];
+    auto load_one = [&](const unsigned short* __restrict__ P, bool kcontig, int c, int row0, int R, int ld, int tile_rows,
+                        int k0) -> s16x8_t {
+        s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (kcontig) {
+            const int row = c >> 3, t = c & 7;
+            int gr = row0 + row; gr = gr < R ? gr : R - 1;
+            const int gk = k0 + 8 * t;
+            if (gk < K) {
+                v = *reinterpret_cast<const s16x8_t*>(P + (int64_t)gr * ld + gk);
+                if (gk + 8 > K) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (gk + e >= K) v[e] = 0;
+                }
+            }
+        } else {
+            const int krow = c / (tile_rows / 8), c16 = c % (tile_rows / 8);
+            const int gk = k0 + krow;
+            int gr = row0 + 8 * c16; gr = gr + 8 <= ld ? gr : 0;  // keep the 16-B load inside the row
+            if (gk < K) v = *reinterpret_cast<const s16x8_t*>(P + (int64_t)gk * ld + gr);
+        }
+        return v;
+    };
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) ra[i] = load_one(A, A_KC, tid + 256 * i, m0, M, p.lda, BM, k0);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) rb[i] = load_one(B, B_KC, tid + 256 * i, n0, N, p.ldb, BN, k0);
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int c = tid + 256 * i;
+            const int off = A_KC ? kc_off(c >> 3, c & 7) : st_off<BM>(c / (BM / 8), c % (BM / 8));
+            *reinterpret_cast<s16x8_t*>(sa + off) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int c = tid + 256 * i;
+            const int off = B_KC ? kc_off(c >> 3, c & 7) : st_off<BN>(c / (BN / 8), c % (BN / 8));
+            *reinterpret_cast<s16x8_t*>(sb + off) = rb[i];
+        }
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) load_tiles((t + 1) * BK);
+        const unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
+        mma_stage<FM, FN, A_KC, B_KC, BM, BN>(sa, sa + A_BYTES, wm0, wn0, lane, acc);
+        if (t + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+}
+
+// --------------------------------------------------------------------------------------------
+// LDS-DMA pipelined kernel (K % 64 == 0)
+// --------------------------------------------------------------------------------------------
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+template <int LAYOUT, int BM, int BN, int NSTAGE, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmArgs p) {
+    constexpr int NW = WGM * WGN;  // waves per block (4 or 8: two waves per SIMD overlap each other's DMA issue / LDS reads)
+    constexpr bool A_KC = (LAYOUT != L_TN);
+    constexpr bool B_KC = (LAYOUT == L_NT);
+    constexpr int BK = 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INS = A_BYTES / 1024 / NW, B_INS = B_BYTES / 1024 / NW;  // DMA instructions per wave per stage
+    constexpr int LPS = A_INS + B_INS;
+    static_assert(A_INS >= 1 && B_INS >= 1, "tile too small for this many waves");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WGN) * WM;
+    const int wn0 = (wave % WGN) * WN;
+    int bx, by;
+    tile_coords(p, bx, by);
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int zo = z / p.inner, zi = z % p.inner;
+    const unsigned short* __restrict__ A = p.A + zo * p.sA0 + zi * p.sA1;
+    const unsigned short* __restrict__ B = p.B + zo * p.sB0 + zi * p.sB1;
+    const int M = p.M, N = p.N, K = p.K;
+
+    // per-lane SOURCE offsets (elements, without k0): DMA instruction `ins` fills LDS bytes [ins*1024, +1024), lane
+    // owns 16 of them; the source chunk is whatever the image says lives there (inverse of kc_off / st_off).
+    int64_t offA[A_INS], offB[B_INS];
+    auto src_off = [&](bool kcontig, int ins, int row0, int R, int ld, int tile_rows) -> int64_t {
+        const int byte = ins * 1024 + lane * 16;
+        if (kcontig) {
+            const int row = byte >> 7, ps = (byte >> 4) & 7;
+            const int t = ps ^ ((row >> 1) & 7);
+            int gr = row0 + row; gr = gr < R ? gr : R - 1;
+            return (int64_t)gr * ld + 8 * t;
+        } else {
+            const int rs = tile_rows * 2;
+            const int k = byte / rs, pc16 = (byte % rs) >> 4;
+            const int f = tile_rows == 128 ? st_f<128>(k) : st_f<64>(k);
+            const int c16 = (((pc16 >> 1) ^ f) << 1) | (pc16 & 1);
+            int gr = row0 + 8 * c16; gr = gr + 8 <= ld ? gr : 0;
+            return (int64_t)k * ld + gr;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < A_INS; ++i) offA[i] = src_off(A_KC, wave + NW * i, m0, M, p.lda, BM);
+#pragma unroll
+    for (int i = 0; i < B_INS; ++i) offB[i] = src_off(B_KC, wave + NW * i, n0, N, p.ldb, BN);
+    const int64_t kstepA = A_KC ? 64 : (int64_t)64 * p.lda;
+    const int64_t kstepB = B_KC ? 64 : (int64_t)64 * p.ldb;
+
+    auto issue = [&](int t) {
+        unsigned char* sa = smem + (t % NSTAGE) * STAGE;
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_INS; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + offA[i] + t * kstepA),
+                                             (__attribute__((address_space(3))) void*)(sa + (wave + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_INS; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + offB[i] + t * kstepB),
+                                             (__attribute__((address_space(3))) void*)(sb + (wave + NW * i) * 1024), 16, 0, 0);
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) issue(s);
+
+    for (int t = 0; t < nk; ++t) {
+        // stage t has landed once at most the younger issued stages (<= NSTAGE-2 of them) are still outstanding
+        const int younger = nk - 1 - t < NSTAGE - 2 ? nk - 1 - t : NSTAGE - 2;
+        if (younger >= 2) wait_vmcnt<2 * LPS>();
+        else if (younger == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads of step t-1 are complete
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NSTAGE - 1 < nk && !(p.exp & 1)) issue(t + NSTAGE - 1);  // into the buffer every wave finished reading at step t-1
+        const unsigned char* sa = smem + ((p.exp & 8) ? 0 : (t % NSTAGE)) * STAGE;
+        if (p.exp & 2) mma_stage<FM, FN, A_KC, B_KC, BM, BN, true>(sa, sa + A_BYTES, wm0, wn0, lane, acc);
+        else mma_stage<FM, FN, A_KC, B_KC, BM, BN, false>(sa, sa + A_BYTES, wm0, wn0, lane, acc);
+    }
+    if (!(p.exp & 4)) gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+    else if (acc[0][0][0] == 12345.f) ((float*)p.C)[0] = 1.f;
+}
+
+static int g_exp = 0;
+static int g_swz_mode = -1;  // -1 automatic, 0 off (swat_gemm_set_swizzle)
+
+// grid + XCD-aware tile order: per-XCD working set = (#distinct row tiles) * BM * K + (#distinct col tiles) * BN * K
+static dim3 plan_grid(GemmArgs& b, int bm, int bn, int batch) {
+    const int tm = (b.M + bm - 1) / bm, tn = (b.N + bn - 1) / bn;
+    b.tiles_m = tm; b.tiles_n = tn; b.swz = 0; b.exp = g_exp;
+    if (batch != 1 || tm * tn < 16 || g_swz_mode == 0) return dim3(tn, tm, batch);
+    const int per = (tm * tn + 7) / 8;
+    auto ws = [&](int fast, int slow, int fsz, int ssz) {  // `per` consecutive tiles, `fast` dimension first
+        const int nf = per < fast ? per : fast;
+        const int ns = (per + fast - 1) / fast + (per % fast ? 1 : 0);
+        return (int64_t)nf * fsz + (int64_t)(ns < slow ? ns : slow) * ssz;
+    };
+    const int64_t m_first = ws(tm, tn, bm, bn), n_first = ws(tn, tm, bn, bm);
+    b.swz = m_first <= n_first ? 1 : 2;
+    return dim3(tm * tn, 1, 1);
+}
+
+// tile configurations.  register-staged: 0 = 64x64, 1 = 128x128, 2 = 128x64, 3 = 64x128;
+// LDS-DMA pipelined: 6 = 128x128 x 3 stages, 7 = 64x64 x 4 stages, 8 = 128x64 x 4 stages, 9 = 64x64 x 3 stages
+template <int LAYOUT>
+static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
+#define SWAT_STAGE(BM_, BN_)                                                                              \
+    {                                                                                                     \
+        GemmArgs b = a;                                                                                   \
+        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
+        hipLaunchKernelGGL((gemm_stage_kernel<LAYOUT, BM_, BN_>), grid, dim3(256), 0, s, b);              \
+    }
+#define SWAT_GLDS(BM_, BN_, NS_)                                                                          \
+    {                                                                                                     \
+        GemmArgs b = a;                                                                                   \
+        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
+        hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, BM_, BN_, NS_>), grid, dim3(256), 0, s, b);          \
+    }
+#define SWAT_GLDS8(BM_, BN_, NS_, WGM_, WGN_)                                                             \
+    {                                                                                                     \
+        GemmArgs b = a;                                                                                   \
+        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
+        hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, b); \
+    }
+    if (cfg >= 6 && a.K % 64 != 0) cfg = (cfg == 6 || cfg >= 10) ? 1 : (cfg == 8 ? 2 : 0);  // the LDS-DMA kernel has no K tail
+    switch (cfg) {
+        case 1: SWAT_STAGE(128, 128) break;
+        case 2: SWAT_STAGE(128, 64) break;
+        case 3: SWAT_STAGE(64, 128) break;
+        case 6: SWAT_GLDS(128, 128, 3) break;
+        case 7: SWAT_GLDS(64, 64, 4) break;
+        case 8: SWAT_GLDS(128, 64, 4) break;
+        case 9: SWAT_GLDS(64, 64, 3) break;
+        case 10: SWAT_GLDS8(128, 128, 3, 2, 4) break;
+        case 11: SWAT_GLDS8(128, 128, 3, 4, 2) break;
+        case 12: SWAT_GLDS8(128, 64, 4, 4, 2) break;
+        case 13: SWAT_GLDS8(256, 128, 2, 4, 2) break;
+        default: SWAT_STAGE(64, 64) break;
+    }
+#undef SWAT_STAGE
+#undef SWAT_GLDS
+#undef SWAT_GLDS8
     return check_launch("swat_gemm_bf16");
+}
+
+static int g_force_cfg = -1;  // swat_gemm_set_tile(): experiments / tests pin one configuration
+
+static int pick_cfg(const GemmArgs& a, int batch) {
+    if (g_force_cfg >= 0) return g_force_cfg;
+    auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * batch; };
+    // measured on MI355X (tools/perf_gemm.py, M = 1600): with ~1 block per CU the 64x64 x 3-stage LDS-DMA tile wins on
+    // every shape of the step; 8-wave 128x128 only pays once a launch has many more tiles than CUs.
+    if (a.M >= 1024 && a.N >= 1024 && blocks(128, 128) >= 1024) return 10;
+    return 9;
 }
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around every GEMM ----
@@ -275,15 +459,13 @@ struct GemmProf {
     bool on = false;
     int cap = 0, n = 0;
     hipEvent_t* ev = nullptr;  // 2 per launch
-    int* kind = nullptr;       // layout * 2 + (tile == 128)
+    int* kind = nullptr;       // layout * 2 + (128-row tile)
     double* flops = nullptr;
 };
 static GemmProf g_prof;
 
 int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
-    // tile choice: 128x128 only when it still yields >= ~1.5 waves of blocks over 256 CUs
-    const int64_t big = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
-    const int tile = (big >= 384 && a.M >= 128 && a.N >= 128) ? 128 : 64;
+    const int tile = pick_cfg(a, batch);
     const bool prof = g_prof.on && g_prof.n < g_prof.cap;
     if (prof) hipEventRecord(g_prof.ev[2 * g_prof.n], s);
     int rc;
@@ -292,7 +474,7 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     else rc = launch_gemm<L_TN>(a, batch, tile, s);
     if (prof) {
         hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
-        g_prof.kind[g_prof.n] = layout * 2 + (tile == 128);
+        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || tile >= 10);
         g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
         ++g_prof.n;
     }
@@ -300,6 +482,21 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
 }
 
 }  // namespace swat
+
+SWAT_API int swat_gemm_set_exp(int e) {
+    swat::g_exp = e;
+    return 0;
+}
+
+SWAT_API int swat_gemm_set_swizzle(int mode) {
+    swat::g_swz_mode = mode;
+    return 0;
+}
+
+SWAT_API int swat_gemm_set_tile(int cfg) {
+    swat::g_force_cfg = cfg;
+    return 0;
+}
 
 // Start timing every GEMM launch (up to max_launches) with hipEvents on its own stream; not graph-capturable.
 SWAT_API int swat_gemm_prof_begin(int max_launches) {
@@ -317,7 +514,7 @@ SWAT_API int swat_gemm_prof_begin(int max_launches) {
     return 0;
 }
 
-// Stop, synchronise the events and report per kind (layout*2 + is128; 6 kinds): total ms, launches, flops launched.
+// Stop, synchronise the events and report per kind (layout*2 + 128-row tile; 6 kinds): total ms, launches, flops.
 SWAT_API int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind) {
     using swat::g_prof;
     g_prof.on = false;

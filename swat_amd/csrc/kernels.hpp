@@ -24,6 +24,10 @@ struct GemmArgs {
     float alpha;
     int rpg, gstride, roff;        // output row remap: out_row = (m / rpg) * gstride + (m % rpg) + roff (rpg = 0: identity)
     const float* rowbias;          // [.., N] fp32 added as rowbias[(m % rpg) + roff, n]
+    // XCD-aware tile order (filled by the launcher): 0 = 2-D grid as is; 1 / 2 = 1-D grid, consecutive tiles of one
+    // XCD walk M first / N first, so the tiles an XCD's L2 serves share operand panels.
+    int swz, tiles_m, tiles_n;
+    int exp;  // tuning experiments (bit 0: no loads after the prologue, bit 1: no MFMA, bit 2: no epilogue); 0 in production
 };
 
 int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s);

@@ -10,19 +10,30 @@
 
 namespace swat {
 
-// C[m,n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]  (+ C if accumulate); sequential fma over k.
+// C[m,n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]  (+ C if accumulate).
+// Block = one output row m, 64 columns x 4 k-lanes: lane j runs an fma chain over k = j, j+4, ...; the four partial
+// sums are added in lane order -> deterministic.
 __global__ __launch_bounds__(256) void sgemm_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                           float* __restrict__ C, int M, int N, int K, int64_t sam, int64_t sak,
                                                           int64_t sbk, int64_t sbn, int64_t ldc, float alpha, int accumulate) {
+    __shared__ float sh[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (m >= M || n >= N) return;
-    const float* a = A + (int64_t)m * sam;
-    const float* b = B + (int64_t)n * sbn;
+    const int m = blockIdx.y;
+    const int j = threadIdx.x >> 6;
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc = fmaf(a[(int64_t)k * sak], b[(int64_t)k * sbk], acc);
-    float* c = C + (int64_t)m * ldc + n;
-    *c = accumulate ? *c + alpha * acc : alpha * acc;
+    if (n < N) {
+        const float* a = A + (int64_t)m * sam;
+        const float* b = B + (int64_t)n * sbn;
+        for (int k = j; k < K; k += 4) acc = fmaf(a[(int64_t)k * sak], b[(int64_t)k * sbk], acc);
+    }
+    sh[j][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (j == 0 && n < N) {
+        const int t = threadIdx.x;
+        const float v = alpha * (((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t]);
+        float* c = C + (int64_t)m * ldc + n;
+        *c = accumulate ? *c + v : v;
+    }
 }
 
 // y = x / ||x||_2 per row (no eps — ref utils/training.py:333); one wave per row; norm saved.
@@ -121,7 +132,7 @@ using namespace swat;
 SWAT_API int swat_sgemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak,
                               int64_t sbk, int64_t sbn, int64_t ldc, float alpha, int accumulate, swat_stream_t s) {
     if (M <= 0 || N <= 0) return 0;
-    hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 63) / 64, (M + 3) / 4), dim3(256), 0, (hipStream_t)s, A, B, C, M, N, K,
+    hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 63) / 64, M), dim3(256), 0, (hipStream_t)s, A, B, C, M, N, K,
                        sam, sak, sbk, sbn, ldc, alpha, accumulate);
     return check_launch("swat_sgemm_small");
 }

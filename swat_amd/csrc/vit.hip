@@ -73,6 +73,7 @@ struct VitWs {
     unsigned short* dqkv;     // [M,3d]
     float* du;                // [B,d]
     void* lnws;
+    void* csws;               // column-sum partials
     int64_t total;
 };
 
@@ -115,6 +116,7 @@ static VitWs carve(const VitDims& D, void* base) {
         w.dqkv = (unsigned short*)take(M * 3 * d * 2);
         w.du = (float*)take((int64_t)D.B * d * 4);
         w.lnws = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
+        w.csws = take(swat_colsum_bf16_workspace_bytes(D.mlp > 3 * D.d ? D.mlp : 3 * D.d));
     }
     w.total = off;
     return w;
@@ -302,7 +304,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             const unsigned short* ga = w.gact + (int64_t)l * M * mlp;
             // c_proj: dW = dx^T g, db = colsum(dx), dF = (dx W) * act'(F)
             TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, M, d, mlp, mlp, 1), 1, s));
-            TRY(swat_colsum(w.dxb, SWAT_BF16, M, d, d, grads + lo[PRB], 0, 0, 0, s));
+            TRY(swat_colsum_bf16(w.dxb, M, d, d, grads + lo[PRB], w.csws, s));
             {
                 GemmArgs a = G(w.dxb, sh + lo[PRW], w.dfb, M, mlp, d, d, mlp, mlp, 0);
                 a.actin = f; a.ldact = mlp; a.act = D.act;
@@ -310,20 +312,20 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             }
             // c_fc: dW = dF^T h2, db = colsum(dF), dh2 = dF W
             TRY(gemm_dispatch(L_TN, G(w.dfb, h2, grads + lo[FCW], mlp, d, M, mlp, d, d, 1), 1, s));
-            TRY(swat_colsum(w.dfb, SWAT_BF16, M, mlp, mlp, grads + lo[FCB], 0, 0, 0, s));
+            TRY(swat_colsum_bf16(w.dfb, M, mlp, mlp, grads + lo[FCB], w.csws, s));
             TRY(gemm_dispatch(L_NN, G(w.dfb, sh + lo[FCW], w.dh, M, d, mlp, mlp, d, d, 1), 1, s));
             // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
             TRY(swat_layernorm_bwd(w.dh, d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
                                    w.dx, d, w.dxb, d, grads + lo[LN2W], grads + lo[LN2B], w.lnws, M, d, s));
             // out_proj: dW = dx1^T a, db = colsum(dx1), da = dx1 W
             TRY(gemm_dispatch(L_TN, G(w.dxb, at, grads + lo[OUTW], d, d, M, d, d, d, 1), 1, s));
-            TRY(swat_colsum(w.dxb, SWAT_BF16, M, d, d, grads + lo[OUTB], 0, 0, 0, s));
+            TRY(swat_colsum_bf16(w.dxb, M, d, d, grads + lo[OUTB], w.csws, s));
             TRY(gemm_dispatch(L_NN, G(w.dxb, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
             // attention backward -> dqkv
             TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s));
             // in_proj: dW = dqkv^T h1, db = colsum(dqkv), dh1 = dqkv W
             TRY(gemm_dispatch(L_TN, G(w.dqkv, h1, grads + lo[QKVW], 3 * d, d, M, 3 * d, d, d, 1), 1, s));
-            TRY(swat_colsum(w.dqkv, SWAT_BF16, M, 3 * d, 3 * d, grads + lo[QKVB], 0, 0, 0, s));
+            TRY(swat_colsum_bf16(w.dqkv, M, 3 * d, 3 * d, grads + lo[QKVB], w.csws, s));
             TRY(gemm_dispatch(L_NN, G(w.dqkv, sh + lo[QKVW], w.dh, M, d, 3 * d, 3 * d, d, d, 1), 1, s));
             // ln_1 backward: dx0 = dx1 + LN'(dh1)
             TRY(swat_layernorm_bwd(w.dh, d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,

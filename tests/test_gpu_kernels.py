@@ -248,3 +248,27 @@ def test_adamw_matches_torch():
         ref = torch.cat([t.detach() for t in tp])
         assert (p - ref).abs().max().item() < 3e-6
     assert torch.equal(shadow, p.to(BF))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_every_tile_configuration(cfg, layout):
+    """All register-staged and LDS-DMA pipelined tile configurations give the same product (ragged M/N edges)."""
+    from swat_amd import ops, _lib
+    M, N, K = 1600, 840, 768  # 1600 = 12.5 x 128 rows, 840 = 6.56 x 128 cols: edge tiles on both sides
+    a, b = rnd(M, K, seed=31, dtype=BF), rnd(N, K, seed=32, scale=0.05, dtype=BF)
+    ref = a.float() @ b.float().t()
+    _lib.lib().swat_gemm_set_tile(cfg)
+    try:
+        C = torch.empty(M, N, device=dev(), dtype=F32)
+        if layout == "nt":
+            ops.gemm(ops.NT, a, b, M, N, K, K, K, C, N)
+        elif layout == "nn":
+            bt = b.t().contiguous()  # [K, N]
+            ops.gemm(ops.NN, a, bt, M, N, K, K, N, C, N)
+        else:
+            at, bt = a.t().contiguous(), b.t().contiguous()  # [K, M], [K, N]
+            ops.gemm(ops.TN, at, bt, M, N, K, M, N, C, N)
+    finally:
+        _lib.lib().swat_gemm_set_tile(-1)
+    close(C, ref, False, K)

@@ -154,6 +154,218 @@ def golden_retrieval():
 SECTIONS = {"retrieval": golden_retrieval}
 
 
+# --------------------------------------------------------------------------------------------
+# Path A — host logic the reference owns (LR trace, rand_bbox, CutMix transcript, mixup_criterion,
+# calculate_scores / validate) and the loops themselves
+# --------------------------------------------------------------------------------------------
+def _ref_args(**kw):
+    a = types.SimpleNamespace(method="cutmix", device="cpu", freeze_visual=False, lr_classifier=1e-4, lr_backbone=1e-6,
+                              temperature=0.07, optim="AdamW", wd=1e-2, epochs=2, early_stop=False, cutmix_beta=1.0,
+                              mix_prob=0.5, loss_name="CE", pre_extracted=False, dataset="synthetic", output_dir="/tmp",
+                              save_ckpt=False, save_freq=100, stop_epochs=-1, bsz=8)
+    a.__dict__.update(kw)
+    return a
+
+
+def golden_host():
+    from oracle import ref_shims
+    ref_shims.install()
+    import utils.training as rt
+    import utils.optimizers as ro
+    import testing as rtest
+    out = {}
+
+    # G1: LR trace of set_optimizer (utils/optimizers.py:22-35) for 3 groups, two T_max values
+    traces = {}
+    for total_iter_loader, epochs, lrb in [(100, 2, 1e-6), (1388, 50, 1e-6), (20, 3, 1e-4)]:
+        ps = [torch.nn.Parameter(torch.zeros(2)) for _ in range(3)]
+        params = [{"params": [ps[0]], "lr": 1e-4}, {"params": [ps[1]], "lr": lrb}, {"params": [ps[2]], "lr": 1e-4}]
+        args = _ref_args(epochs=epochs, lr_backbone=lrb)
+        opt, sched, total = ro.set_optimizer(args, params, [None] * total_iter_loader)
+        tr = []
+        for it in range(300):
+            tr.append([g["lr"] for g in opt.param_groups])
+            opt.step()
+            sched.step()
+        traces[f"{total_iter_loader}x{epochs}_{lrb}"] = {"total_iter": total, "lrs": tr}
+    out["lr_trace"] = traces
+
+    # G2: rand_bbox (utils/training.py:1404-1420)
+    boxes = []
+    rs = np.random.RandomState(0)
+    for i in range(300):
+        lam = float(rs.beta(1.0, 1.0))
+        np.random.seed(1000 + i)
+        b = rt.rand_bbox((32, 3, 224, 224), lam)
+        boxes.append([lam] + [int(v) for v in b])
+    out["rand_bbox"] = boxes
+
+    # G4: mixup_criterion over nn.CrossEntropyLoss (utils/training.py:1157-1158, utils/losses.py:10-11)
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(32, 200, generator=g) * 3
+    ya = torch.randint(0, 200, (32,), generator=g)
+    yb = torch.randint(0, 200, (32,), generator=g)
+    ce = torch.nn.CrossEntropyLoss()
+    out["mixup_criterion"] = {"seed": 5, "vals": [[lam, float(rt.mixup_criterion(ce, logits, ya, yb, lam))]
+                                                  for lam in (1.0, 0.0, 0.3, 0.7312)]}
+
+    # G6: calculate_scores + validate on pre-extracted features (testing.py:134-186, 403-486)
+    g = torch.Generator().manual_seed(6)
+    C, E = 7, 16
+    W = torch.randn(C, E, generator=g)
+    head = rt.build_classifier_head.__globals__["MyLinear"](weights=W)
+    feats = [torch.nn.functional.normalize(torch.randn(9, E, generator=g), dim=-1) for _ in range(4)]
+    labels = [torch.randint(0, C, (9,), generator=g) for _ in range(4)]
+    data = [(f, l, None, None) for f, l in zip(feats, labels)]
+
+    class _M(torch.nn.Module):
+        pass
+
+    acc, loss, cm = rtest.validate(_ref_args(), data, _M(), _logger(), torch.nn.CrossEntropyLoss(), torch.tensor([4.60517]),
+                                   head, show_confusion_matrix=True, device="cpu", pre_extracted=True)
+    scores = rtest.calculate_scores(cm)
+    out["validate"] = {"seed": 6, "C": C, "E": E, "acc": acc, "loss": float(loss), "cm": cm.tolist(),
+                       "scores": {"acc": float(scores["acc"]), "avg_class_accuracy": float(scores["avg_class_accuracy"]),
+                                  "recall": [float(scores["per_class_recall"][i]) for i in range(C)],
+                                  "precision": [float(scores["per_class_precision"][i]) for i in range(C)],
+                                  "f1": [float(scores["per_class_f1score"][i]) for i in range(C)]}}
+    with open(os.path.join(GOLD, "host_logic.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote tests/golden/host_logic.json")
+
+
+TINY = (64, 16, 128, 2, 2, 64, "quick_gelu")
+
+
+def loop_inputs(seed, n_batches, B, C, img=64):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(B, 3, img, img, generator=g), torch.randint(0, C, (B,), generator=g), None,
+             torch.ones(B, dtype=torch.long)) for _ in range(n_batches)]
+
+
+def golden_loop():
+    """G3 + G5: the reference's own train_cutmix / train_ce (utils/training.py:1422-1556, 296-412) driven on CPU with the
+    fp32 oracle tower as `model`; records loss.csv, the CutMix transcript (lam', target_b, pasted box decoded from the
+    images the model received) and the final head / logit_scale."""
+    from oracle import ref_shims, vit_oracle as vo
+    ref_shims.install()
+    import utils.training as rt
+    import utils.optimizers as ro
+    import utils.models as rm
+    res = {}
+    for method in ("cutmix", "finetune"):
+        B, C, nb, epochs = 8, 10, 4, 2
+        torch.manual_seed(0)
+        model = vo.OracleCLIP(vision_cfg=TINY, text_width=64, text_heads=1, text_layers=1, ctx=8, vocab=64)
+        W = torch.randn(C, TINY[5])
+        W /= W.norm(dim=-1, keepdim=True)
+        head = rm.MyLinear(weights=W.clone())
+        args = _ref_args(method=method, epochs=epochs, bsz=B)
+        args.loss = torch.nn.CrossEntropyLoss()
+        params, logit_scale = ro.set_params(args, model, head, _logger())
+        train = loop_inputs(11, nb, B, C)
+        val = loop_inputs(12, 2, B, C)
+        test = loop_inputs(13, 2, B, C)
+        opt, sched, _ = ro.set_optimizer(args, params, train)
+        args.optimizer, args.scheduler = opt, sched
+        transcript = []
+        orig_mix = rt.mixup_criterion
+
+        def rec_mix(criterion, pred, y_a, y_b, lam):
+            transcript.append({"lam": float(lam), "y_b": y_b.tolist()})
+            return orig_mix(criterion, pred, y_a, y_b, lam)
+
+        rt.mixup_criterion = rec_mix
+        rt.set_training_seed(types.SimpleNamespace(training_seed=1))
+        csv = io.StringIO()
+        # the reference pastes IN PLACE into the tensors its loader yields; a real DataLoader yields fresh tensors every
+        # epoch, so hand it a loader that clones on every iteration
+        class Fresh:
+            def __len__(self):
+                return len(train)
+
+            def __iter__(self):
+                for x, y, t, s in train:
+                    yield x.clone(), y.clone(), t, s.clone()
+
+        train_c = Fresh()
+        fn = rt.train_cutmix if method == "cutmix" else rt.train_ce
+        extra = () if method == "cutmix" else (False,)
+        best_model, best_head, best_records, best_ls = fn(args, _logger(), csv, model, head, train_c, val, test, *extra)
+        rt.mixup_criterion = orig_mix
+        res[method] = {"loss_csv": csv.getvalue(), "transcript": transcript,
+                       "head": head.linear.weight.detach().numpy().astype(np.float32),
+                       "logit_scale": float(logit_scale.item()),
+                       "best_val_acc": float(best_records["best_val_acc"]), "best_epoch": int(best_records["best_epoch"]),
+                       "best_iter": int(best_records["best_iter"]),
+                       "cm": np.asarray(best_records["best_confusion_matrix"])}
+        print(f"[loop/{method}] loss.csv:\n{csv.getvalue()}")
+    np.savez_compressed(os.path.join(GOLD, "loop_tiny.npz"),
+                        cutmix_csv=res["cutmix"]["loss_csv"], finetune_csv=res["finetune"]["loss_csv"],
+                        cutmix_transcript=json.dumps(res["cutmix"]["transcript"]),
+                        cutmix_head=res["cutmix"]["head"], finetune_head=res["finetune"]["head"],
+                        cutmix_ls=res["cutmix"]["logit_scale"], finetune_ls=res["finetune"]["logit_scale"],
+                        cutmix_best=json.dumps([res["cutmix"][k] for k in ("best_val_acc", "best_epoch", "best_iter")]),
+                        finetune_best=json.dumps([res["finetune"][k] for k in ("best_val_acc", "best_epoch", "best_iter")]),
+                        cutmix_cm=res["cutmix"]["cm"], finetune_cm=res["finetune"]["cm"])
+    print("wrote tests/golden/loop_tiny.npz")
+
+
+def hf_to_oracle_state(hf):
+    """HF CLIPVisionModelWithProjection -> open_clip VisionTransformer key names (SURVEY App. A mapping)."""
+    sd = hf.state_dict()
+    out = {"conv1.weight": sd["vision_model.embeddings.patch_embedding.weight"],
+           "class_embedding": sd["vision_model.embeddings.class_embedding"],
+           "positional_embedding": sd["vision_model.embeddings.position_embedding.weight"],
+           "ln_pre.weight": sd["vision_model.pre_layrnorm.weight"], "ln_pre.bias": sd["vision_model.pre_layrnorm.bias"],
+           "ln_post.weight": sd["vision_model.post_layernorm.weight"], "ln_post.bias": sd["vision_model.post_layernorm.bias"],
+           "proj": sd["visual_projection.weight"].t().contiguous()}
+    L = hf.config.num_hidden_layers
+    for i in range(L):
+        h = f"vision_model.encoder.layers.{i}."
+        o = f"transformer.resblocks.{i}."
+        out[o + "ln_1.weight"], out[o + "ln_1.bias"] = sd[h + "layer_norm1.weight"], sd[h + "layer_norm1.bias"]
+        out[o + "ln_2.weight"], out[o + "ln_2.bias"] = sd[h + "layer_norm2.weight"], sd[h + "layer_norm2.bias"]
+        out[o + "attn.in_proj_weight"] = torch.cat([sd[h + f"self_attn.{n}_proj.weight"] for n in "qkv"])
+        out[o + "attn.in_proj_bias"] = torch.cat([sd[h + f"self_attn.{n}_proj.bias"] for n in "qkv"])
+        out[o + "attn.out_proj.weight"], out[o + "attn.out_proj.bias"] = sd[h + "self_attn.out_proj.weight"], sd[h + "self_attn.out_proj.bias"]
+        out[o + "mlp.c_fc.weight"], out[o + "mlp.c_fc.bias"] = sd[h + "mlp.fc1.weight"], sd[h + "mlp.fc1.bias"]
+        out[o + "mlp.c_proj.weight"], out[o + "mlp.c_proj.bias"] = sd[h + "mlp.fc2.weight"], sd[h + "mlp.fc2.bias"]
+    return out
+
+
+def golden_vit():
+    """G8: the oracle tower vs an INDEPENDENT implementation of the same architecture (HF transformers CLIP)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from oracle import vit_oracle as vo
+    recs = {}
+    for name, cfg, act in [("b32_quickgelu", (224, 32, 768, 12, 12, 512), "quick_gelu"), ("tiny_gelu", (56, 14, 128, 2, 2, 64), "gelu")]:
+        img, patch, width, layers, heads, embed = cfg
+        torch.manual_seed(0)
+        hf = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=width, intermediate_size=4 * width, num_hidden_layers=layers,
+                                                            num_attention_heads=heads, patch_size=patch, image_size=img,
+                                                            projection_dim=embed, hidden_act=act, layer_norm_eps=1e-5)).eval()
+        with torch.no_grad():
+            for n, p in hf.named_parameters():
+                if n.endswith("bias"):
+                    p.add_(0.02 * torch.randn_like(p))
+        ref = vo.OracleVisionTransformer(img, patch, width, layers, heads, embed, act)
+        ref.load_state_dict(hf_to_oracle_state(hf))
+        x = torch.randn(2, 3, img, img, generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            a = hf(pixel_values=x).image_embeds
+            b = ref(x)
+        err = (a - b).abs().max().item()
+        print(f"[vit/{name}] oracle vs HF max-abs {err:.3e}")
+        assert err < 2e-5
+        recs[name + "_embeds"] = a.numpy()
+    np.savez_compressed(os.path.join(GOLD, "vit_hf.npz"), **recs)
+    print("wrote tests/golden/vit_hf.npz")
+
+
+SECTIONS.update({"host": golden_host, "loop": golden_loop, "vit": golden_vit})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     todo = sys.argv[1:] or list(SECTIONS)

@@ -1,0 +1,45 @@
+"""Row-sharded retrieval across the GPUs of one node: every rank holds a contiguous slice of the
+class-grouped index and runs the local filtered top-k; one gather of [n_seg, k] (value, global row) lists and a
+k-way merge by (value desc, global row asc) finish the query.  No other exchange on the data path.
+
+ref: the single-GPU sampler loop retrieval/sample_retrieval.py:724-825 is the semantics being sharded.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows, world, rank):
+    """Contiguous row range [lo, hi) of `rank` (first n_rows % world ranks get one extra row)."""
+    q, r = divmod(n_rows, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def local_segments(offsets, lo, hi):
+    """Clip global CSR class offsets to the shard [lo, hi) and rebase them to shard-local rows."""
+    return (offsets.clamp(lo, hi) - lo).contiguous()
+
+
+def merge_topk(idx_list, val_list, k):
+    """idx/val per shard: [n_seg, k] (global rows, -1 padded / -inf).  Shards must be passed in rank order: rows of a
+    lower rank are lower global rows, so a STABLE descending sort of the concatenation reproduces
+    (value desc, global row asc) — the reference's stable sorted(reverse=True) order."""
+    idx = torch.cat(idx_list, dim=1)
+    val = torch.cat(val_list, dim=1)
+    val = torch.where(idx >= 0, val, torch.full_like(val, float("-inf")))
+    order = torch.sort(val, dim=1, descending=True, stable=True).indices[:, :k]
+    out_idx = torch.gather(idx, 1, order)
+    out_val = torch.gather(val, 1, order)
+    cnt = (out_idx >= 0).sum(dim=1)
+    return out_idx, out_val, cnt
+
+
+def gather_and_merge(idx, val, k, group=None):
+    """All ranks call; every rank returns the merged global lists (all_gather keeps it symmetric and tiny:
+    12 B x n_seg x k per rank)."""
+    world = dist.get_world_size(group)
+    idxs = [torch.empty_like(idx) for _ in range(world)]
+    vals = [torch.empty_like(val) for _ in range(world)]
+    dist.all_gather(idxs, idx.contiguous(), group=group)
+    dist.all_gather(vals, val.contiguous(), group=group)
+    return merge_topk(idxs, vals, k)

@@ -7,6 +7,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from .ddp import SliceReducer
 
 
 class FusedTrainStep:
@@ -52,7 +53,7 @@ class FusedTrainStep:
         if target_b is None:
             target_b = target_a
         ws, dfeats = self._head_ws(B, dev)
-        pending = []
+        red = SliceReducer()
         if self.train_visual:
             feats = self.visual.forward_raw(images, save=True, perm=perm, box=box)
         else:
@@ -66,7 +67,7 @@ class FusedTrainStep:
         if self.world > 1:
             lo = min(self.off_head, self.off_ls)
             hi = max(self.off_head + self.C * self.E, self.off_ls + 1)
-            pending.append(dist.all_reduce(g[lo:hi], async_op=True))
+            red.reduce(g, lo, hi)
         if self.train_visual:
             L = self.visual.layers
             if self.world > 1:
@@ -74,11 +75,10 @@ class FusedTrainStep:
                 for s in range(L + 1, -1, -1):
                     self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
                     lo, hi = self._stage_slices[s]
-                    pending.append(dist.all_reduce(g[lo:hi], async_op=True))
+                    red.reduce(g, lo, hi)
             else:
                 self.visual.backward_raw(dfeats)
-        for w in pending:
-            w.wait()
+        red.wait()
         self.opt.step()
         return self.loss
 

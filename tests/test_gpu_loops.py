@@ -1,0 +1,98 @@
+"""GPU: the product's train_cutmix / train_ce / validate (HIP tower, fused step) against what the REFERENCE's own loops
+produced on the same seeded inputs with the fp32 oracle tower (tests/golden/loop_tiny.npz, host_logic.json)."""
+import io
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as vo
+from oracle.make_golden import TINY, loop_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+class _Lg:
+    handlers = []
+
+    def info(self, *a):
+        pass
+
+
+def _args(**kw):
+    a = types.SimpleNamespace(method="cutmix", device="cuda", freeze_visual=False, lr_classifier=1e-4, lr_backbone=1e-6,
+                              temperature=0.07, optim="AdamW", wd=1e-2, epochs=2, early_stop=False, cutmix_beta=1.0,
+                              mix_prob=0.5, loss_name="CE", pre_extracted=False, dataset="synthetic", output_dir="/tmp",
+                              save_ckpt=False, save_freq=100, stop_epochs=-1, bsz=8, training_seed=1)
+    a.__dict__.update(kw)
+    return a
+
+
+@pytest.mark.parametrize("method", ["cutmix", "finetune"])
+def test_training_loop_reproduces_reference_loss_csv(golden_dir, method):
+    from swat_amd import optimizers, training
+    from swat_amd.clip_model import CLIP
+    from swat_amd.models import MyLinear
+    g = np.load(os.path.join(golden_dir, "loop_tiny.npz"), allow_pickle=False)
+    B, C, nb, epochs = 8, 10, 4, 2
+    torch.manual_seed(0)  # same construction order as oracle/make_golden.py golden_loop
+    ref = vo.OracleCLIP(vision_cfg=TINY, text_width=64, text_heads=1, text_layers=1, ctx=8, vocab=64)
+    W = torch.randn(C, TINY[5])
+    W /= W.norm(dim=-1, keepdim=True)
+    model = CLIP(vision_cfg=TINY, text_cfg=(8, 64, 64, 1, 1))
+    model.load_state_dict(ref.state_dict())
+    model.to("cuda")
+    head = MyLinear(weights=W.clone()).to("cuda")
+    args = _args(method=method, epochs=epochs)
+    args.loss = torch.nn.CrossEntropyLoss()
+    params, logit_scale = optimizers.set_params(args, model, head, _Lg())
+    train, val, test = loop_inputs(11, nb, B, C), loop_inputs(12, 2, B, C), loop_inputs(13, 2, B, C)
+    opt, sched, _ = optimizers.set_optimizer(args, params, train)
+    args.optimizer, args.scheduler = opt, sched
+    training.set_training_seed(args)
+    csv = io.StringIO()
+    if method == "cutmix":
+        out = training.train_cutmix(args, _Lg(), csv, model, head, train, val, test)
+    else:
+        out = training.train_ce(args, _Lg(), csv, model, head, train, val, test, False)
+    best_model, best_head, best_records, best_ls = out
+    got = [[float(v) for v in line.split(",")] for line in csv.getvalue().strip().split("\n")]
+    want = [[float(v) for v in line.split(",")] for line in str(g[f"{method}_csv"]).strip().split("\n")]
+    assert len(got) == len(want) == epochs
+    for a, b in zip(got, want):
+        assert a[0] == b[0] and a[1] == b[1]                # epoch, iter
+        assert abs(a[2] - b[2]) < 2e-2                      # train loss (stated bf16 tolerance)
+        assert abs(a[3] - b[3]) < 5e-2                      # val loss (-1 before the last epoch)
+        assert abs(a[4] - b[4]) <= 6.25 + 1e-9 and abs(a[5] - b[5]) <= 6.25 + 1e-9  # acc: at most one of 16 samples flips
+    want_best = json.loads(str(g[f"{method}_best"]))
+    assert best_records["best_epoch"] == want_best[1] and best_records["best_iter"] == want_best[2]
+    assert best_records["best_confusion_matrix"].sum() == np.asarray(g[f"{method}_cm"]).sum()
+    # trained head / logit_scale end up where the reference's did (AdamW, 3 LR groups, warm-up LR trace)
+    ref_head = torch.from_numpy(g[f"{method}_head"])
+    assert ((head.linear.weight.cpu() - ref_head).norm() / ref_head.norm()).item() < 1e-3
+    assert abs(logit_scale.item() - float(g[f"{method}_ls"])) < 1e-3
+    # the returned best model is a usable deep copy on its own arena
+    with torch.no_grad():
+        f = best_model.visual.forward_raw(train[0][0].to("cuda"))
+    assert torch.isfinite(f).all()
+
+
+def test_validate_on_pre_extracted_features_matches_reference(golden_dir):
+    from swat_amd.models import MyLinear
+    from swat_amd.testing import validate
+    rec = json.load(open(os.path.join(golden_dir, "host_logic.json")))["validate"]
+    g = torch.Generator().manual_seed(rec["seed"])
+    C, E = rec["C"], rec["E"]
+    W = torch.randn(C, E, generator=g)
+    head = MyLinear(weights=W).to("cuda")
+    feats = [torch.nn.functional.normalize(torch.randn(9, E, generator=g), dim=-1) for _ in range(4)]
+    labels = [torch.randint(0, C, (9,), generator=g) for _ in range(4)]
+    data = [(f, l, None, None) for f, l in zip(feats, labels)]
+    acc, loss, cm = validate(_args(), data, torch.nn.Module(), _Lg(), None, torch.tensor([4.60517], device="cuda"), head,
+                             show_confusion_matrix=True, device="cuda", pre_extracted=True)
+    assert acc == rec["acc"]                       # fp32 head on exact inputs: identical predictions
+    assert np.array_equal(cm, np.array(rec["cm"]))
+    assert abs(loss - rec["loss"]) < 1e-4

@@ -1,0 +1,114 @@
+"""CPU: the product's host-side logic against golden vectors recorded from the imported reference
+(tests/golden/host_logic.json, loop_tiny.npz — oracle/make_golden.py `host` / `loop`)."""
+import json
+import os
+import types
+
+import numpy as np
+import torch
+
+
+def _gold(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "host_logic.json")))
+
+
+class _Opt:
+    def __init__(self, lrs):
+        self.param_groups = [{"lr": lr, "initial_lr": lr} for lr in lrs]
+
+
+def test_lr_schedule_matches_reference_trace(golden_dir):
+    """LinearWarmupScheduler over CosineAnnealingLR (ref utils/optimizers.py:22-35,158-206), 3 LR groups, 300 its."""
+    from swat_amd.optimizers import LinearWarmupScheduler
+    for key, rec in _gold(golden_dir)["lr_trace"].items():
+        lrb = float(key.split("_")[1])
+        opt = _Opt([1e-4, lrb, 1e-4])
+        sched = LinearWarmupScheduler(opt, rec["total_iter"], warmup_iter=50, warmup_lr=1e-5 if lrb > 5e-5 else 1e-6)
+        for it, want in enumerate(rec["lrs"]):
+            got = [g["lr"] for g in opt.param_groups]
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-18), (key, it, got, want)
+            sched.step()
+
+
+def test_rand_bbox_matches_reference(golden_dir):
+    from swat_amd.training import rand_bbox
+    for i, (lam, x1, y1, x2, y2) in enumerate(_gold(golden_dir)["rand_bbox"]):
+        np.random.seed(1000 + i)
+        assert [int(v) for v in rand_bbox((32, 3, 224, 224), lam)] == [x1, y1, x2, y2]
+
+
+def test_mixup_criterion_matches_reference(golden_dir):
+    from swat_amd.training import mixup_criterion
+    rec = _gold(golden_dir)["mixup_criterion"]
+    g = torch.Generator().manual_seed(rec["seed"])
+    logits = torch.randn(32, 200, generator=g) * 3
+    ya = torch.randint(0, 200, (32,), generator=g)
+    yb = torch.randint(0, 200, (32,), generator=g)
+    ce = torch.nn.CrossEntropyLoss()
+    for lam, want in rec["vals"]:
+        assert abs(float(mixup_criterion(ce, logits, ya, yb, lam)) - want) < 1e-6
+
+
+def test_calculate_scores_matches_reference(golden_dir):
+    from swat_amd.testing import calculate_scores
+    rec = _gold(golden_dir)["validate"]
+    s = calculate_scores(np.array(rec["cm"]))
+    assert abs(s["acc"] - rec["scores"]["acc"]) < 1e-12
+    assert np.isclose(s["avg_class_accuracy"], rec["scores"]["avg_class_accuracy"], equal_nan=True)
+    C = rec["C"]
+    assert np.allclose([s["per_class_recall"][i] for i in range(C)], rec["scores"]["recall"])
+    assert np.allclose([s["per_class_precision"][i] for i in range(C)], rec["scores"]["precision"])
+    assert np.allclose([s["per_class_f1score"][i] for i in range(C)], rec["scores"]["f1"])
+
+
+def test_cutmix_host_rng_transcript_matches_reference_loop(golden_dir):
+    """Same seeds -> the product's cutmix_draw consumes the global NumPy / torch generators in the reference's order
+     and reproduces every (lam', target_b) the reference's train_cutmix fed to mixup_criterion."""
+    from oracle.make_golden import loop_inputs
+    from swat_amd.training import cutmix_draw, set_training_seed
+    g = np.load(os.path.join(golden_dir, "loop_tiny.npz"), allow_pickle=False)
+    transcript = json.loads(str(g["cutmix_transcript"]))
+    train = loop_inputs(11, 4, 8, 10)
+    args = types.SimpleNamespace(cutmix_beta=1.0, mix_prob=0.5, training_seed=1)
+    set_training_seed(args)
+    it = 0
+    for epoch in range(2):
+        for x, y, _, _ in train:
+            lam, perm, box = cutmix_draw(args, x.size())
+            yb = y[perm] if perm is not None else y
+            assert abs(lam - transcript[it]["lam"]) < 1e-15, it
+            assert yb.tolist() == transcript[it]["y_b"], it
+            if box is not None:
+                assert abs(lam - (1 - (box[2] - box[0]) * (box[3] - box[1]) / (64 * 64))) < 1e-15
+            it += 1
+    assert it == len(transcript)
+
+
+def test_model_cfg_mapping():
+    from swat_amd.engine import parse_model_cfg
+    assert parse_model_cfg("vitb32_openclip_laion400m") == ("ViT-B-32-quickgelu", "laion400m_e32")
+    assert parse_model_cfg("vitb16_openclip_laion400m") == ("ViT-B-16", "laion400m_e32")
+    assert parse_model_cfg("vitb32_openclip_laion2b") == ("ViT-B-32", "laion2b_s34b_b79k")
+    assert parse_model_cfg("vitl14_openclip_laion400m") == ("ViT-L-14", "laion400m_e32")
+
+
+def test_state_dict_uses_open_clip_key_names():
+    from oracle import vit_oracle as vo
+    from swat_amd.clip_model import CLIP
+    cfg = (64, 16, 128, 2, 2, 64, "quick_gelu")
+    mine = CLIP(vision_cfg=cfg, text_cfg=(8, 64, 64, 1, 1))
+    ref = vo.OracleCLIP(vision_cfg=cfg, text_width=64, text_heads=1, text_layers=1, ctx=8, vocab=64)
+    a = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert a == b
+    assert "visual.transformer.resblocks.1.attn.in_proj_weight" in a and "visual.proj" in a and "logit_scale" in a
+    mine.load_state_dict(ref.state_dict())
+
+
+def test_tower_refuses_cpu():
+    import pytest
+    from swat_amd import _lib
+    from swat_amd.clip_model import CLIP
+    m = CLIP(vision_cfg=(64, 16, 128, 2, 2, 64, "quick_gelu"), text_cfg=(8, 64, 64, 1, 1))
+    with pytest.raises(_lib.SwatHipError):
+        m.encode_image(torch.zeros(1, 3, 64, 64))

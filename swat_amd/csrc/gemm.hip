@@ -275,6 +275,134 @@ __global__ __launch_bounds__(256) void gemm_stage_kernel(const GemmArgs p) {
 }
 
 // --------------------------------------------------------------------------------------------
+// register-ring kernel (any K): like gemm_stage_kernel, but D stages of global loads are kept in flight in a
+// register ring (16 VGPRs per stage for a 64x64 tile), so memory latency is covered by prefetch DEPTH while the
+// per-step issue cost stays at global_load_dwordx4 + ds_write_b128 (~25 cycles per KiB vs ~100 measured for an
+// LDS-DMA piece issued by the computing wave itself: rocprofv3 SQ_ACTIVE_INST_ANY / SQ_WAIT_ANY, profiles/).
+// Plain loads stay in flight across __syncthreads() (it only drains LDS ops when no LDS-DMA is pending).
+// --------------------------------------------------------------------------------------------
+template <int LAYOUT, int BM, int BN, int D>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmArgs p) {
+    constexpr bool A_KC = (LAYOUT != L_TN);
+    constexpr bool B_KC = (LAYOUT == L_NT);
+    constexpr int BK = 64;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int A_CH = A_BYTES / 16 / 256, B_CH = B_BYTES / 16 / 256;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM;
+    const int wn0 = (wave & 1) * WN;
+    int bx, by;
+    tile_coords(p, bx, by);
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int zo = z / p.inner, zi = z % p.inner;
+    const unsigned short* __restrict__ A = p.A + zo * p.sA0 + zi * p.sA1;
+    const unsigned short* __restrict__ B = p.B + zo * p.sB0 + zi * p.sB1;
+    const int M = p.M, N = p.N, K = p.K;
+
+    // per-thread chunk geometry is loop-invariant: precompute source pointers / LDS offsets once
+    const unsigned short* srcA[A_CH];
+    const unsigned short* srcB[B_CH];
+    int ldsA[A_CH], ldsB[B_CH], kA[A_CH], kB[B_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int c = tid + 256 * i;
+        if constexpr (A_KC) {
+            const int row = c >> 3, t = c & 7;
+            int gr = m0 + row; gr = gr < M ? gr : M - 1;
+            srcA[i] = A + (int64_t)gr * p.lda + 8 * t; kA[i] = 8 * t; ldsA[i] = kc_off(row, t);
+        } else {
+            const int krow = c / (BM / 8), c16 = c % (BM / 8);
+            int gr = m0 + 8 * c16; gr = gr + 8 <= p.lda ? gr : 0;
+            srcA[i] = A + (int64_t)krow * p.lda + gr; kA[i] = krow; ldsA[i] = st_off<BM>(krow, c16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int c = tid + 256 * i;
+        if constexpr (B_KC) {
+            const int row = c >> 3, t = c & 7;
+            int gr = n0 + row; gr = gr < N ? gr : N - 1;
+            srcB[i] = B + (int64_t)gr * p.ldb + 8 * t; kB[i] = 8 * t; ldsB[i] = kc_off(row, t);
+        } else {
+            const int krow = c / (BN / 8), c16 = c % (BN / 8);
+            int gr = n0 + 8 * c16; gr = gr + 8 <= p.ldb ? gr : 0;
+            srcB[i] = B + (int64_t)krow * p.ldb + gr; kB[i] = krow; ldsB[i] = st_off<BN>(krow, c16);
+        }
+    }
+    const int64_t stepA = A_KC ? 64 : (int64_t)64 * p.lda;
+    const int64_t stepB = B_KC ? 64 : (int64_t)64 * p.ldb;
+
+    auto load_chunk = [&](const unsigned short* src, bool kcontig, int kk, int k0) -> s16x8_t {
+        s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int gk = k0 + kk;
+        if (gk < K) {
+            v = *reinterpret_cast<const s16x8_t*>(src);
+            if (kcontig && gk + 8 > K) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (gk + e >= K) v[e] = 0;
+            }
+        }
+        return v;
+    };
+    s16x8_t ring[D][A_CH + B_CH];
+    auto load_stage = [&](s16x8_t (&r)[A_CH + B_CH], int step) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) r[i] = load_chunk(srcA[i] + step * stepA, A_KC, kA[i], step * BK);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) r[A_CH + i] = load_chunk(srcB[i] + step * stepB, B_KC, kB[i], step * BK);
+    };
+    auto store_stage = [&](const s16x8_t (&r)[A_CH + B_CH], int buf) {
+        unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<s16x8_t*>(sa + ldsA[i]) = r[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<s16x8_t*>(sb + ldsB[i]) = r[A_CH + i];
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + BK - 1) / BK;
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nk) load_stage(ring[s], s);
+    store_stage(ring[0], 0);
+    if (D < nk) load_stage(ring[0], D);
+    __syncthreads();
+    for (int t0 = 0; t0 < nk; t0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int t = t0 + u;
+            if (t < nk) {
+                constexpr int dummy = 0; (void)dummy;
+                const int nu = (u + 1) % D;  // static after unrolling: ring slot of step t+1
+                if (t + 1 < nk) {
+                    store_stage(ring[nu], (t + 1) & 1);  // the other buffer: its readers passed the last barrier
+                    if (t + 1 + D < nk) load_stage(ring[nu], t + 1 + D);
+                }
+                const unsigned char* sa = smem + (t & 1) * (A_BYTES + B_BYTES);
+                mma_stage<FM, FN, A_KC, B_KC, BM, BN>(sa, sa + A_BYTES, wm0, wn0, lane, acc);
+                __syncthreads();
+            }
+        }
+    }
+    gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+}
+
+// --------------------------------------------------------------------------------------------
 // LDS-DMA pipelined kernel (K % 64 == 0)
 // --------------------------------------------------------------------------------------------
 template <int N_>
@@ -381,6 +509,351 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmArg
     else if (acc[0][0][0] == 12345.f) ((float*)p.C)[0] = 1.f;
 }
 
+// --------------------------------------------------------------------------------------------
+// LDS-DMA kernel, lean main loop (K % 64 == 0).  Same pipeline as gemm_glds_kernel, but everything that does not
+// change from step to step is hoisted: the per-lane source offsets are 32-bit and added to a wave-uniform base
+// pointer that advances in SGPRs (saddr + voffset addressing), the main loop is unrolled by NSTAGE so every LDS
+// stage address is an immediate, and the fragment read addresses are precomputed per lane.  rocprofv3 showed the
+// first version issuing ~95 VALU + 60 SALU per 8 MFMAs (SQ_ACTIVE_INST_ANY 38 %, MFMA busy 17 %): the loop was
+// bound by its own address arithmetic, not by memory, LDS or the matrix pipe.
+// --------------------------------------------------------------------------------------------
+template <int LAYOUT, int BM, int BN, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
+    constexpr bool A_KC = (LAYOUT != L_TN);
+    constexpr bool B_KC = (LAYOUT == L_NT);
+    constexpr int BK = 64;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INS = A_BYTES / 1024 / 4, B_INS = B_BYTES / 1024 / 4;
+    constexpr int LPS = A_INS + B_INS;
+    constexpr int NA = A_KC ? 1 : 2, NB = B_KC ? 1 : 2;  // LDS reads per fragment
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * WM;
+    const int wn0 = (wave & 1) * WN;
+    int bx, by;
+    tile_coords(p, bx, by);
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int zo = z / p.inner, zi = z % p.inner;
+    const int M = p.M, N = p.N, K = p.K;
+
+    // ---- loop-invariant per-lane SOURCE byte offsets (32-bit) relative to wave-uniform bases ----
+    auto src_off = [&](bool kcontig, int ins, int row0, int R, int ld, int tile_rows) -> unsigned {
+        const int byte = ins * 1024 + lane * 16;
+        if (kcontig) {
+            const int row = byte >> 7, ps = (byte >> 4) & 7;
+            const int t = ps ^ ((row >> 1) & 7);
+            int gr = row0 + row; gr = gr < R ? gr : R - 1;
+            return (unsigned)((gr - row0) * ld + 8 * t) * 2u;   // relative to the tile's first row
+        } else {
+            const int rs = tile_rows * 2;
+            const int k = byte / rs, pc16 = (byte % rs) >> 4;
+            const int f = tile_rows == 128 ? st_f<128>(k) : st_f<64>(k);
+            const int c16 = (((pc16 >> 1) ^ f) << 1) | (pc16 & 1);
+            int gc = row0 + 8 * c16; gc = gc + 8 <= ld ? gc : 0;
+            return (unsigned)(k * ld + gc) * 2u;                 // relative to row k0 of the matrix
+        }
+    };
+    unsigned offA[A_INS], offB[B_INS];
+#pragma unroll
+    for (int i = 0; i < A_INS; ++i) offA[i] = src_off(A_KC, wave + 4 * i, m0, M, p.lda, BM);
+#pragma unroll
+    for (int i = 0; i < B_INS; ++i) offB[i] = src_off(B_KC, wave + 4 * i, n0, N, p.ldb, BN);
+    // wave-uniform base pointers of step 0 (k-contiguous: first row of the tile; strided: row 0, column 0)
+    const char* gA = reinterpret_cast<const char*>(p.A + zo * p.sA0 + zi * p.sA1 + (A_KC ? (int64_t)m0 * p.lda : 0));
+    const char* gB = reinterpret_cast<const char*>(p.B + zo * p.sB0 + zi * p.sB1 + (B_KC ? (int64_t)n0 * p.ldb : 0));
+    const int64_t stepA = A_KC ? 128 : (int64_t)128 * p.lda;  // bytes per 64-deep k-step
+    const int64_t stepB = B_KC ? 128 : (int64_t)128 * p.ldb;
+
+    // ---- loop-invariant per-lane fragment READ offsets inside a stage ----
+    const int r16 = lane & 15, g = lane >> 4;
+    unsigned ra[2][FM][NA], rb[2][FN][NB];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if constexpr (A_KC) ra[ks][i][0] = kc_off(wm0 + 16 * i + r16, 4 * ks + g);
+            else {
+                const int k = 32 * ks + 8 * g + (r16 >> 2), c32 = (wm0 + 16 * i) >> 4;
+                ra[ks][i][0] = k * (BM * 2) + ((c32 ^ st_f<BM>(k)) << 5) + 8 * (r16 & 3);
+                ra[ks][i][NA - 1] = (k + 4) * (BM * 2) + ((c32 ^ st_f<BM>(k + 4)) << 5) + 8 * (r16 & 3);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if constexpr (B_KC) rb[ks][j][0] = A_BYTES + kc_off(wn0 + 16 * j + r16, 4 * ks + g);
+            else {
+                const int k = 32 * ks + 8 * g + (r16 >> 2), c32 = (wn0 + 16 * j) >> 4;
+                rb[ks][j][0] = A_BYTES + k * (BN * 2) + ((c32 ^ st_f<BN>(k)) << 5) + 8 * (r16 & 3);
+                rb[ks][j][NB - 1] = A_BYTES + (k + 4) * (BN * 2) + ((c32 ^ st_f<BN>(k + 4)) << 5) + 8 * (r16 & 3);
+            }
+        }
+    }
+    auto frag = [&](const unsigned char* st, const unsigned* off, bool kcontig) -> bf16x8_t {
+        if (kcontig) return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(st + off[0]));
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(st + off[0]));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(st + off[1]));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, v);
+    };
+
+    auto issue = [&](int stage, const char* a, const char* b) {
+        unsigned char* sa = smem + stage * STAGE;
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_INS; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + offA[i]),
+                                             (__attribute__((address_space(3))) void*)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_INS; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + offB[i]),
+                                             (__attribute__((address_space(3))) void*)(sb + (wave + 4 * i) * 1024), 16, 0, 0);
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    // k-order skew: blocks that share an operand panel start at different k-steps (and wrap), so at any instant they
+    // pull different 128-B columns of the panel — with row strides of 1.5-6 KiB a common k-step lands every CU on
+    // the same few L2 channels.  The sum order per block changes (still deterministic run to run).
+    int kk = (p.exp & 8) ? 0 : (bx * 5 + by * 3) % nk;
+    gA += kk * stepA; gB += kk * stepB;
+    auto advance = [&]() {
+        gA += stepA; gB += stepB;
+        if (++kk == nk) { kk = 0; gA -= nk * stepA; gB -= nk * stepB; }
+    };
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+        if (s < nk) issue(s, gA, gB);
+        advance();
+    }
+    // gA / gB now point at the next stage to issue
+
+    for (int t0 = 0; t0 < nk; t0 += NSTAGE) {
+#pragma unroll
+        for (int u = 0; u < NSTAGE; ++u) {
+            const int t = t0 + u;
+            if (t < nk) {
+                const int younger = nk - 1 - t;  // issued stages younger than t: min(younger, NSTAGE-2)
+                if (younger >= NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * LPS>();  // steady state
+                else switch (younger) {                                        // drain at the tail
+                    case 6: wait_vmcnt<(NSTAGE > 8 ? 6 : 0) * LPS>(); break;
+                    case 5: wait_vmcnt<(NSTAGE > 7 ? 5 : 0) * LPS>(); break;
+                    case 4: wait_vmcnt<(NSTAGE > 6 ? 4 : 0) * LPS>(); break;
+                    case 3: wait_vmcnt<(NSTAGE > 5 ? 3 : 0) * LPS>(); break;
+                    case 2: wait_vmcnt<(NSTAGE > 4 ? 2 : 0) * LPS>(); break;
+                    case 1: wait_vmcnt<(NSTAGE > 3 ? 1 : 0) * LPS>(); break;
+                    default: wait_vmcnt<0>(); break;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (t + NSTAGE - 1 < nk) issue((u + NSTAGE - 1) % NSTAGE, gA, gB);
+                advance();
+                const unsigned char* st = smem + u * STAGE;  // immediate after unrolling
+                if (p.exp & 2) continue;  // tuning only: DMA streaming without LDS reads / MFMA
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8_t af[FM], bfr[FN];
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) af[i] = frag(st, ra[ks][i], A_KC);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) bfr[j] = frag(st, rb[ks][j], B_KC);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+}
+
+// --------------------------------------------------------------------------------------------
+// lean register-ring kernel (K % 64 == 0, K >= 64 * D): plain global_load_dwordx4 (cheap to issue: measured LDS-DMA
+// pieces cost the issuing wave ~100 cycles each, ~25 GB/s per wave) into a D-deep register ring, ds_write_b128 into
+// two LDS buffers; all addresses loop-invariant (32-bit lane offsets + SGPR base, immediates for the LDS side); the
+// steady-state loop is branch-free so hipcc keeps counted vmcnt waits.
+// --------------------------------------------------------------------------------------------
+template <int LAYOUT, int BM, int BN, int D>
+__global__ __launch_bounds__(256) void gemm_ring2_kernel(const GemmArgs p) {
+    static_assert(D % 2 == 0, "even ring depth keeps the LDS buffer index static");
+    constexpr bool A_KC = (LAYOUT != L_TN);
+    constexpr bool B_KC = (LAYOUT == L_NT);
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_CH = A_BYTES / 16 / 256, B_CH = B_BYTES / 16 / 256;
+    constexpr int NA = A_KC ? 1 : 2, NB = B_KC ? 1 : 2;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM;
+    const int wn0 = (wave & 1) * WN;
+    int bx, by;
+    tile_coords(p, bx, by);
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int zo = z / p.inner, zi = z % p.inner;
+    const int M = p.M, N = p.N, K = p.K;
+
+    unsigned offA[A_CH], offB[B_CH], ldsA[A_CH], ldsB[B_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int c = tid + 256 * i;
+        if constexpr (A_KC) {
+            const int row = c >> 3, t = c & 7;
+            int gr = m0 + row; gr = gr < M ? gr : M - 1;
+            offA[i] = (unsigned)((gr - m0) * p.lda + 8 * t) * 2u; ldsA[i] = kc_off(row, t);
+        } else {
+            const int krow = c / (BM / 8), c16 = c % (BM / 8);
+            int gc = m0 + 8 * c16; gc = gc + 8 <= p.lda ? gc : 0;
+            offA[i] = (unsigned)(krow * p.lda + gc) * 2u; ldsA[i] = st_off<BM>(krow, c16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int c = tid + 256 * i;
+        if constexpr (B_KC) {
+            const int row = c >> 3, t = c & 7;
+            int gr = n0 + row; gr = gr < N ? gr : N - 1;
+            offB[i] = (unsigned)((gr - n0) * p.ldb + 8 * t) * 2u; ldsB[i] = A_BYTES + kc_off(row, t);
+        } else {
+            const int krow = c / (BN / 8), c16 = c % (BN / 8);
+            int gc = n0 + 8 * c16; gc = gc + 8 <= p.ldb ? gc : 0;
+            offB[i] = (unsigned)(krow * p.ldb + gc) * 2u; ldsB[i] = A_BYTES + st_off<BN>(krow, c16);
+        }
+    }
+    const char* gA = reinterpret_cast<const char*>(p.A + zo * p.sA0 + zi * p.sA1 + (A_KC ? (int64_t)m0 * p.lda : 0));
+    const char* gB = reinterpret_cast<const char*>(p.B + zo * p.sB0 + zi * p.sB1 + (B_KC ? (int64_t)n0 * p.ldb : 0));
+    const int64_t stepA = A_KC ? 128 : (int64_t)128 * p.lda;
+    const int64_t stepB = B_KC ? 128 : (int64_t)128 * p.ldb;
+
+    const int r16 = lane & 15, g = lane >> 4;
+    unsigned ra[2][FM][NA], rb[2][FN][NB];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if constexpr (A_KC) ra[ks][i][0] = kc_off(wm0 + 16 * i + r16, 4 * ks + g);
+            else {
+                const int k = 32 * ks + 8 * g + (r16 >> 2), c32 = (wm0 + 16 * i) >> 4;
+                ra[ks][i][0] = k * (BM * 2) + ((c32 ^ st_f<BM>(k)) << 5) + 8 * (r16 & 3);
+                ra[ks][i][NA - 1] = (k + 4) * (BM * 2) + ((c32 ^ st_f<BM>(k + 4)) << 5) + 8 * (r16 & 3);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if constexpr (B_KC) rb[ks][j][0] = A_BYTES + kc_off(wn0 + 16 * j + r16, 4 * ks + g);
+            else {
+                const int k = 32 * ks + 8 * g + (r16 >> 2), c32 = (wn0 + 16 * j) >> 4;
+                rb[ks][j][0] = A_BYTES + k * (BN * 2) + ((c32 ^ st_f<BN>(k)) << 5) + 8 * (r16 & 3);
+                rb[ks][j][NB - 1] = A_BYTES + (k + 4) * (BN * 2) + ((c32 ^ st_f<BN>(k + 4)) << 5) + 8 * (r16 & 3);
+            }
+        }
+    }
+    auto frag = [&](const unsigned char* st, const unsigned* off, bool kcontig) -> bf16x8_t {
+        if (kcontig) return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(st + off[0]));
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(st + off[0]));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(st + off[1]));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, v);
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    s16x8_t ring[D][A_CH + B_CH];
+    auto load_slot = [&](s16x8_t (&r)[A_CH + B_CH]) {  // loads the step gA/gB point at, then advances them
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) r[i] = *reinterpret_cast<const s16x8_t*>(gA + offA[i]);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) r[A_CH + i] = *reinterpret_cast<const s16x8_t*>(gB + offB[i]);
+        gA += stepA; gB += stepB;
+    };
+    auto store_slot = [&](const s16x8_t (&r)[A_CH + B_CH], int buf) {
+        unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<s16x8_t*>(st + ldsA[i]) = r[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<s16x8_t*>(st + ldsB[i]) = r[A_CH + i];
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = frag(st, ra[ks][i], A_KC);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[j] = frag(st, rb[ks][j], B_KC);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = K >> 6;  // >= D (checked by the launcher)
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_slot(ring[s]);  // steps 0 .. D-1
+    store_slot(ring[0], 0);
+    int next = D;  // next step to load
+    if (next < nk) { load_slot(ring[0]); ++next; }
+    __syncthreads();
+
+    int t = 0;
+    // steady state: every step stores step t+1 and loads a new one; no branches
+    for (; t + D <= nk - D - 1 + 1 && next + D - 1 < nk; t += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            store_slot(ring[(u + 1) % D], (u + 1) & 1);
+            load_slot(ring[(u + 1) % D]);
+            compute(u & 1);
+            __syncthreads();
+        }
+        next += D;
+    }
+    // tail: same schedule with guards (t is a multiple of D here, so slots / buffers stay static per u)
+    for (; t < nk; t += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (t + u < nk) {
+                if (t + u + 1 < nk) {
+                    store_slot(ring[(u + 1) % D], (u + 1) & 1);
+                    if (next < nk) { load_slot(ring[(u + 1) % D]); ++next; }
+                }
+                compute(u & 1);
+                __syncthreads();
+            }
+        }
+    }
+    gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+}
+
 static int g_exp = 0;
 static int g_swz_mode = -1;  // -1 automatic, 0 off (swat_gemm_set_swizzle)
 
@@ -416,13 +889,32 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
         hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, BM_, BN_, NS_>), grid, dim3(256), 0, s, b);          \
     }
+#define SWAT_RING(BM_, BN_, D_)                                                                           \
+    {                                                                                                     \
+        GemmArgs b = a;                                                                                   \
+        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
+        hipLaunchKernelGGL((gemm_ring_kernel<LAYOUT, BM_, BN_, D_>), grid, dim3(256), 0, s, b);           \
+    }
+#define SWAT_DMA(BM_, BN_, NS_)                                                                           \
+    {                                                                                                     \
+        GemmArgs b = a;                                                                                   \
+        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
+        hipLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_>), grid, dim3(256), 0, s, b);           \
+    }
+#define SWAT_RING2(BM_, BN_, D_)                                                                          \
+    {                                                                                                     \
+        GemmArgs b = a;                                                                                   \
+        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
+        hipLaunchKernelGGL((gemm_ring2_kernel<LAYOUT, BM_, BN_, D_>), grid, dim3(256), 0, s, b);          \
+    }
 #define SWAT_GLDS8(BM_, BN_, NS_, WGM_, WGN_)                                                             \
     {                                                                                                     \
         GemmArgs b = a;                                                                                   \
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
         hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, b); \
     }
-    if (cfg >= 6 && a.K % 64 != 0) cfg = (cfg == 6 || cfg >= 10) ? 1 : (cfg == 8 ? 2 : 0);  // the LDS-DMA kernel has no K tail
+    if (cfg >= 30 && (a.K % 64 != 0 || a.K < 64 * 6)) cfg = 20;  // lean ring needs whole, >= D k-steps
+    if (cfg >= 6 && cfg < 20 && a.K % 64 != 0) cfg = (cfg == 6 || (cfg >= 10 && cfg != 14 && cfg != 17 && cfg != 18 && cfg != 19)) ? 1 : (cfg == 8 ? 2 : 0);  // the LDS-DMA kernel has no K tail
     switch (cfg) {
         case 1: SWAT_STAGE(128, 128) break;
         case 2: SWAT_STAGE(128, 64) break;
@@ -435,23 +927,46 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
         case 11: SWAT_GLDS8(128, 128, 3, 4, 2) break;
         case 12: SWAT_GLDS8(128, 64, 4, 4, 2) break;
         case 13: SWAT_GLDS8(256, 128, 2, 4, 2) break;
+        case 14: SWAT_DMA(64, 64, 3) break;
+        case 15: SWAT_DMA(128, 128, 3) break;
+        case 16: SWAT_DMA(128, 64, 3) break;
+        case 17: SWAT_DMA(64, 64, 4) break;
+        case 18: SWAT_DMA(64, 64, 6) break;
+        case 19: SWAT_DMA(64, 64, 8) break;
+        case 20: SWAT_RING(64, 64, 4) break;
+        case 30: SWAT_RING2(64, 64, 4) break;
+        case 31: SWAT_RING2(64, 64, 2) break;
+        case 32: SWAT_RING2(128, 64, 4) break;
+        case 33: SWAT_RING2(128, 128, 2) break;
+        case 34: SWAT_RING2(64, 64, 6) break;
+        case 21: SWAT_RING(128, 128, 3) break;
+        case 22: SWAT_RING(128, 64, 4) break;
+        case 23: SWAT_RING(64, 64, 6) break;
+        case 24: SWAT_RING(64, 64, 2) break;
         default: SWAT_STAGE(64, 64) break;
     }
 #undef SWAT_STAGE
 #undef SWAT_GLDS
 #undef SWAT_GLDS8
+#undef SWAT_RING
+#undef SWAT_RING2
+#undef SWAT_DMA
     return check_launch("swat_gemm_bf16");
 }
 
 static int g_force_cfg = -1;  // swat_gemm_set_tile(): experiments / tests pin one configuration
 
-static int pick_cfg(const GemmArgs& a, int batch) {
+static int pick_cfg(int layout, const GemmArgs& a, int batch) {
     if (g_force_cfg >= 0) return g_force_cfg;
-    auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * batch; };
-    // measured on MI355X (tools/perf_gemm.py, M = 1600): with ~1 block per CU the 64x64 x 3-stage LDS-DMA tile wins on
-    // every shape of the step; 8-wave 128x128 only pays once a launch has many more tiles than CUs.
-    if (a.M >= 1024 && a.N >= 1024 && blocks(128, 128) >= 1024) return 10;
-    return 9;
+    // Measured on MI355X (tools/perf_gemm.py; M = B*T = 1600, ~1-5 blocks per CU).  The launches are short (10-30 us):
+    // ramp, first-touch latency and the epilogue are comparable to the k-loop, so 64x64 tiles (more blocks in
+    // flight, shorter tails) beat 128x128 everywhere; LDS-DMA (14/16) wins the k-contiguous NT products, the lean
+    // register ring (30) wins the deep-K dgrad / small wgrad products; everything ragged goes to the staged ring (20).
+    const bool whole = a.K % 64 == 0;
+    if (!whole || batch > 1) return a.K % 64 == 0 && batch > 1 ? 14 : 20;
+    if (layout == L_NT) return (a.N >= 2048 && a.K <= 1024 && a.M >= 128) ? 16 : 14;
+    if (layout == L_NN) return (a.K >= 1024 || a.N >= 2048) && a.K >= 384 ? 30 : 14;
+    return ((int64_t)a.M * a.N >= (1 << 21)) ? 14 : (a.K >= 384 ? 30 : 14);
 }
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around every GEMM ----
@@ -465,7 +980,7 @@ struct GemmProf {
 static GemmProf g_prof;
 
 int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
-    const int tile = pick_cfg(a, batch);
+    const int tile = pick_cfg(layout, a, batch);
     const bool prof = g_prof.on && g_prof.n < g_prof.cap;
     if (prof) hipEventRecord(g_prof.ev[2 * g_prof.n], s);
     int rc;
@@ -474,7 +989,7 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     else rc = launch_gemm<L_TN>(a, batch, tile, s);
     if (prof) {
         hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
-        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || tile >= 10);
+        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || (tile >= 10 && tile < 14) || tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33);
         g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
         ++g_prof.n;
     }

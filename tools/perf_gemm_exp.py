@@ -19,8 +19,7 @@ def t(layout, m, n, k, cfg, exp, swz=-1):
     lib.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
     lib.swat_gemm_set_tile(-1); lib.swat_gemm_set_exp(0); lib.swat_gemm_set_swizzle(-1)
     return sum(ms) / 20 * 1e3
-for name, layout, m, n, k in [("fwd fc", ops.NT, 1600, 3072, 768), ("wgrad fc", ops.TN, 3072, 768, 1600), ("big 4096^3", ops.NT, 4096, 4096, 4096)]:
-    for cfg in (6, 9):
-        row = [t(layout, m, n, k, cfg, e) for e in (0, 1, 2, 3, 4, 7)]
-        nosw = t(layout, m, n, k, cfg, 0, swz=0)
-        print(f"{name:12s} cfg{cfg}: full {row[0]:7.1f}us  noloads {row[1]:7.1f}  nomfma {row[2]:7.1f}  neither {row[3]:7.1f}  noepi {row[4]:7.1f}  nothing {row[5]:7.1f} | noswz {nosw:7.1f}   ({2.0*m*n*k/row[0]/1e6:.0f} TF)")
+for name, layout, m, n, k in [("fwd fc", ops.NT, 1600, 3072, 768), ("fwd proj", ops.NT, 1600, 768, 3072), ("wgrad fc", ops.TN, 3072, 768, 1600)]:
+    for cfg in (14, 15, 16):
+        full = t(layout, m, n, k, cfg, 0); dma = t(layout, m, n, k, cfg, 2); nosk = t(layout, m, n, k, cfg, 8); noskd = t(layout, m, n, k, cfg, 10)
+        print(f"{name:10s} cfg{cfg}: skew: full {full:6.1f}us dma-only {dma:6.1f}us | no skew: full {nosk:6.1f} dma-only {noskd:6.1f}   ({2.0*m*n*k/full/1e6:.0f} TF)")

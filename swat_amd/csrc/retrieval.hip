@@ -18,6 +18,12 @@ namespace swat {
 // The next chunk's loads are issued before the current chunk is consumed (register staging).
 // Waves are independent (no workgroup barrier): 4 waves/block, 2 blocks/CU by LDS.
 // --------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f4v_t;
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+    const f4v_t v = __builtin_nontemporal_load(reinterpret_cast<const f4v_t*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 constexpr int KC = 64;              // floats per row per chunk (256 B)
 constexpr int ROW_F4 = KC / 4 + 1;  // padded row stride in float4
 
@@ -33,7 +39,15 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
     if (row0 >= n_rows) return;  // wave-uniform
     const int64_t last = n_rows - 1;
     const int64_t myrow = row0 + lane < last ? row0 + lane : last;
+    // Rows are class-grouped, so a 64-row wave tile almost always sits inside ONE segment: then the query is
+    // wave-uniform and is fetched through the scalar cache (s_load) instead of 16 more vector loads per chunk, which
+    // would double the work of the CU's vector-memory front end on an otherwise pure HBM stream.
+    const int64_t lastrow = row0 + 63 < last ? row0 + 63 : last;
+    const int seg_lo = row_seg ? row_seg[row0] : 0;
+    const int seg_hi = row_seg ? row_seg[lastrow] : 0;
+    const bool uniform_q = __builtin_amdgcn_readfirstlane(seg_lo) == __builtin_amdgcn_readfirstlane(seg_hi);
     const float* q = queries + (row_seg ? (int64_t)row_seg[myrow] * d : 0);
+    const float* qu = queries + (int64_t)__builtin_amdgcn_readfirstlane(seg_lo) * d;
 
     const int lr = lane >> 4;    // row inside a 4-row load group
     const int slot = lane & 15;  // 16-B slot inside the 256-B row chunk
@@ -46,7 +60,7 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
     }
     float4 stage[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) stage[j] = *reinterpret_cast<const float4*>(src[j]);
+    for (int j = 0; j < 16; ++j) stage[j] = nt_load4(src[j]);
 
     float acc = 0.0f;
     const int nchunk = d / KC;
@@ -55,19 +69,32 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
         for (int j = 0; j < 16; ++j) tile[(4 * j + lr) * ROW_F4 + slot] = stage[j];
         if (c + 1 < nchunk) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) stage[j] = *reinterpret_cast<const float4*>(src[j] + (c + 1) * KC);
+            for (int j = 0; j < 16; ++j)
+                stage[j] = nt_load4(src[j] + (c + 1) * KC);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const float4* qc = reinterpret_cast<const float4*>(q + c * KC);
+        if (uniform_q) {
+            const float* qc = qu + c * KC;  // wave-uniform address -> scalar loads; SGPR operand of v_fma
 #pragma unroll
-        for (int g = 0; g < KC / 4; ++g) {
-            const float4 x = tile[lane * ROW_F4 + g];
-            const float4 w = qc[g];
-            acc = fmaf(x.x, w.x, acc);
-            acc = fmaf(x.y, w.y, acc);
-            acc = fmaf(x.z, w.z, acc);
-            acc = fmaf(x.w, w.w, acc);
+            for (int g = 0; g < KC / 4; ++g) {
+                const float4 x = tile[lane * ROW_F4 + g];
+                acc = fmaf(x.x, qc[4 * g + 0], acc);
+                acc = fmaf(x.y, qc[4 * g + 1], acc);
+                acc = fmaf(x.z, qc[4 * g + 2], acc);
+                acc = fmaf(x.w, qc[4 * g + 3], acc);
+            }
+        } else {
+            const float4* qc = reinterpret_cast<const float4*>(q + c * KC);
+#pragma unroll
+            for (int g = 0; g < KC / 4; ++g) {
+                const float4 x = tile[lane * ROW_F4 + g];
+                const float4 w = qc[g];
+                acc = fmaf(x.x, w.x, acc);
+                acc = fmaf(x.y, w.y, acc);
+                acc = fmaf(x.z, w.z, acc);
+                acc = fmaf(x.w, w.w, acc);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();

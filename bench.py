@@ -170,6 +170,31 @@ def retrieval_secondary(dev, steps=5):
                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(ms_sim, 4)}}
 
 
+def retrieval_dense_secondary(dev, steps=3):
+    """BASELINE config 4 on one shard: N_query = 200 random unit queries against 1.25 M x 512 fp32 rows (the per-GPU share
+    of 10 M), k = 500, exact (value desc, row asc) top-k on the fp32 matrix cores (157.3 TF peak)."""
+    from swat_amd.retrieval import dense
+    n, d, nq, k = 1_250_000, 512, 200, 500
+    g = torch.Generator(device=dev).manual_seed(7)
+    db = torch.randn(n, d, device=dev, generator=g)
+    db /= db.norm(dim=-1, keepdim=True)
+    q = torch.randn(nq, d, device=dev, generator=g)
+    q /= q.norm(dim=-1, keepdim=True)
+    dense.topk_dense(db, q, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        idx, val, cnt = dense.topk_dense(db, q, k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tf = 2.0 * nq * n * d / dt / 1e12
+    return {"metric": "retrieval top-k queries/s (dense N_query x N_db, exact fp32)", "value": round(nq / dt, 1), "unit": "queries/s",
+            "config": {"workload": f"{nq} queries x {n} x {d} fp32 rows, k={k}, threshold-pruned exact top-k"},
+            "ms_per_pass": round(dt * 1e3, 3),
+            "roofline": {"bound": "mfma", "kernel": "sim_topk_candidates_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(tf, 1),
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,7 +262,7 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(a.bsz)
         if not a.no_secondary:
-            out["secondary"] = [retrieval_secondary(dev)]
+            out["secondary"] = [retrieval_secondary(dev), retrieval_dense_secondary(dev)]
     elif rank == 0:
         out["roofline"] = None
         out["cpu_baseline"] = None

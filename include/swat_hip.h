@@ -52,6 +52,22 @@ int swat_segment_topk(const float* sims, const float* t2i, const uint8_t* exclud
                       const int64_t* seg_offsets, int64_t n_seg, float thr, float t2i_thr, int k,
                       int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);
 
+/* B4/B5 dense form (BASELINE config 4): S = Q DB^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 is a k-ordered
+ *     fp32 fma chain: bit-identical to swat_sim_segmented and the oracle).  Entries >= thr_dev[q] are appended to
+ *     cand_keys [n_q, cap] (uint64: ordered(sim) << 32 | ~(row_base + row)), cand_cnt [n_q] (uint32, zero it first);
+ *     S_out [n_q, ld_s] optionally receives the full product (threshold sampling, tests).
+ *     ref: the per-class GEMV loop :724-825 generalised to N_query x N_db. */
+int swat_sim_topk_candidates(const float* queries, int n_q, const float* db, int64_t n_db, int d,
+                             const float* thr_dev, int64_t row_base, void* cand_keys, int cap,
+                             void* cand_cnt, float* S_out, int64_t ld_s, swat_stream_t stream);
+/*     sort each query's candidates, emit the (value desc, row asc) top-k (cap <= 8192). */
+int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k,
+                         int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);
+/* B6  remove_near_duplicates2 (ref :237-275): marks[j] = 1 iff <f_i, f_j> > thr for some i < j (S = F F^T on the
+ *     fp32 matrix cores, exact canonical order). */
+int swat_near_dup_marks(const float* feats, int64_t n, int d, float thr, uint8_t* marks,
+                        swat_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Path A — OpenCLIP ViT finetuning step (ref: utils/training.py train_ce :326-347,
  * train_cutmix :1452-1489; the ViT arithmetic is open_clip 2.26.1's VisionTransformer)

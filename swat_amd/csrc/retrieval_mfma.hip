@@ -1,0 +1,186 @@
+// swat_amd/csrc/retrieval_mfma.hip — exact fp32 similarity products on the matrix cores (path B, dense form).
+//
+// gfx950's v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fp32 fma chain (MI355X guide, "FP32-input MFMA"), i.e.
+// exactly the canonical order of oracle/retrieval_oracle.c: feeding k in ascending order makes the matrix-core result
+// BIT-IDENTICAL to the lane-per-row scan kernel and to the CPU oracle.  Two users:
+//   * swat_sim_topk_candidates — the (N_query x N_db) scan of BASELINE config 4: S = Q DB^T tile by tile, entries
+//     >= a per-query threshold are appended (key = ordered(sim) << 32 | ~row) to a per-query candidate list;
+//     swat_candidates_topk sorts a list and emits the (value desc, row asc) top-k.  Exact: the threshold comes from a
+//     sample and the caller checks count >= k (else re-runs that query with a lower threshold).
+//   * swat_near_dup_marks — remove_near_duplicates2 (ref retrieval/sample_retrieval.py:237-275): marks[j] = 1 iff
+//     <f_i, f_j> > thr for some i < j, from S = F F^T.
+// Tiling: block = 4 waves, 64 x 64 output tile (one 32x32 accumulator per wave), 64-float k-chunks staged through LDS
+// with rows padded by one float so the lane-per-row ds_read_b32 operand fetches are conflict-free.  DB rows are
+// streamed once per 64-query tile; fp32 MFMA peak (157 TF) bounds it once N_query > ~40.
+#include "common.hpp"
+#include "../../include/swat_hip.h"
+
+namespace swat {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+constexpr int MK = 64;          // floats per k-chunk
+constexpr int MLD = MK + 1;     // padded LDS row (floats)
+
+__device__ __forceinline__ uint32_t ordered_bits_m(float s) {
+    if (s == 0.0f) s = 0.0f;
+    uint32_t u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// computes the 64x64 tile S[i0.., j0..] = A[i0.., :] . B[j0.., :]^T ; acc layout = v_mfma 32x32 C/D map:
+// col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), for the wave's quadrant (wr, wc).
+__device__ __forceinline__ void tile_product(const float* __restrict__ A, int64_t na, const float* __restrict__ B, int64_t nb,
+                                             int d, int64_t i0, int64_t j0, float* sA, float* sB, f32x16_t& acc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < d; k0 += MK) {
+        // stage 64 rows x 64 floats of each operand: 1024 float4 per operand, 4 per thread
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = tid + 256 * it;
+            const int row = c >> 4, c4 = c & 15;
+            int64_t ra = i0 + row; ra = ra < na ? ra : na - 1;
+            int64_t rb = j0 + row; rb = rb < nb ? rb : nb - 1;
+            const float4 va = *reinterpret_cast<const float4*>(A + ra * d + k0 + 4 * c4);
+            const float4 vb = *reinterpret_cast<const float4*>(B + rb * d + k0 + 4 * c4);
+            float* pa = sA + row * MLD + 4 * c4;
+            float* pb = sB + row * MLD + 4 * c4;
+            pa[0] = va.x; pa[1] = va.y; pa[2] = va.z; pa[3] = va.w;
+            pb[0] = vb.x; pb[1] = vb.y; pb[2] = vb.z; pb[3] = vb.w;
+        }
+        __syncthreads();
+        const float* la = sA + (wr + (lane & 31)) * MLD + (lane >> 5);
+        const float* lb = sB + (wc + (lane & 31)) * MLD + (lane >> 5);
+#pragma unroll 8
+        for (int kk = 0; kk < MK; kk += 2)  // k ascending: the MFMA adds k = kk (lanes 0-31) then kk+1 (lanes 32-63)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(la[kk], lb[kk], acc, 0, 0, 0);
+        __syncthreads();
+    }
+}
+
+// grid: (ceil(n_db / 64), ceil(n_q / 64)).  A = queries (rows of S), B = db (columns of S).
+__global__ __launch_bounds__(256) void sim_topk_candidates_kernel(const float* __restrict__ queries, int n_q,
+                                                                  const float* __restrict__ db, int64_t n_db, int d,
+                                                                  const float* __restrict__ thr, int64_t row_base,
+                                                                  unsigned long long* __restrict__ cand, int cap,
+                                                                  unsigned* __restrict__ cnt, float* __restrict__ S_out,
+                                                                  int64_t ld_s) {
+    __shared__ float sA[64 * MLD];
+    __shared__ float sB[64 * MLD];
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    const int64_t i0 = (int64_t)blockIdx.y * 64;
+    f32x16_t acc;
+    tile_product(queries, n_q, db, n_db, d, i0, j0, sA, sB, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t col = j0 + (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < n_q && col < n_db) {
+            const float s = acc[r];
+            if (S_out) S_out[row * ld_s + col] = s;
+            if (cand && s >= thr[row]) {
+                const unsigned pos = atomicAdd(&cnt[row], 1u);
+                if (pos < (unsigned)cap)
+                    cand[row * (int64_t)cap + pos] = ((unsigned long long)ordered_bits_m(s) << 32) |
+                                                     (unsigned long long)(0xFFFFFFFFu - (uint32_t)(row_base + col));
+            }
+        }
+    }
+}
+
+// marks[j] = 1 iff exists i < j with <f_i, f_j> > thr.  grid over the upper-triangular tiles (x = j tile >= y = i tile).
+__global__ __launch_bounds__(256) void near_dup_kernel(const float* __restrict__ F, int64_t n, int d, float thr,
+                                                       uint8_t* __restrict__ marks) {
+    if (blockIdx.x < blockIdx.y) return;
+    __shared__ float sA[64 * MLD];
+    __shared__ float sB[64 * MLD];
+    const int64_t j0 = (int64_t)blockIdx.x * 64, i0 = (int64_t)blockIdx.y * 64;
+    f32x16_t acc;
+    tile_product(F, n, F, n, d, i0, j0, sA, sB, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t col = j0 + (wave & 1) * 32 + (lane & 31);
+    bool hit = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < col && col < n && acc[r] > thr) hit = true;
+    }
+    if (hit) marks[col] = 1;  // every writer stores the same value
+}
+
+// One block per query: sort its candidate keys (<= CAND_MAX) descending, emit the first k.
+constexpr int CAND_MAX = 8192;
+__global__ __launch_bounds__(256) void candidates_topk_kernel(const unsigned long long* __restrict__ cand, int cap,
+                                                              const unsigned* __restrict__ cnt, int k,
+                                                              int64_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                              int64_t* __restrict__ out_cnt) {
+    __shared__ unsigned long long keys[CAND_MAX];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    unsigned n = cnt[q];
+    if (n > (unsigned)cap) n = cap;
+    int np2 = 1;
+    while (np2 < (int)n) np2 <<= 1;
+    for (int i = tid; i < np2; i += 256) keys[i] = i < (int)n ? cand[q * (int64_t)cap + i] : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < np2 / 2; i += 256) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], c = keys[hi];
+                if ((a < c) == desc) { keys[lo] = c; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int kk = (int)n < k ? (int)n : k;
+    for (int r = tid; r < k; r += 256) {
+        int64_t idx = -1;
+        float val = -INFINITY;
+        if (r < kk) {
+            const unsigned long long key = keys[r];
+            idx = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+            const uint32_t o = (uint32_t)(key >> 32);
+            val = __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+        }
+        out_idx[(int64_t)q * k + r] = idx;
+        out_val[(int64_t)q * k + r] = val;
+    }
+    if (tid == 0) out_cnt[q] = kk;
+}
+
+}  // namespace swat
+using namespace swat;
+
+SWAT_API int swat_sim_topk_candidates(const float* queries, int n_q, const float* db, int64_t n_db, int d,
+                                      const float* thr_dev, int64_t row_base, void* cand_keys, int cap, void* cand_cnt,
+                                      float* S_out, int64_t ld_s, swat_stream_t s) {
+    SWAT_REQUIRE(d > 0 && d % MK == 0, "swat_sim_topk_candidates: d=%d must be a multiple of %d", d, MK);
+    SWAT_REQUIRE(n_q > 0 && n_db > 0, "swat_sim_topk_candidates: empty operand");
+    SWAT_REQUIRE(row_base + n_db < (1ll << 32), "swat_sim_topk_candidates: global rows must fit 32 bits");
+    SWAT_REQUIRE((cand_keys && cand_cnt && thr_dev) || S_out, "swat_sim_topk_candidates: nothing to produce");
+    dim3 grid((unsigned)((n_db + 63) / 64), (unsigned)((n_q + 63) / 64));
+    hipLaunchKernelGGL(sim_topk_candidates_kernel, grid, dim3(256), 0, (hipStream_t)s, queries, n_q, db, n_db, d, thr_dev,
+                       row_base, (unsigned long long*)cand_keys, cap, (unsigned*)cand_cnt, S_out, ld_s);
+    return check_launch("swat_sim_topk_candidates");
+}
+
+SWAT_API int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k, int64_t* out_idx,
+                                  float* out_val, int64_t* out_cnt, swat_stream_t s) {
+    SWAT_REQUIRE(cap >= 1 && cap <= CAND_MAX && k >= 1 && k <= cap, "swat_candidates_topk: need 1 <= k <= cap <= %d", CAND_MAX);
+    hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(256), 0, (hipStream_t)s, (const unsigned long long*)cand_keys,
+                       cap, (const unsigned*)cand_cnt, k, out_idx, out_val, out_cnt);
+    return check_launch("swat_candidates_topk");
+}
+
+SWAT_API int swat_near_dup_marks(const float* feats, int64_t n, int d, float thr, uint8_t* marks, swat_stream_t s) {
+    SWAT_REQUIRE(d > 0 && d % MK == 0, "swat_near_dup_marks: d=%d must be a multiple of %d", d, MK);
+    if (n <= 0) return 0;
+    hipMemsetAsync(marks, 0, (size_t)n, (hipStream_t)s);
+    const unsigned t = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(near_dup_kernel, dim3(t, t), dim3(256), 0, (hipStream_t)s, feats, n, d, thr, marks);
+    return check_launch("swat_near_dup_marks");
+}

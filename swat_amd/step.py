@@ -11,7 +11,7 @@ from .ddp import SliceReducer
 
 
 class FusedTrainStep:
-    def __init__(self, model, classifier_head, logit_scale, optimizer, world_size=None):
+    def __init__(self, model, classifier_head, logit_scale, optimizer, world_size=None, staged=None):
         self.visual = model.visual
         self.head = classifier_head
         self.logit_scale = logit_scale
@@ -28,6 +28,10 @@ class FusedTrainStep:
         self._ws = {}
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.opt.grad_scale = 1.0 / self.world
+        # staged backward (one call per stage + a slice all-reduce after each) is the N > 1 path; `staged=True` forces it
+        # at world 1 so single-GPU tests exercise exactly the code the 8-GPU job runs
+        self.staged = (self.world > 1) if staged is None else bool(staged)
+        self.reduce = self.staged and dist.is_initialized()
         # contiguous gradient slices per backward stage (the tower is laid out stage by stage in the arena)
         self._stage_slices = []
         if self.train_visual:
@@ -64,18 +68,18 @@ class FusedTrainStep:
                                        _lib.ptr(dfeats), g.data_ptr() + 4 * self.off_head, g.data_ptr() + 4 * self.off_ls, None,
                                        None, _lib.ptr(self.loss_accum), B, self.E, self.C, 1, _lib.stream())
         _lib.check(rc, "swat_head_loss")
-        if self.world > 1:
-            lo = min(self.off_head, self.off_ls)
-            hi = max(self.off_head + self.C * self.E, self.off_ls + 1)
-            red.reduce(g, lo, hi)
+        if self.reduce:
+            red.reduce(g, self.off_head, self.off_head + self.C * self.E)  # head group (first in the arena)
+            red.reduce(g, self.off_ls, self.off_ls + 1)                      # logit_scale group (last)
         if self.train_visual:
             L = self.visual.layers
-            if self.world > 1:
+            if self.staged:
                 # stage by stage: reduce a stage's slice (RCCL, its own stream) while the next stage's kernels run
                 for s in range(L + 1, -1, -1):
                     self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
-                    lo, hi = self._stage_slices[s]
-                    red.reduce(g, lo, hi)
+                    if self.reduce:
+                        lo, hi = self._stage_slices[s]
+                        red.reduce(g, lo, hi)
             else:
                 self.visual.backward_raw(dfeats)
         red.wait()

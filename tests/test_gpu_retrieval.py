@@ -148,3 +148,45 @@ def test_full_size_properties():
     sub = feats[: 2 * (n // nseg)].cpu().numpy()
     o_idx, o_cnt = orc.sample_index(sub, None, q[:2].cpu().numpy(), off[:3].cpu().numpy(), k, thr=-2.0)
     assert np.array_equal(idx[:2].cpu().numpy(), o_idx)
+
+
+@pytest.mark.parametrize("n,nq,k", [(3000, 5, 17), (70000, 33, 500), (200001, 200, 500)])
+def test_dense_mfma_topk_bit_exact_vs_oracle(n, nq, k):
+    """(N_query x N_db) scan on the fp32 matrix cores: same bits as the lane-per-row kernel and the C oracle."""
+    from swat_amd.retrieval import dense, ops
+    dev = _dev()
+    rs = np.random.RandomState(n + nq)
+    db = synth.unit_rows(rs, n, 512)
+    for _ in range(n // 20):
+        a, b = rs.randint(n), rs.randint(n)
+        db[a] = db[b]
+    q = synth.unit_rows(rs, nq, 512)
+    d_db, d_q = torch.from_numpy(db).to(dev), torch.from_numpy(q).to(dev)
+    idx, val, cnt = dense.topk_dense(d_db, d_q, k, row_base=0)
+    chk = min(nq, 4)  # the oracle sorts all n rows per query: keep the CPU leg to seconds
+    o_idx, o_val = orc.topk_multi(db, q[:chk], k)
+    assert np.array_equal(idx[:chk].cpu().numpy(), o_idx)
+    assert np.array_equal(val[:chk].cpu().numpy(), o_val)
+    assert (cnt == min(k, n)).all()
+    # every query: MFMA similarities == lane-per-row scan kernel, bit for bit; lists sorted with the tie rule
+    S = dense.sim_matrix(d_q[:8].contiguous(), d_db[:4096].contiguous())
+    for i in range(min(8, nq)):
+        s = ops.similarity_segmented(d_db[:4096].contiguous(), d_q[i:i + 1].contiguous())
+        assert torch.equal(S[i], s)
+    assert (val[:, 1:] <= val[:, :-1]).all()
+    ties = val[:, 1:] == val[:, :-1]
+    assert (idx[:, 1:][ties] > idx[:, :-1][ties]).all()
+
+
+@pytest.mark.parametrize("kind", ["grid", "float"])
+def test_near_dup_matches_reference_golden(golden_dir, kind):
+    from swat_amd.retrieval import SegmentedIndex, dense
+    g, spec, case = _load(golden_dir, kind)
+    dev = _dev()
+    index = SegmentedIndex(torch.from_numpy(case["img"]), torch.from_numpy(case["cap"]), torch.from_numpy(case["labels"]),
+                           case["paths"], device=dev)
+    dups, fracs, avg = dense.remove_near_duplicates2(index)
+    path_to_row = {p: i for i, p in enumerate(case["paths"])}
+    rows = np.array(sorted(path_to_row[p] for c in dups for p in dups[c]), np.int64)
+    assert np.array_equal(rows, g["dedup_rows"])
+    assert np.allclose(fracs, g["dedup_frac"], rtol=0, atol=1e-12)

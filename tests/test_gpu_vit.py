@@ -209,3 +209,44 @@ def test_validate_matches_oracle_eval():
     assert cm.sum() == n and cm.shape == (C, C)
     s = calculate_scores(cm)
     assert abs(s["acc"] * 100 - acc) < 1e-9
+
+
+def test_staged_backward_with_process_group_equals_monolithic_step():
+    """The N > 1 code path (stage-by-stage backward + a slice all-reduce after every stage) run on ONE GPU inside a
+    1-rank RCCL process group must reproduce the monolithic step bit for bit (same kernels, same order per tensor)."""
+    import os
+    import torch.distributed as dist
+    from swat_amd import optimizers
+    from swat_amd.clip_model import CLIP
+    from swat_amd.models import MyLinear
+    from swat_amd.step import FusedTrainStep
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+        created = True
+    try:
+        results = []
+        for staged in (False, True):
+            torch.manual_seed(3)
+            model = CLIP(vision_cfg=TINY, text_cfg=(8, 64, 64, 1, 1)).to(dev())
+            W = torch.randn(10, TINY[5])
+            head = MyLinear(weights=W).to(dev())
+            args = _args()
+            params, ls = optimizers.set_params(args, model, head, _Lg())
+            opt, sched, _ = optimizers.set_optimizer(args, params, [None] * 50)
+            step = FusedTrainStep(model, head, ls, opt, world_size=1, staged=staged)
+            g = torch.Generator().manual_seed(9)
+            for it in range(3):
+                x = torch.randn(8, 3, 64, 64, generator=g).to(dev())
+                y = torch.randint(0, 10, (8,), generator=g).to(dev())
+                step(x, y, y.flip(0), 0.6, perm=torch.arange(7, -1, -1, device=dev()), box=(3, 9, 40, 50))
+                sched.step()
+            results.append((opt.arena.flat.clone(), opt.arena.grad.clone(), step.loss.clone()))
+        assert torch.equal(results[0][0], results[1][0])
+        assert torch.equal(results[0][1], results[1][1])
+        assert torch.equal(results[0][2], results[1][2])
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -196,6 +196,15 @@ int swat_head_loss(const float* feats, const float* W, const float* logit_scale_
                    float* dlogit_scale, float* z_out, float* feat_norm_out, double* loss_accum, int B,
                    int E, int C, int want_grad, swat_stream_t stream);
 
+/* §8(f).1  CLIP text tower pieces (ref: model.encode_text — utils/features.py:27-36, extract_mined_feature.py:119-121):
+ *     token-embedding gather + positional add, and a forward-only stack of L pre-LN blocks on x [B*T, d] fp32 (in
+ *     place) with an optional causal mask.  dims (HOST int32[8]): B, T, d, L, H, mlp, act, causal; offs 12 per block. */
+int swat_embed_tokens(const int64_t* tokens, const float* table, const float* pos, float* out, int64_t rows,
+                      int T, int d, swat_stream_t stream);
+int64_t swat_transformer_workspace_bytes(const int32_t* dims);
+int swat_transformer_forward(const int32_t* dims, const int64_t* offs, const float* params,
+                             const void* shadow_bf16, float* x, void* workspace, swat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

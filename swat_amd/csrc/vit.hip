@@ -138,12 +138,12 @@ static GemmArgs G(const void* A, const void* B, void* C, int M, int N, int K, in
 
 // multi-head attention forward on the packed qkv buffer of one layer
 static int attn_forward(const VitDims& D, const unsigned short* qkv, float* S, unsigned short* P, unsigned short* out,
-                        hipStream_t s) {
+                        hipStream_t s, int causal = 0) {
     const int T = D.T, d = D.d, dh = D.dh, H = D.H, ldp = D.ldp;
     GemmArgs a = G(qkv, qkv + d, S, T, T, dh, 3 * d, 3 * d, ldp, 1);
     a.inner = H; a.sA0 = (int64_t)T * 3 * d; a.sA1 = dh; a.sB0 = a.sA0; a.sB1 = dh; a.sC0 = (int64_t)H * T * ldp; a.sC1 = (int64_t)T * ldp;
     TRY(gemm_dispatch(L_NT, a, D.B * H, s));
-    TRY(swat_softmax_fwd(S, P, (int64_t)D.B * H * T, T, T, ldp, 1.0f / sqrtf((float)dh), 0, s));
+    TRY(swat_softmax_fwd(S, P, (int64_t)D.B * H * T, T, T, ldp, 1.0f / sqrtf((float)dh), causal, s));
     GemmArgs b = G(P, qkv + 2 * d, out, T, dh, T, ldp, 3 * d, d, 0);
     b.inner = H; b.sA0 = (int64_t)H * T * ldp; b.sA1 = (int64_t)T * ldp; b.sB0 = (int64_t)T * 3 * d; b.sB1 = dh; b.sC0 = (int64_t)T * d; b.sC1 = dh;
     return gemm_dispatch(L_NN, b, D.B * H, s);
@@ -175,6 +175,20 @@ static int attn_backward(const VitDims& D, const unsigned short* qkv, const unsi
         TRY(gemm_dispatch(L_TN, a, BH, s));
     }
     return 0;
+}
+
+
+// ---- token embedding gather + positional add (text tower input; ref: open_clip CLIP.encode_text) ----
+__global__ void embed_tokens_kernel(const int64_t* __restrict__ tok, const float* __restrict__ table, const float* __restrict__ pos,
+                                    float* __restrict__ out, int64_t rows, int T, int d) {
+    const int64_t total = rows * (d / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (d / 4);
+        const int c = (int)(i % (d / 4));
+        const float4 e = reinterpret_cast<const float4*>(table + tok[r] * d)[c];
+        const float4 q = reinterpret_cast<const float4*>(pos + (r % T) * d)[c];
+        reinterpret_cast<float4*>(out + r * d)[c] = make_float4(e.x + q.x, e.y + q.y, e.z + q.z, e.w + q.w);
+    }
 }
 
 }  // namespace swat
@@ -372,6 +386,75 @@ SWAT_API int swat_head_loss(const float* feats, const float* W, const float* log
         TRY(swat_sgemm_small(dz, fn, dW, C, E, B, 1, C, E, 1, E, 1.0f, 0, s));   // dW[c,e]  = sum_b dz[b,c] fn[b,e]
         TRY(swat_sgemm_small(dz, W, dfn, B, E, C, C, 1, E, 1, E, 1.0f, 0, s));   // dfn[b,e] = sum_c dz[b,c] W[c,e]
         TRY(swat_l2norm_bwd(fn, nrm, dfn, dfeats, B, E, s));
+    }
+    return 0;
+}
+
+SWAT_API int swat_embed_tokens(const int64_t* tokens, const float* table, const float* pos, float* out, int64_t rows, int T,
+                               int d, swat_stream_t s) {
+    SWAT_REQUIRE(d % 4 == 0, "swat_embed_tokens: d must be a multiple of 4");
+    if (rows <= 0) return 0;
+    int64_t blocks = (rows * (d / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, tokens, table, pos, out, rows, T, d);
+    return check_launch("swat_embed_tokens");
+}
+
+// Forward-only stack of L pre-LN residual blocks on x [B*T, d] fp32 (in place): the CLIP text tower (causal = 1; ref:
+// model.encode_text, utils/features.py:27-36, retrieval/extract_mined_feature.py:119-121) or any frozen tower.
+// dims (HOST int32[8]): B, T, d, L, H, mlp, act, causal.  offs: 12 per block, as in swat_vit_forward.
+SWAT_API int64_t swat_transformer_workspace_bytes(const int32_t* dims) {
+    const int64_t B = dims[0], T = dims[1], d = dims[2], H = dims[4], mlp = dims[5];
+    const int64_t M = B * T, ldp = (T + 7) / 8 * 8;
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    return al(M * d * 2) * 2 + al(M * 3 * d * 2) + al(B * H * T * ldp * 4) + al(B * H * T * ldp * 2) + al(M * mlp * 2) * 2 + al(M * d * 4) + 1024;
+}
+
+SWAT_API int swat_transformer_forward(const int32_t* dims, const int64_t* offs, const float* params, const void* shadow_bf16,
+                                      float* x, void* workspace, swat_stream_t stream) {
+    VitDims D{};
+    D.B = dims[0]; D.T = dims[1]; D.d = dims[2]; D.L = dims[3]; D.H = dims[4]; D.mlp = dims[5]; D.act = dims[6];
+    const int causal = dims[7];
+    SWAT_REQUIRE(D.B > 0 && D.T > 0 && D.d % 64 == 0 && D.H > 0 && D.d % D.H == 0 && (D.d / D.H) % 8 == 0, "swat_transformer_forward: bad dims");
+    D.M = D.B * D.T; D.dh = D.d / D.H; D.ldp = (D.T + 7) / 8 * 8;
+    const int M = D.M, d = D.d;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned short* sh = (const unsigned short*)shadow_bf16;
+    char* p = (char*)workspace;
+    auto take = [&](int64_t bytes) { void* r = p; p += (bytes + 255) / 256 * 256; return r; };
+    unsigned short* h = (unsigned short*)take((int64_t)M * d * 2);
+    unsigned short* at = (unsigned short*)take((int64_t)M * d * 2);
+    unsigned short* qkv = (unsigned short*)take((int64_t)M * 3 * d * 2);
+    float* S = (float*)take((int64_t)D.B * D.H * D.T * D.ldp * 4);
+    unsigned short* P = (unsigned short*)take((int64_t)D.B * D.H * D.T * D.ldp * 2);
+    unsigned short* f = (unsigned short*)take((int64_t)M * D.mlp * 2);
+    unsigned short* ga = (unsigned short*)take((int64_t)M * D.mlp * 2);
+    float* x1 = (float*)take((int64_t)M * d * 4);
+    for (int l = 0; l < D.L; ++l) {
+        const int64_t* lo = offs + 12 * l;
+        TRY(swat_layernorm_fwd(x, d, params + lo[LN1W], params + lo[LN1B], h, nullptr, nullptr, nullptr, M, d, 1e-5f, s));
+        {
+            GemmArgs a = G(h, sh + lo[QKVW], qkv, M, 3 * d, d, d, d, 3 * d, 0);
+            a.bias = params + lo[QKVB];
+            TRY(gemm_dispatch(L_NT, a, 1, s));
+        }
+        TRY(attn_forward(D, qkv, S, P, at, s, causal));
+        {
+            GemmArgs a = G(at, sh + lo[OUTW], x1, M, d, d, d, d, d, 1);
+            a.bias = params + lo[OUTB]; a.residual = x;
+            TRY(gemm_dispatch(L_NT, a, 1, s));
+        }
+        TRY(swat_layernorm_fwd(x1, d, params + lo[LN2W], params + lo[LN2B], h, nullptr, nullptr, nullptr, M, d, 1e-5f, s));
+        {
+            GemmArgs a = G(h, sh + lo[FCW], f, M, D.mlp, d, d, d, D.mlp, 0);
+            a.bias = params + lo[FCB]; a.act = D.act; a.C2 = ga;
+            TRY(gemm_dispatch(L_NT, a, 1, s));
+        }
+        {
+            GemmArgs a = G(ga, sh + lo[PRW], x, M, d, D.mlp, D.mlp, D.mlp, d, 1);
+            a.bias = params + lo[PRB]; a.residual = x1;
+            TRY(gemm_dispatch(L_NT, a, 1, s));
+        }
     }
     return 0;
 }

@@ -250,3 +250,23 @@ def test_staged_backward_with_process_group_equals_monolithic_step():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_text_tower_matches_oracle():
+    """encode_text (token gather, causal blocks, ln_final at EOT, text_projection) vs the fp32 oracle."""
+    from swat_amd.clip_model import CLIP
+    torch.manual_seed(2)
+    ctx, vocab, tw, th, tl = 16, 300, 128, 2, 3
+    ref = vo.OracleCLIP(vision_cfg=TINY, text_width=tw, text_heads=th, text_layers=tl, ctx=ctx, vocab=vocab)
+    model = CLIP(vision_cfg=TINY, text_cfg=(ctx, vocab, tw, th, tl))
+    model.load_state_dict(ref.state_dict())
+    model.to(dev())
+    tok = torch.randint(1, vocab - 1, (6, ctx))
+    for i in range(6):  # EOT (highest id) at a ragged position, zero padding after it
+        e = 3 + 2 * i
+        tok[i, e] = vocab - 1
+        tok[i, e + 1:] = 0
+    with torch.no_grad():
+        want = ref.encode_text(tok)
+    got = model.encode_text(tok.to(dev()))
+    assert (got.cpu() - want).abs().max().item() <= 0.02 * want.abs().max().item()

@@ -189,12 +189,13 @@ int swat_vit_backward(const int32_t* dims, const int64_t* offs, const float* par
                       int stage_hi, int stage_lo, swat_stream_t stream);
 /* A3+A4+A6 fused with their backward (ref utils/training.py:1475-1481): loss, d/dfeats, d/dW_head,
  *     d/dlogit_scale.  want_grad = 0: forward only (validate, testing.py:430-447); z_out / feat_norm_out
- *     optionally receive the un-scaled head output and the normalised features. */
+ *     optionally receive the un-scaled head output and the normalised features.  normalize = 0: feats are
+ *     pre-extracted unit-norm features and are used as they are (train_probing, utils/training.py:96-97). */
 int64_t swat_head_loss_workspace_bytes(int B, int E, int C);
 int swat_head_loss(const float* feats, const float* W, const float* logit_scale_dev, const int64_t* ya,
                    const int64_t* yb, float lam, void* workspace, float* loss, float* dfeats, float* dW,
                    float* dlogit_scale, float* z_out, float* feat_norm_out, double* loss_accum, int B,
-                   int E, int C, int want_grad, swat_stream_t stream);
+                   int E, int C, int want_grad, int normalize, swat_stream_t stream);
 
 /* §8(f).1  CLIP text tower pieces (ref: model.encode_text — utils/features.py:27-36, extract_mined_feature.py:119-121):
  *     token-embedding gather + positional add, and a forward-only stack of L pre-LN blocks on x [B*T, d] fp32 (in

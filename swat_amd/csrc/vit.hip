@@ -367,7 +367,7 @@ SWAT_API int64_t swat_head_loss_workspace_bytes(int B, int E, int C) {
 SWAT_API int swat_head_loss(const float* feats, const float* W, const float* logit_scale_dev, const int64_t* ya,
                             const int64_t* yb, float lam, void* workspace, float* loss, float* dfeats, float* dW,
                             float* dlogit_scale, float* z_out, float* feat_norm_out, double* loss_accum, int B, int E,
-                            int C, int want_grad, swat_stream_t s) {
+                            int C, int want_grad, int normalize, swat_stream_t s) {
     SWAT_REQUIRE(feats && W && logit_scale_dev && ya && yb && workspace && loss, "swat_head_loss: null pointer");
     float* fn = (float*)workspace;
     float* nrm = fn + (int64_t)B * E;
@@ -377,15 +377,16 @@ SWAT_API int swat_head_loss(const float* feats, const float* W, const float* log
     float* ps = dfn + (int64_t)B * E;
     if (feat_norm_out) fn = feat_norm_out;
     if (z_out) z = z_out;
-    TRY(swat_l2norm_fwd(feats, fn, nrm, B, E, s));
+    if (normalize) TRY(swat_l2norm_fwd(feats, fn, nrm, B, E, s));
+    else fn = const_cast<float*>(feats);  // pre-extracted, already unit-norm features (train_probing, ref utils/training.py:96-97)
     TRY(swat_sgemm_small(fn, W, z, B, C, E, E, 1, 1, E, C, 1.0f, 0, s));  // z[b,c] = sum_e fn[b,e] W[c,e]
     TRY(swat_ce_mixed(z, logit_scale_dev, ya, yb, lam, ps, loss, dlogit_scale, want_grad ? dz : nullptr, nullptr, loss_accum,
                       B, C, s));
     if (want_grad) {
-        SWAT_REQUIRE(dfeats && dW && dlogit_scale, "swat_head_loss: gradient outputs are null");
+        SWAT_REQUIRE((dfeats || !normalize) && dW && dlogit_scale, "swat_head_loss: gradient outputs are null");
         TRY(swat_sgemm_small(dz, fn, dW, C, E, B, 1, C, E, 1, E, 1.0f, 0, s));   // dW[c,e]  = sum_b dz[b,c] fn[b,e]
         TRY(swat_sgemm_small(dz, W, dfn, B, E, C, C, 1, E, 1, E, 1.0f, 0, s));   // dfn[b,e] = sum_c dz[b,c] W[c,e]
-        TRY(swat_l2norm_bwd(fn, nrm, dfn, dfeats, B, E, s));
+        if (normalize) TRY(swat_l2norm_bwd(fn, nrm, dfn, dfeats, B, E, s));
     }
     return 0;
 }

@@ -1,0 +1,134 @@
+"""Datasets / loaders without torchvision (mirror of the reference's utils/dataloader.py + utils/datasets/dataset_utils.py).
+
+ref: MyDataset dataset_utils.py:130-180 (list files `relpath label source`), TensorDataset :237-255,
+     get_dataloader dataloader.py:107-135 (train bsz=args.bsz shuffle drop_last; val 128; test 256),
+     extract_dataloader :11-31, extract_train_dataloader :278-296, set_dataloaders :182-254.
+"""
+import os
+
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from .features import extract_test_feats
+from .transforms import build_transform
+
+
+def _pil_loader(path):
+    from PIL import Image
+    with open(path, 'rb') as f:
+        return Image.open(f).convert('RGB')
+
+
+class MyDataset(Dataset):
+    def __init__(self, dataset_root, split, transform, tokenized_text_prompts=None, loader=_pil_loader):
+        self.loader, self.transform, self.tokenized_text_prompts = loader, transform, tokenized_text_prompts
+        lines = []
+        for file, path in zip(split[0], split[1]):
+            with open(os.path.join(dataset_root, file), 'r') as f:
+                lines.extend(os.path.join(path, l) for l in f.readlines())
+        self.data, self.labels = [], []
+        for line in lines:
+            path, id, is_fewshot = line.strip('\n').split(' ')
+            self.data.append((path, int(id), int(is_fewshot)))
+            self.labels.append(int(id))
+        self.targets = self.labels
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, i):
+        path, label, source = self.data[i]
+        img = self.transform(self.loader(path))
+        if self.tokenized_text_prompts is not None:
+            tok = self.tokenized_text_prompts[str(label)]['all']
+            tok = tok[torch.randint(0, tok.size(0), (1,))]  # one random prompt per sample (ref :174)
+        else:
+            tok = torch.zeros(1, 1, dtype=torch.long)
+        return img, label, tok, source
+
+
+class TensorDataset(Dataset):
+    """Pre-extracted features saved by extract_test_feats: {'image_features' [N,E], 'labels' [N]}."""
+
+    def __init__(self, pre_extracted_path=None, device='cpu', data=None):
+        d = data if data is not None else torch.load(pre_extracted_path, map_location='cpu', weights_only=False)
+        self.input_tensor, self.label_tensor = d['image_features'], d['labels']
+
+    def __len__(self):
+        return self.label_tensor.size(0)
+
+    def __getitem__(self, i):
+        return self.input_tensor[i], self.label_tensor[i], self.label_tensor[i], self.label_tensor[i]
+
+
+class SyntheticImages(Dataset):
+    """Seeded N(0,1) images with class-dependent mean shift: a dataset-free smoke path for the CLI (--synthetic)."""
+
+    def __init__(self, n, num_classes, size=224, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.labels = torch.randint(0, num_classes, (n,), generator=g)
+        self.seed, self.size, self.n = seed, size, n
+        self.targets = self.labels.tolist()
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        y = int(self.labels[i])
+        img = torch.randn(3, self.size, self.size, generator=g) + 0.15 * ((y % 7) - 3)
+        return img, y, torch.zeros(1, 1, dtype=torch.long), 1
+
+
+def load_dataset(dataset_root, split, preprocess, tokenized_text_prompts):
+    return MyDataset(dataset_root, split, preprocess, tokenized_text_prompts)
+
+
+def get_dataloader(args, train_split, val_split, test_split, tokenized_text_prompts, preprocess):
+    if getattr(args, 'synthetic', 0):
+        C = args.num_classes
+        tr, va, te = SyntheticImages(args.synthetic, C, seed=1), SyntheticImages(max(64, args.synthetic // 4), C, seed=2), \
+            SyntheticImages(max(64, args.synthetic // 4), C, seed=3)
+    else:
+        tr = load_dataset(args.dataset_root, train_split, build_transform(224, 'train'), tokenized_text_prompts)
+        va = load_dataset(args.dataset_root, val_split, preprocess, tokenized_text_prompts)
+        te = load_dataset(args.dataset_root, test_split, preprocess, tokenized_text_prompts)
+    train_loader = DataLoader(tr, batch_size=args.bsz, pin_memory=True, shuffle=True, drop_last=True, num_workers=args.num_workers)
+    val_loader = DataLoader(va, batch_size=128, drop_last=False, pin_memory=True, shuffle=False, num_workers=args.num_workers)
+    test_loader = DataLoader(te, batch_size=256, drop_last=False, pin_memory=True, shuffle=False, num_workers=args.num_workers)
+    return train_loader, val_loader, test_loader
+
+
+def _dataset_for(args, split, preprocess, tokenized_text_prompts, seed):
+    if getattr(args, 'synthetic', 0):
+        return SyntheticImages(max(64, args.synthetic // 4), args.num_classes, seed=seed)
+    return load_dataset(args.dataset_root, split, preprocess, tokenized_text_prompts)
+
+
+def extract_dataloader(args, model, split, fea_path, preprocess, tokenized_text_prompts, bsz=128, seed=2):
+    """ref :11-31 — encode the split once with `model`, cache to fea_path, serve the features (bsz 128, no shuffle)."""
+    ds = _dataset_for(args, split, preprocess, tokenized_text_prompts, seed)
+    feats = extract_test_feats(model, DataLoader(ds, batch_size=128, shuffle=False, num_workers=args.num_workers))
+    os.makedirs(os.path.dirname(fea_path) or '.', exist_ok=True)
+    torch.save(feats, fea_path)
+    return DataLoader(TensorDataset(data=feats), batch_size=bsz, shuffle=False, drop_last=False, num_workers=0)
+
+
+def extract_train_dataloader(args, model, split, fea_path, preprocess, tokenized_text_prompts, bsz=32):
+    """ref :278-296 — same with the TRAIN transform, shuffled batches of args.bsz."""
+    if getattr(args, 'synthetic', 0):
+        ds = SyntheticImages(args.synthetic, args.num_classes, seed=1)
+    else:
+        ds = load_dataset(args.dataset_root, split, build_transform(224, 'train'), tokenized_text_prompts)
+    feats = extract_test_feats(model, DataLoader(ds, batch_size=128, shuffle=False, num_workers=args.num_workers))
+    os.makedirs(os.path.dirname(fea_path) or '.', exist_ok=True)
+    torch.save(feats, fea_path)
+    return DataLoader(TensorDataset(data=feats), batch_size=bsz, shuffle=True, drop_last=True, num_workers=0)
+
+
+def set_dataloaders(args, model, tokenized_text_prompts, preprocess, logger):
+    """ref :182-254 (image loaders; the pre-extracted branch serves cached features)."""
+    train_loader, val_loader, test_loader = get_dataloader(args, args.train_split, args.val_split, args.test_split,
+                                                           tokenized_text_prompts, preprocess)
+    logger.info(f'len(train_loader): {len(train_loader)}, len(val_loader): {len(val_loader)}, len(test_loader): {len(test_loader)}')
+    return train_loader, val_loader, test_loader

@@ -20,11 +20,16 @@ class FusedTrainStep:
         W = classifier_head.linear.weight
         self.C, self.E = W.shape
         self.off_head = self.arena.offset_of(W)
-        self.off_ls = self.arena.offset_of(logit_scale)
+        try:
+            self.off_ls = self.arena.offset_of(logit_scale)
+        except RuntimeError:
+            self.off_ls = None  # fixed temperature (probing / zero-shot: ref utils/optimizers.py:51,58), not trained
         self.train_visual = any(g.get('swat_tower') is self.visual for g in optimizer.param_groups)
         dev = self.arena.flat.device
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)  # per-epoch running sum: ONE host sync per epoch
+        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._dls_scratch = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ls_fixed = None if self.off_ls is not None else logit_scale.detach().reshape(-1)[:1].to(dev, torch.float32).contiguous()  # per-epoch running sum: ONE host sync per epoch
         self._ws = {}
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.opt.grad_scale = 1.0 / self.world
@@ -61,16 +66,19 @@ class FusedTrainStep:
         if self.train_visual:
             feats = self.visual.forward_raw(images, save=True, perm=perm, box=box)
         else:
-            feats = images  # pre-extracted, already normalised features (train_probing)
+            feats = images.float().contiguous()  # pre-extracted, already normalised features (train_probing)
         g = a.grad
-        rc = _lib.lib().swat_head_loss(_lib.ptr(feats), a.flat.data_ptr() + 4 * self.off_head, a.flat.data_ptr() + 4 * self.off_ls,
+        ls_ptr = a.flat.data_ptr() + 4 * self.off_ls if self.off_ls is not None else _lib.ptr(self._ls_fixed)
+        dls_ptr = g.data_ptr() + 4 * self.off_ls if self.off_ls is not None else _lib.ptr(self._dls_scratch)
+        rc = _lib.lib().swat_head_loss(_lib.ptr(feats), a.flat.data_ptr() + 4 * self.off_head, ls_ptr,
                                        _lib.ptr(target_a), _lib.ptr(target_b), float(lam), _lib.ptr(ws), _lib.ptr(self.loss),
-                                       _lib.ptr(dfeats), g.data_ptr() + 4 * self.off_head, g.data_ptr() + 4 * self.off_ls, None,
-                                       None, _lib.ptr(self.loss_accum), B, self.E, self.C, 1, _lib.stream())
+                                       _lib.ptr(dfeats), g.data_ptr() + 4 * self.off_head, dls_ptr, None,
+                                       None, _lib.ptr(self.loss_accum), B, self.E, self.C, 1, int(self.train_visual), _lib.stream())
         _lib.check(rc, "swat_head_loss")
         if self.reduce:
             red.reduce(g, self.off_head, self.off_head + self.C * self.E)  # head group (first in the arena)
-            red.reduce(g, self.off_ls, self.off_ls + 1)                      # logit_scale group (last)
+            if self.off_ls is not None:
+                red.reduce(g, self.off_ls, self.off_ls + 1)                  # logit_scale group (last)
         if self.train_visual:
             L = self.visual.layers
             if self.staged:

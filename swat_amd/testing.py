@@ -63,7 +63,7 @@ def head_eval(feats, W, logit_scale, labels, normalize=True):
     if normalize:
         ws = torch.empty(_lib.lib().swat_head_loss_workspace_bytes(B, E, C), dtype=torch.uint8, device=dev)
         rc = _lib.lib().swat_head_loss(_lib.ptr(feats), _lib.ptr(Wd), _lib.ptr(ls), _lib.ptr(labels), _lib.ptr(labels), 1.0,
-                                       _lib.ptr(ws), _lib.ptr(loss), None, None, None, _lib.ptr(z), None, None, B, E, C, 0,
+                                       _lib.ptr(ws), _lib.ptr(loss), None, None, None, _lib.ptr(z), None, None, B, E, C, 0, 1,
                                        _lib.stream())
         _lib.check(rc, "swat_head_loss")
     else:

@@ -171,3 +171,66 @@ def train_cutmix(args, logger, loss_logger, model, classifier_head, train_loader
     """CutMix finetuning (ref :1422-1556)."""
     logger.info("Start Training cutmix ......")
     return _train_loop(args, logger, loss_logger, model, classifier_head, train_loader, val_loader, test_loader, True)
+
+
+def train_probing(args, logger, loss_logger, model, classifier_head, tokenized_text_prompts, preprocess,
+                  train_loader, val_loader, test_loader, reload_model=False):
+    """Linear probing on (pre-extracted) features with the visual encoder frozen (ref :47-161).
+    -> (best_model, best_head, best_records, best_logit_scale, val_loader, test_loader)"""
+    from .dataloader import extract_dataloader, extract_train_dataloader
+    if reload_model:
+        load_model(args, logger, model, None, classifier_head)
+        root = f'{args.dataset_root}/pre_extracted/{args.dataset}_{args.model_cfg}_{args.seed}'
+        train_loader = extract_train_dataloader(args, model, args.train_split, f'{root}_train_features_new.pth', preprocess,
+                                                tokenized_text_prompts, bsz=args.bsz)
+        val_loader = extract_dataloader(args, model, args.val_split, f'{root}_val_features_new.pth', preprocess, tokenized_text_prompts)
+        test_loader = extract_dataloader(args, model, args.test_split, f'{root}_test_features_new.pth', preprocess, tokenized_text_prompts)
+        args.pre_extracted = True
+    logger.info("Start Training (linear probing) ......")
+    logit_scale = args.logit_scale
+    optimizer, scheduler = args.optimizer, args.scheduler
+    model.eval()
+    classifier_head.train()
+    step = FusedTrainStep(model, classifier_head, logit_scale, optimizer)
+    best_records = {}
+    best_val_acc = -1
+    best_model, best_head, best_logit_scale = model, classifier_head, logit_scale
+    num_iter = 0
+    for epoch in range(1, args.epochs + 1):
+        for inputs, labels, text, source in train_loader:
+            num_iter += 1
+            x = inputs.to(args.device)
+            labels = labels.to(args.device).long()
+            if not args.pre_extracted:
+                from .features import l2_normalize
+                with torch.no_grad():
+                    x = l2_normalize(model.visual.forward_raw(x))
+            step(x, labels, labels, 1.0)
+            scheduler.step()
+        train_loss_sum = step.pop_loss_sum()
+        val_acc, val_loss, confusion_matrix = validate(args, data_loader=val_loader, model=model, logger=logger, loss=args.loss,
+                                                       logit_scale=logit_scale, classifier_head=classifier_head,
+                                                       show_confusion_matrix=True, dataset=args.dataset,
+                                                       output_dir=args.output_dir, device=args.device,
+                                                       pre_extracted=args.pre_extracted)
+        scores = calculate_scores(confusion_matrix)
+        if (args.early_stop or epoch == args.epochs) and val_acc >= best_val_acc:
+            best_val_acc = val_acc
+            best_logit_scale = copy.deepcopy(logit_scale)
+            best_head = copy.deepcopy(classifier_head)
+            best_model = copy.deepcopy(model)
+            best_records.update(best_val_acc=best_val_acc, best_logit_scale=best_logit_scale, best_epoch=epoch,
+                                best_iter=num_iter, best_scores=copy.deepcopy(scores),
+                                best_confusion_matrix=copy.deepcopy(confusion_matrix))
+        test_acc, _, _ = validate(args, data_loader=test_loader, model=model, logger=logger, loss=args.loss,
+                                  logit_scale=logit_scale, classifier_head=classifier_head, dataset=args.dataset,
+                                  output_dir=args.output_dir, device=args.device, pre_extracted=args.pre_extracted)
+        train_loss_avg = train_loss_sum / len(train_loader)
+        loss_logger.write(f'{epoch},{num_iter},{round(train_loss_avg, 6)},{round(val_loss, 6)},{round(val_acc, 6)},{round(test_acc, 6)}\n')
+        loss_logger.flush()
+        logger.info(f"Epoch {int(epoch)}, Iter {num_iter}, Trn Loss: {round(train_loss_avg, 6)}, Val Loss: {round(val_loss, 6)}, "
+                    f"Val Acc: {round(val_acc, 3)}, Test Acc: {round(test_acc, 3)}")
+        if args.save_ckpt and (num_iter % args.save_freq == 0 or epoch == args.epochs):
+            save_model_ckpt(args, best_records, model, classifier_head, optimizer, scheduler, logit_scale, val_acc, epoch, num_iter)
+    logger.info('Probing done.')
+    return best_model, best_head, best_records, best_logit_scale, val_loader, test_loader

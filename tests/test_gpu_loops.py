@@ -96,3 +96,28 @@ def test_validate_on_pre_extracted_features_matches_reference(golden_dir):
     assert acc == rec["acc"]                       # fp32 head on exact inputs: identical predictions
     assert np.array_equal(cm, np.array(rec["cm"]))
     assert abs(loss - rec["loss"]) < 1e-4
+
+
+def test_cli_end_to_end_on_synthetic_data(tmp_path, monkeypatch):
+    """main.py: stage 1 (cutmix) -> WiSE-FT -> feature re-extraction -> tau-norm -> checkpoint -> stage-2 probing + FSFT,
+    on a tiny synthetic dataset (ViT-B/32 weights random): the whole pipeline runs on the HIP path and prints the CSV line."""
+    import sys
+    monkeypatch.chdir(tmp_path)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import main as cli
+    summary = cli.main(["--synthetic", "96", "--num_classes", "5", "--method", "cutmix", "--epochs", "1", "--bsz", "16",
+                        "--num_workers", "0", "--log_mode", "file", "--shots", "4", "--folder", str(tmp_path / "out")])
+    parts = summary.split(",")
+    assert parts[0] == "synthetic" and parts[1] == "cutmix" and len(parts) == 11
+    accs = [float(v) for v in parts[7:]]
+    assert all(0.0 <= a <= 100.0 for a in accs)
+    import glob
+    csvs = glob.glob(str(tmp_path / "out" / "**" / "loss.csv"), recursive=True)
+    assert len(csvs) == 1
+    case_dir = os.path.dirname(csvs[0])
+    files = os.listdir(case_dir)
+    assert any(f.startswith("stage1_model_best") for f in files)
+    out, case = type(tmp_path)(case_dir).parent, os.path.basename(case_dir)
+    ck = torch.load(out / case / [f for f in files if f.startswith("stage1_model_best")][0], map_location="cpu", weights_only=False)
+    assert {"clip", "head", "logit_scale", "test_acc", "best_tau", "wsft_test_acc", "wsft_backbone"} <= set(ck.keys())
+    assert "visual.transformer.resblocks.11.mlp.c_proj.weight" in ck["clip"]

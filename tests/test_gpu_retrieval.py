@@ -190,3 +190,40 @@ def test_near_dup_matches_reference_golden(golden_dir, kind):
     rows = np.array(sorted(path_to_row[p] for c in dups for p in dups[c]), np.int64)
     assert np.array_equal(rows, g["dedup_rows"])
     assert np.allclose(fracs, g["dedup_frac"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["grid", "float"])
+@pytest.mark.parametrize("method,name", [("T2T-rank", "t2t"), ("T2T-rank-T2I-tshd", "t2t_t2i"), ("T2I-rank", "t2i")])
+def test_sampling_driver_writes_reference_bytes(golden_dir, tmp_path, kind, method, name):
+    """sampling() with the reference's plug-in signature: `<prefix>.txt` bytes, per-class counts and the returned
+    mined_split equal what the reference's own samplers + save_sample_file_list produced."""
+    import types
+    from collections import defaultdict
+    from swat_amd.retrieval import samplers
+    g, spec, case = _load(golden_dir, kind)
+    mined = {"image_features": torch.from_numpy(case["img"]), "caption_features": torch.from_numpy(case["cap"]),
+             "labels": torch.from_numpy(case["labels"]), "filepath": case["paths"]}
+    prompt_tensors = {str(c): {"mean": torch.from_numpy(case["queries"][i])} for i, c in enumerate(case["class_ids"])}
+    dup, filt = defaultdict(set), defaultdict(set)
+    for p, e in zip(case["paths"], case["excl_dup"]):
+        if e:
+            dup[p.split("/")[-2]].add(p)
+    for p, e in zip(case["paths"], case["excl_filt"]):
+        if e:
+            filt[p.split("/")[-2]].add(p)
+
+    class Lg:
+        def info(self, *a):
+            pass
+
+    args = types.SimpleNamespace(output_folder=str(tmp_path), prefix="golden", sampling_method=method, num_samples=spec["k"])
+    index = samplers.transform_extracted_fea(mined)
+    split, counts = samplers.SAMPLERS[method](args, Lg(), prompt_tensors, spec["k"], 0.0, index, dup, filt)
+    files = [p for fl in split["file_list"] for p in fl]
+    labels = torch.cat(split["label_list"])
+    samplers.save_sample_file_list(args, files, labels)
+    assert open(tmp_path / "golden.txt").read() == str(g[f"{name}_txt"])
+    assert {c: n for c, n in counts.items()} == json.loads(str(g[f"{name}_counts"]))
+    path_to_row = {p: i for i, p in enumerate(case["paths"])}
+    rows = np.array([path_to_row[p] for p in files], np.int64)
+    assert torch.equal(torch.cat(split["feature_list"]), torch.from_numpy(case["img"][rows]))

@@ -104,12 +104,13 @@ int swat_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma,
                        float eps, swat_stream_t stream);
 int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d);
 /*     dx_out = (dx_add ? dx_add : 0) + LN'(dy); optional bf16 copy; dgamma/dbeta reduced in a fixed
- *     order through `workspace` (deterministic). */
+ *     order through `workspace` (deterministic).  dcolsum (optional) = column sums of the bf16 output = the bias
+ *     gradient of the linear layer whose output stream this is (saves a separate pass over dx). */
 int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float* x, int64_t x_stride,
                        const float* gamma, const float* mean, const float* rstd, const float* dx_add,
                        int64_t dxa_stride, float* dx_out, int64_t dxo_stride, void* dx_bf16,
-                       int64_t dxb_stride, float* dgamma, float* dbeta, void* workspace, int rows,
-                       int d, swat_stream_t stream);
+                       int64_t dxb_stride, float* dgamma, float* dbeta, float* dcolsum, void* workspace,
+                       int rows, int d, swat_stream_t stream);
 
 /* A2d  attention softmax over score rows (fp32 S, ld = padded T): P = softmax(scale*S[:, :T]) bf16,
  *     pad columns zeroed; causal!=0 for the text tower.  Backward: dS = scale*P o (dP - rowsum(P o dP)). */

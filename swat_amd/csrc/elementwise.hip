@@ -77,14 +77,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
                                                      unsigned short* __restrict__ dx_bf, int64_t dxb_stride,
                                                      float* __restrict__ part, int rows, int d) {
-    __shared__ float sh[2][4][64 * 4 * LN_MAXV];  // [dg/db][wave][d]
+    __shared__ float sh[3][4][64 * 4 * LN_MAXV];  // [dgamma / dbeta / colsum(dx_bf16)][wave][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
-    float4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+    float4 dg[LN_MAXV], db[LN_MAXV], dcs[LN_MAXV], gm[LN_MAXV];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[i] = dg[i];
+        dcs[i] = dg[i];
         const int c = lane + 64 * i;
         gm[i] = c < nv ? reinterpret_cast<const float4*>(gamma)[c] : dg[i];
     }
@@ -124,8 +125,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
                 }
                 if (dx_out) reinterpret_cast<float4*>(dx_out + (int64_t)row * dxo_stride)[c] = o;
-                if (dx_bf)
-                    reinterpret_cast<ushort4*>(dx_bf + (int64_t)row * dxb_stride)[c] = make_ushort4(f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w));
+                if (dx_bf) {
+                    const ushort4 ob = make_ushort4(f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w));
+                    reinterpret_cast<ushort4*>(dx_bf + (int64_t)row * dxb_stride)[c] = ob;
+                    // column sums of the ROUNDED output = bias gradient of the linear layer that produced this stream
+                    dcs[i].x += bf2f(ob.x); dcs[i].y += bf2f(ob.y); dcs[i].z += bf2f(ob.z); dcs[i].w += bf2f(ob.w);
+                }
             }
         }
     }
@@ -135,35 +140,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         if (c < nv) {
             reinterpret_cast<float4*>(sh[0][wave])[c] = dg[i];
             reinterpret_cast<float4*>(sh[1][wave])[c] = db[i];
+            reinterpret_cast<float4*>(sh[2][wave])[c] = dcs[i];
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += 256) {
-        part[((int64_t)blockIdx.x * 2 + 0) * d + c] = ((sh[0][0][c] + sh[0][1][c]) + sh[0][2][c]) + sh[0][3][c];
-        part[((int64_t)blockIdx.x * 2 + 1) * d + c] = ((sh[1][0][c] + sh[1][1][c]) + sh[1][2][c]) + sh[1][3][c];
+        part[((int64_t)blockIdx.x * 3 + 0) * d + c] = ((sh[0][0][c] + sh[0][1][c]) + sh[0][2][c]) + sh[0][3][c];
+        part[((int64_t)blockIdx.x * 3 + 1) * d + c] = ((sh[1][0][c] + sh[1][1][c]) + sh[1][2][c]) + sh[1][3][c];
+        part[((int64_t)blockIdx.x * 3 + 2) * d + c] = ((sh[2][0][c] + sh[2][1][c]) + sh[2][2][c]) + sh[2][3][c];
     }
 }
 
 // block = 64 columns x 4 partial-lanes; lane j sums partials j, j+4, ... then the 4 lanes combine in a fixed order
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int d,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float sh[2][4][64];
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dcolsum) {
+    __shared__ float sh[3][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int j = threadIdx.x >> 6;
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, e = 0.f;
     if (c < d) {
         for (int i = j; i < nblk; i += 4) {
-            a += part[((int64_t)i * 2 + 0) * d + c];
-            b += part[((int64_t)i * 2 + 1) * d + c];
+            a += part[((int64_t)i * 3 + 0) * d + c];
+            b += part[((int64_t)i * 3 + 1) * d + c];
+            e += part[((int64_t)i * 3 + 2) * d + c];
         }
     }
     sh[0][j][threadIdx.x & 63] = a;
     sh[1][j][threadIdx.x & 63] = b;
+    sh[2][j][threadIdx.x & 63] = e;
     __syncthreads();
     if (j == 0 && c < d) {
         const int t = threadIdx.x;
         dgamma[c] = ((sh[0][0][t] + sh[0][1][t]) + sh[0][2][t]) + sh[0][3][t];
         dbeta[c] = ((sh[1][0][t] + sh[1][1][t]) + sh[1][2][t]) + sh[1][3][t];
+        if (dcolsum) dcolsum[c] = ((sh[2][0][t] + sh[2][1][t]) + sh[2][2][t]) + sh[2][3][t];
     }
 }
 
@@ -426,13 +437,13 @@ SWAT_API int swat_layernorm_fwd(const float* x, int64_t x_row_stride, const floa
 
 SWAT_API int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d) {
     (void)rows;
-    return (int64_t)256 * 2 * d * sizeof(float);
+    return (int64_t)256 * 3 * d * sizeof(float);
 }
 
 SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float* x, int64_t x_stride, const float* gamma,
                                 const float* mean, const float* rstd, const float* dx_add, int64_t dxa_stride,
                                 float* dx_out, int64_t dxo_stride, void* dx_bf16, int64_t dxb_stride, float* dgamma,
-                                float* dbeta, void* workspace, int rows, int d, swat_stream_t s) {
+                                float* dbeta, float* dcolsum, void* workspace, int rows, int d, swat_stream_t s) {
     SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV, "swat_layernorm_bwd: d=%d unsupported", d);
     if (rows <= 0) return 0;
     int nblk = (rows + 3) / 4;
@@ -440,7 +451,7 @@ SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float*
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
                        dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d);
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)s, (const float*)workspace,
-                       nblk, d, dgamma, dbeta);
+                       nblk, d, dgamma, dbeta, dcolsum);
     return check_launch("swat_layernorm_bwd");
 }
 

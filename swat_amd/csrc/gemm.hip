@@ -517,16 +517,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmArg
 // first version issuing ~95 VALU + 60 SALU per 8 MFMAs (SQ_ACTIVE_INST_ANY 38 %, MFMA busy 17 %): the loop was
 // bound by its own address arithmetic, not by memory, LDS or the matrix pipe.
 // --------------------------------------------------------------------------------------------
-template <int LAYOUT, int BM, int BN, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
+template <int LAYOUT, int BM, int BN, int NSTAGE, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmArgs p) {
+    constexpr int NW = WGM * WGN;
     constexpr bool A_KC = (LAYOUT != L_TN);
     constexpr bool B_KC = (LAYOUT == L_NT);
     constexpr int BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INS = A_BYTES / 1024 / 4, B_INS = B_BYTES / 1024 / 4;
+    constexpr int A_INS = A_BYTES / 1024 / NW, B_INS = B_BYTES / 1024 / NW;
+    static_assert(A_INS >= 1 && B_INS >= 1, "tile too small for this many waves");
     constexpr int LPS = A_INS + B_INS;
     constexpr int NA = A_KC ? 1 : 2, NB = B_KC ? 1 : 2;  // LDS reads per fragment
 
@@ -535,8 +537,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * WM;
-    const int wn0 = (wave & 1) * WN;
+    const int wm0 = (wave / WGN) * WM;
+    const int wn0 = (wave % WGN) * WN;
     int bx, by;
     tile_coords(p, bx, by);
     const int m0 = by * BM;
@@ -564,9 +566,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
     };
     unsigned offA[A_INS], offB[B_INS];
 #pragma unroll
-    for (int i = 0; i < A_INS; ++i) offA[i] = src_off(A_KC, wave + 4 * i, m0, M, p.lda, BM);
+    for (int i = 0; i < A_INS; ++i) offA[i] = src_off(A_KC, wave + NW * i, m0, M, p.lda, BM);
 #pragma unroll
-    for (int i = 0; i < B_INS; ++i) offB[i] = src_off(B_KC, wave + 4 * i, n0, N, p.ldb, BN);
+    for (int i = 0; i < B_INS; ++i) offB[i] = src_off(B_KC, wave + NW * i, n0, N, p.ldb, BN);
     // wave-uniform base pointers of step 0 (k-contiguous: first row of the tile; strided: row 0, column 0)
     const char* gA = reinterpret_cast<const char*>(p.A + zo * p.sA0 + zi * p.sA1 + (A_KC ? (int64_t)m0 * p.lda : 0));
     const char* gB = reinterpret_cast<const char*>(p.B + zo * p.sB0 + zi * p.sB1 + (B_KC ? (int64_t)n0 * p.ldb : 0));
@@ -611,11 +613,11 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < A_INS; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + offA[i]),
-                                             (__attribute__((address_space(3))) void*)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sa + (wave + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < B_INS; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + offB[i]),
-                                             (__attribute__((address_space(3))) void*)(sb + (wave + 4 * i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sb + (wave + NW * i) * 1024), 16, 0, 0);
     };
 
     f32x4_t acc[FM][FN];
@@ -907,12 +909,19 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
         hipLaunchKernelGGL((gemm_ring2_kernel<LAYOUT, BM_, BN_, D_>), grid, dim3(256), 0, s, b);          \
     }
+#define SWAT_DMA8(BM_, BN_, NS_, WGM_, WGN_)                                                              \
+    {                                                                                                     \
+        GemmArgs b = a;                                                                                   \
+        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
+        hipLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, b); \
+    }
 #define SWAT_GLDS8(BM_, BN_, NS_, WGM_, WGN_)                                                             \
     {                                                                                                     \
         GemmArgs b = a;                                                                                   \
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
         hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, b); \
     }
+    if (cfg >= 25 && cfg <= 28 && a.K % 64 != 0) cfg = 20;
     if (cfg >= 30 && (a.K % 64 != 0 || a.K < 64 * 6)) cfg = 20;  // lean ring needs whole, >= D k-steps
     if (cfg >= 6 && cfg < 20 && a.K % 64 != 0) cfg = (cfg == 6 || (cfg >= 10 && cfg != 14 && cfg != 17 && cfg != 18 && cfg != 19)) ? 1 : (cfg == 8 ? 2 : 0);  // the LDS-DMA kernel has no K tail
     switch (cfg) {
@@ -934,6 +943,10 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
         case 18: SWAT_DMA(64, 64, 6) break;
         case 19: SWAT_DMA(64, 64, 8) break;
         case 20: SWAT_RING(64, 64, 4) break;
+        case 25: SWAT_DMA8(128, 128, 3, 2, 4) break;
+        case 26: SWAT_DMA8(128, 128, 4, 2, 4) break;
+        case 27: SWAT_DMA8(128, 64, 4, 4, 2) break;
+        case 28: SWAT_DMA8(256, 128, 2, 4, 2) break;
         case 30: SWAT_RING2(64, 64, 4) break;
         case 31: SWAT_RING2(64, 64, 2) break;
         case 32: SWAT_RING2(128, 64, 4) break;
@@ -951,6 +964,7 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
 #undef SWAT_RING
 #undef SWAT_RING2
 #undef SWAT_DMA
+#undef SWAT_DMA8
     return check_launch("swat_gemm_bf16");
 }
 
@@ -989,7 +1003,7 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     else rc = launch_gemm<L_TN>(a, batch, tile, s);
     if (prof) {
         hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
-        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || (tile >= 10 && tile < 14) || tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33);
+        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || (tile >= 10 && tile < 14) || tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28));
         g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
         ++g_prof.n;
     }

@@ -303,7 +303,8 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             hipMemsetAsync(w.dxb, 0, (size_t)M * d * 2, s);
             const float* xl = w.xs + (int64_t)D.L * M * d;
             TRY(swat_layernorm_bwd(w.du, d, xl, (int64_t)T * d, params + O.lnpost_w, w.mean_post, w.rstd_post, nullptr, 0, w.dx,
-                                   (int64_t)T * d, w.dxb, (int64_t)T * d, grads + O.lnpost_w, grads + O.lnpost_b, w.lnws, D.B, d, s));
+                                   (int64_t)T * d, w.dxb, (int64_t)T * d, grads + O.lnpost_w, grads + O.lnpost_b,
+                                   grads + (O.layer + 12 * (D.L - 1))[PRB], w.lnws, D.B, d, s));
         } else if (stage >= 1) {
             const int l = stage - 1;
             const int64_t* lo = O.layer + 12 * l;
@@ -318,7 +319,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             const unsigned short* ga = w.gact + (int64_t)l * M * mlp;
             // c_proj: dW = dx^T g, db = colsum(dx), dF = (dx W) * act'(F)
             TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, M, d, mlp, mlp, 1), 1, s));
-            TRY(swat_colsum_bf16(w.dxb, M, d, d, grads + lo[PRB], w.csws, s));
+            // (c_proj bias gradient = column sums of dx: produced by the LayerNorm backward that wrote dx)
             {
                 GemmArgs a = G(w.dxb, sh + lo[PRW], w.dfb, M, mlp, d, d, mlp, mlp, 0);
                 a.actin = f; a.ldact = mlp; a.act = D.act;
@@ -330,10 +331,10 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(gemm_dispatch(L_NN, G(w.dfb, sh + lo[FCW], w.dh, M, d, mlp, mlp, d, d, 1), 1, s));
             // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
             TRY(swat_layernorm_bwd(w.dh, d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
-                                   w.dx, d, w.dxb, d, grads + lo[LN2W], grads + lo[LN2B], w.lnws, M, d, s));
+                                   w.dx, d, w.dxb, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], w.lnws, M, d, s));
             // out_proj: dW = dx1^T a, db = colsum(dx1), da = dx1 W
             TRY(gemm_dispatch(L_TN, G(w.dxb, at, grads + lo[OUTW], d, d, M, d, d, d, 1), 1, s));
-            TRY(swat_colsum_bf16(w.dxb, M, d, d, grads + lo[OUTB], w.csws, s));
+            // (out_proj bias gradient: produced by the ln_2 backward above)
             TRY(gemm_dispatch(L_NN, G(w.dxb, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
             // attention backward -> dqkv
             TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s));
@@ -343,11 +344,12 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(gemm_dispatch(L_NN, G(w.dqkv, sh + lo[QKVW], w.dh, M, d, 3 * d, 3 * d, d, d, 1), 1, s));
             // ln_1 backward: dx0 = dx1 + LN'(dh1)
             TRY(swat_layernorm_bwd(w.dh, d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
-                                   w.dx, d, w.dxb, d, grads + lo[LN1W], grads + lo[LN1B], w.lnws, M, d, s));
+                                   w.dx, d, w.dxb, d, grads + lo[LN1W], grads + lo[LN1B],
+                                   l > 0 ? grads + (O.layer + 12 * (l - 1))[PRB] : nullptr, w.lnws, M, d, s));
         } else {
             // stem: ln_pre backward, positional / class embedding, conv1 weight
             TRY(swat_layernorm_bwd(w.dx, d, w.xpre, d, params + O.lnpre_w, w.mean_pre, w.rstd_pre, nullptr, 0, w.dh, d, nullptr, 0,
-                                   grads + O.lnpre_w, grads + O.lnpre_b, w.lnws, M, d, s));
+                                   grads + O.lnpre_w, grads + O.lnpre_b, nullptr, w.lnws, M, d, s));
             TRY(swat_colsum(w.dh, SWAT_F32, D.B, T * d, T * d, grads + O.pos, 0, 0, 0, s));  // dpos[t,:] = sum_b
             TRY(swat_colsum(w.dh, SWAT_F32, D.B, d, T * d, grads + O.cls, 0, 0, 0, s));      // dcls = sum_b row 0
             TRY(swat_gather_cast_bf16(w.dh, w.dxb, np, d, D.g * D.g, T, 1, s));              // drop the cls rows

@@ -73,7 +73,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, rows=None, row_stride=None, out_bf16
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx_add=None, want_bf16=False, rows=None, dy_stride=None, x_stride=None,
-                  dx_out=None, dxo_stride=None, dxa_stride=None):
+                  dx_out=None, dxo_stride=None, dxa_stride=None, want_colsum=False):
     d = gamma.numel()
     if rows is None:
         rows = dy.numel() // d
@@ -86,11 +86,14 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx_add=None, want_bf16=False, rows=N
     dx_bf = torch.empty((rows, d), dtype=_BF, device=dev) if want_bf16 else None
     dg = torch.empty(d, dtype=_F32, device=dev)
     db = torch.empty(d, dtype=_F32, device=dev)
+    dcs = torch.empty(d, dtype=_F32, device=dev) if want_bf16 else None
     ws = torch.empty(_lib.lib().swat_layernorm_bwd_workspace_bytes(rows, d), dtype=torch.uint8, device=dev)
     rc = _lib.lib().swat_layernorm_bwd(_p(dy), dy_stride, _p(x), x_stride, _p(gamma), _p(mean), _p(rstd), _p(dx_add),
-                                       dxa_stride or d, _p(dx_out), dxo_stride, _p(dx_bf), d, _p(dg), _p(db), _p(ws),
+                                       dxa_stride or d, _p(dx_out), dxo_stride, _p(dx_bf), d, _p(dg), _p(db), _p(dcs), _p(ws),
                                        rows, d, _lib.stream())
     _chk(rc, "swat_layernorm_bwd")
+    if want_colsum:
+        return dx_out, dx_bf, dg, db, dcs
     return dx_out, dx_bf, dg, db
 
 

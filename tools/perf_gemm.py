@@ -12,7 +12,7 @@ shapes = [  # (name, layout, M, N, K)  in the kernel's own (rows, cols, reductio
     ("wgrad proj", ops.TN, d, 4 * d, M), ("wgrad fc", ops.TN, 4 * d, d, M), ("wgrad out", ops.TN, d, d, M), ("wgrad qkv", ops.TN, 3 * d, d, M),
     ("patch", ops.NT, 1568, d, 3072), ("wgrad conv", ops.TN, d, 3072, 1568),
 ]
-cfgs = {14: "d64x64s3", 30: "R64x64d4", 31: "R64x64d2", 34: "R64x64d6", 32: "R128x64d4", 33: "R128sqd2"}
+cfgs = {14: "d64x64s3", 16: "d128x64s3", 25: "D128sq8w s3", 26: "D128sq8w s4", 27: "D128x64 8w", 28: "D256x128 8w", 30: "R64x64d4"}
 print(f"{'shape':18s} " + " ".join(f"{v:>11s}" for v in cfgs.values()) + "   (TFLOP/s)")
 for name, layout, m, n, k in shapes:
     if layout == ops.NT:

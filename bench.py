@@ -86,8 +86,15 @@ def gemm_roofline(args, step, sched, images, labels, n_steps, bsz):
     achieved = algo_flops / (total_ms * 1e-3) / 1e12
     per_kind = {names[i]: {"launches_per_step": cnt[i] / n_steps, "avg_us": (1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0,
                            "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0} for i in range(6)}
-    return {"bound": "mfma", "kernel": "gemm_bf16_kernel<layout,tile> (all instantiations)", "achieved": round(achieved, 2),
-            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+    if os.path.exists(tpath):  # PMC passes cannot run inside this process: the committed rocprofv3 --pmc result of this command
+        traffic = round(json.load(open(tpath))["hbm_bytes_per_gemm_launch"])
+        traffic_src = "profiles/r01_gemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per GEMM launch)"
+    return {"bound": "mfma", "kernel": "gemm_dma_kernel / gemm_ring2_kernel / gemm_ring_kernel (all GEMM instantiations)",
+            "achieved": round(achieved, 2),
+            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(algo_flops / (n / n_steps)),
             "gemm_ms_per_step": round(total_ms, 4), "gemm_launches_per_step": n / n_steps,
             "algorithmic_gflop_per_step": round(algo_flops / 1e9, 1), "per_instantiation": per_kind}
 

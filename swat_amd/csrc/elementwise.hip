@@ -151,16 +151,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// block = 64 columns x 4 partial-lanes; lane j sums partials j, j+4, ... then the 4 lanes combine in a fixed order
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int d,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ dcolsum) {
-    __shared__ float sh[3][4][64];
+// block = 64 columns x 16 partial-lanes (1024 threads); lane j sums partials j, j+16, ... then the 16 lanes combine in
+// lane order -> deterministic
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int d,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ dcolsum) {
+    __shared__ float sh[3][16][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int j = threadIdx.x >> 6;
     float a = 0.f, b = 0.f, e = 0.f;
     if (c < d) {
-        for (int i = j; i < nblk; i += 4) {
+        for (int i = j; i < nblk; i += 16) {
             a += part[((int64_t)i * 3 + 0) * d + c];
             b += part[((int64_t)i * 3 + 1) * d + c];
             e += part[((int64_t)i * 3 + 2) * d + c];
@@ -170,11 +171,14 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     sh[1][j][threadIdx.x & 63] = b;
     sh[2][j][threadIdx.x & 63] = e;
     __syncthreads();
-    if (j == 0 && c < d) {
-        const int t = threadIdx.x;
-        dgamma[c] = ((sh[0][0][t] + sh[0][1][t]) + sh[0][2][t]) + sh[0][3][t];
-        dbeta[c] = ((sh[1][0][t] + sh[1][1][t]) + sh[1][2][t]) + sh[1][3][t];
-        if (dcolsum) dcolsum[c] = ((sh[2][0][t] + sh[2][1][t]) + sh[2][2][t]) + sh[2][3][t];
+    if (j < 3 && c < d) {
+        const int t = threadIdx.x & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += sh[j][q][t];
+        if (j == 0) dgamma[c] = v;
+        else if (j == 1) dbeta[c] = v;
+        else if (dcolsum) dcolsum[c] = v;
     }
 }
 
@@ -447,10 +451,10 @@ SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float*
     SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV, "swat_layernorm_bwd: d=%d unsupported", d);
     if (rows <= 0) return 0;
     int nblk = (rows + 3) / 4;
-    if (nblk > 64) nblk = 64;  // 256 waves walk the rows; few partials keep the fixed-order reduce short
+    if (nblk > 256) nblk = 256;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
                        dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d);
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)s, (const float*)workspace,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 63) / 64), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
     return check_launch("swat_layernorm_bwd");
 }

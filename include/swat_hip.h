@@ -112,6 +112,14 @@ int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float* x, int64
                        int64_t dxb_stride, float* dgamma, float* dbeta, float* dcolsum, void* workspace,
                        int rows, int d, swat_stream_t stream);
 
+/*     same, with dy given as `nsplit` partial planes (split_stride floats apart) that are summed on the fly: the
+ *     split-K dgrad GEMM that feeds it writes partial sums instead of paying a reduction pass. */
+int swat_layernorm_bwd_split(const float* dy, int64_t dy_stride, int nsplit, int64_t split_stride, const float* x,
+                             int64_t x_stride, const float* gamma, const float* mean, const float* rstd,
+                             const float* dx_add, int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
+                             void* dx_bf16, int64_t dxb_stride, float* dgamma, float* dbeta, float* dcolsum,
+                             void* workspace, int rows, int d, swat_stream_t stream);
+
 /* A2d  attention softmax over score rows (fp32 S, ld = padded T): P = softmax(scale*S[:, :T]) bf16,
  *     pad columns zeroed; causal!=0 for the text tower.  Backward: dS = scale*P o (dP - rowsum(P o dP)). */
 int swat_softmax_fwd(const float* S, void* P_bf16, int64_t rows, int Tq, int T, int ld, float scale,

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ rstd, const float* dx_add,
                                                      int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
                                                      unsigned short* __restrict__ dx_bf, int64_t dxb_stride,
-                                                     float* __restrict__ part, int rows, int d) {
+                                                     float* __restrict__ part, int rows, int d, int nsplit,
+                                                     int64_t split_stride) {
     __shared__ float sh[3][4][64 * 4 * LN_MAXV];  // [dgamma / dbeta / colsum(dx_bf16)][wave][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -100,6 +101,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             const int c = lane + 64 * i;
             if (c < nv) {
                 dyv[i] = dyr[c];
+                for (int sp = 1; sp < nsplit; ++sp) {  // split-K partial planes of the producing dgrad GEMM, fixed order
+                    const float4 t = reinterpret_cast<const float4*>(dy + sp * split_stride + (int64_t)row * dy_stride)[c];
+                    dyv[i].x += t.x; dyv[i].y += t.y; dyv[i].z += t.z; dyv[i].w += t.w;
+                }
                 const float4 xv = xr[c];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 const float a0 = dyv[i].x * gm[i].x, a1 = dyv[i].y * gm[i].y, a2 = dyv[i].z * gm[i].z, a3 = dyv[i].w * gm[i].w;
@@ -453,10 +458,27 @@ SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float*
     int nblk = (rows + 3) / 4;
     if (nblk > 256) nblk = 256;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
-                       dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d);
+                       dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d, 1, 0);
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 63) / 64), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
     return check_launch("swat_layernorm_bwd");
+}
+
+SWAT_API int swat_layernorm_bwd_split(const float* dy, int64_t dy_stride, int nsplit, int64_t split_stride, const float* x,
+                                      int64_t x_stride, const float* gamma, const float* mean, const float* rstd,
+                                      const float* dx_add, int64_t dxa_stride, float* dx_out, int64_t dxo_stride, void* dx_bf16,
+                                      int64_t dxb_stride, float* dgamma, float* dbeta, float* dcolsum, void* workspace, int rows,
+                                      int d, swat_stream_t s) {
+    SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && nsplit >= 1, "swat_layernorm_bwd_split: bad arguments");
+    if (rows <= 0) return 0;
+    int nblk = (rows + 3) / 4;
+    if (nblk > 256) nblk = 256;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
+                       dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d,
+                       nsplit, split_stride);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 63) / 64), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
+                       nblk, d, dgamma, dbeta, dcolsum);
+    return check_launch("swat_layernorm_bwd_split");
 }
 
 SWAT_API int swat_softmax_fwd(const float* S, void* P_bf16, int64_t rows, int Tq, int T, int ld, float scale, int causal,

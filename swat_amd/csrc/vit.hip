@@ -110,7 +110,7 @@ static VitWs carve(const VitDims& D, void* base) {
         w.dS = (unsigned short*)take(pbytes * 2);
         w.dx = (float*)take(M * d * 4);
         w.dxb = (unsigned short*)take(M * d * 2);
-        w.dh = (float*)take(M * d * 4);
+        w.dh = (float*)take(4 * M * d * 4);  // up to 4 split-K partial planes of the dgrad that feeds a LayerNorm backward
         w.dfb = (unsigned short*)take(M * D.mlp * 2);
         w.dab = (unsigned short*)take(M * d * 2);
         w.dqkv = (unsigned short*)take(M * 3 * d * 2);
@@ -189,6 +189,22 @@ __global__ void embed_tokens_kernel(const int64_t* __restrict__ tok, const float
         const float4 q = reinterpret_cast<const float4*>(pos + (r % T) * d)[c];
         reinterpret_cast<float4*>(out + r * d)[c] = make_float4(e.x + q.x, e.y + q.y, e.z + q.z, e.w + q.w);
     }
+}
+
+// dX = dY W with the reduction split over `S` batched launches writing S partial planes (summed by the consumer): the
+// N = d dgrads of the step are ~300 blocks of 64x64 — 1.2 per CU — and 36-48 k-steps deep; splitting K fills the chip.
+static int dgrad_split(const VitDims& D, const unsigned short* dY, int Kred, const unsigned short* W, float* planes, int& S,
+                       hipStream_t s) {
+    const int M = D.M, d = D.d;
+    S = 1;
+    const int64_t base_blocks = (int64_t)((M + 63) / 64) * ((d + 63) / 64);
+    if (base_blocks < 600) {
+        for (int cand = 4; cand >= 2; --cand)
+            if (Kred % cand == 0 && (Kred / cand) % 64 == 0 && Kred / cand >= 512) { S = cand; break; }
+    }
+    GemmArgs a = G(dY, W, planes, M, d, Kred / S, Kred, d, d, 1);
+    a.inner = S; a.sA1 = Kred / S; a.sB1 = (int64_t)(Kred / S) * d; a.sC1 = (int64_t)M * d;
+    return gemm_dispatch(L_NN, a, S, s);
 }
 
 }  // namespace swat
@@ -328,9 +344,10 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             // c_fc: dW = dF^T h2, db = colsum(dF), dh2 = dF W
             TRY(gemm_dispatch(L_TN, G(w.dfb, h2, grads + lo[FCW], mlp, d, M, mlp, d, d, 1), 1, s));
             TRY(swat_colsum_bf16(w.dfb, M, mlp, mlp, grads + lo[FCB], w.csws, s));
-            TRY(gemm_dispatch(L_NN, G(w.dfb, sh + lo[FCW], w.dh, M, d, mlp, mlp, d, d, 1), 1, s));
+            int S2 = 1;
+            TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
             // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
-            TRY(swat_layernorm_bwd(w.dh, d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
+            TRY(swat_layernorm_bwd_split(w.dh, d, S2, (int64_t)M * d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
                                    w.dx, d, w.dxb, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], w.lnws, M, d, s));
             // out_proj: dW = dx1^T a, db = colsum(dx1), da = dx1 W
             TRY(gemm_dispatch(L_TN, G(w.dxb, at, grads + lo[OUTW], d, d, M, d, d, d, 1), 1, s));
@@ -341,9 +358,10 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             // in_proj: dW = dqkv^T h1, db = colsum(dqkv), dh1 = dqkv W
             TRY(gemm_dispatch(L_TN, G(w.dqkv, h1, grads + lo[QKVW], 3 * d, d, M, 3 * d, d, d, 1), 1, s));
             TRY(swat_colsum_bf16(w.dqkv, M, 3 * d, 3 * d, grads + lo[QKVB], w.csws, s));
-            TRY(gemm_dispatch(L_NN, G(w.dqkv, sh + lo[QKVW], w.dh, M, d, 3 * d, 3 * d, d, d, 1), 1, s));
+            int S1 = 1;
+            TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));
             // ln_1 backward: dx0 = dx1 + LN'(dh1)
-            TRY(swat_layernorm_bwd(w.dh, d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
+            TRY(swat_layernorm_bwd_split(w.dh, d, S1, (int64_t)M * d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
                                    w.dx, d, w.dxb, d, grads + lo[LN1W], grads + lo[LN1B],
                                    l > 0 ? grads + (O.layer + 12 * (l - 1))[PRB] : nullptr, w.lnws, M, d, s));
         } else {

@@ -102,6 +102,11 @@ int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops
 int swat_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
                        void* y_bf16, float* y_f32, float* mean, float* rstd, int rows, int d,
                        float eps, swat_stream_t stream);
+/*     same, with x given as `nsplit` split-K partial planes (plane 0 carries bias + residual): sums them in plane order,
+ *     writes the materialised x to x_sum_out (same row stride) and normalises it. */
+int swat_layernorm_fwd_split(const float* x_planes, int64_t x_row_stride, int nsplit, int64_t split_stride,
+                             float* x_sum_out, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                             float* mean, float* rstd, int rows, int d, float eps, swat_stream_t stream);
 int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d);
 /*     dx_out = (dx_add ? dx_add : 0) + LN'(dy); optional bf16 copy; dgamma/dbeta reduced in a fixed
  *     order through `workspace` (deterministic).  dcolsum (optional) = column sums of the bf16 output = the bias

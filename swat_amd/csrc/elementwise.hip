@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      unsigned short* __restrict__ y_bf, float* __restrict__ y_f32,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int d,
-                                                     float eps) {
+                                                     float eps, int nsplit, int64_t split_stride, float* __restrict__ x_sum_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -30,6 +30,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + 64 * i;
         v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nsplit > 1 && c < nv) {  // split-K partial planes of the GEMM that produced x: sum in plane order, materialise
+            for (int sp = 1; sp < nsplit; ++sp) {
+                const float4 t = reinterpret_cast<const float4*>(x + sp * split_stride + (int64_t)row * x_row_stride)[c];
+                v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+            }
+            reinterpret_cast<float4*>(x_sum_out + (int64_t)row * x_row_stride)[c] = v[i];
+        }
         s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     const float mu = wave_sum(s) / (float)d;
@@ -440,8 +447,18 @@ SWAT_API int swat_layernorm_fwd(const float* x, int64_t x_row_stride, const floa
     SWAT_REQUIRE(x_row_stride % 4 == 0, "swat_layernorm_fwd: row stride must be a multiple of 4");
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, x, x_row_stride, gamma, beta,
-                       (unsigned short*)y_bf16, y_f32, mean, rstd, rows, d, eps);
+                       (unsigned short*)y_bf16, y_f32, mean, rstd, rows, d, eps, 1, 0, nullptr);
     return check_launch("swat_layernorm_fwd");
+}
+
+SWAT_API int swat_layernorm_fwd_split(const float* x_planes, int64_t x_row_stride, int nsplit, int64_t split_stride,
+                                      float* x_sum_out, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                                      float* mean, float* rstd, int rows, int d, float eps, swat_stream_t s) {
+    SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && nsplit >= 1 && (nsplit == 1 || x_sum_out), "swat_layernorm_fwd_split: bad arguments");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, x_planes, x_row_stride, gamma, beta,
+                       (unsigned short*)y_bf16, y_f32, mean, rstd, rows, d, eps, nsplit, split_stride, x_sum_out);
+    return check_launch("swat_layernorm_fwd_split");
 }
 
 SWAT_API int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d) {

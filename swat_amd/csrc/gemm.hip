@@ -113,16 +113,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
-            if (p.bias) {
+            const bool full_epi = !(p.epi0 && zi != 0);
+            if (p.bias && full_epi) {
                 const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
                 v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
             }
-            if (p.rowbias) {
+            if (p.rowbias && full_epi) {
                 const float4 b4 = *reinterpret_cast<const float4*>(p.rowbias + (int64_t)brow * N + n);
                 v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
             }
             const int64_t o = coff + (int64_t)orow * p.ldc + n;
-            if (p.residual) {
+            if (p.residual && full_epi) {
                 const float4 r4 = *reinterpret_cast<const float4*>(p.residual + o);
                 v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             }

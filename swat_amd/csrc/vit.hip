@@ -64,6 +64,7 @@ struct VitWs {
     float *mean1, *rstd1, *mean2, *rstd2;  // L x [M]
     // scratch
     float* S;                 // [B*H,T,ldp] scores / dP
+    float* xsplit;            // 4 x [M,d] forward split-K planes
     unsigned short* dS;       // [B*H,T,ldp]
     float* dx;                // [M,d] residual-stream gradient
     unsigned short* dxb;      // [M,d] its bf16 copy
@@ -106,6 +107,7 @@ static VitWs carve(const VitDims& D, void* base) {
     w.mean1 = (float*)take(Ls * M * 4); w.rstd1 = (float*)take(Ls * M * 4);
     w.mean2 = (float*)take(Ls * M * 4); w.rstd2 = (float*)take(Ls * M * 4);
     w.S = (float*)take(pbytes * 4);
+    w.xsplit = (float*)take(4 * M * d * 4);  // split-K partial planes of a forward N = d GEMM (summed by the next LayerNorm)
     if (D.save) {
         w.dS = (unsigned short*)take(pbytes * 2);
         w.dx = (float*)take(M * d * 4);
@@ -245,6 +247,7 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
     // A2b: ln_pre -> residual stream xs[0]
     TRY(swat_layernorm_fwd(w.xpre, d, params + O.lnpre_w, params + O.lnpre_b, nullptr, w.xs, w.mean_pre, w.rstd_pre, M, d, eps, s));
 
+    int pending = 1;  // split-K planes of the previous block's c_proj still to be summed into xs[l]
     for (int l = 0; l < D.L; ++l) {
         const int64_t* lo = O.layer + 12 * l;
         const int64_t li = D.save ? l : 0;
@@ -259,7 +262,8 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
         unsigned short* f = w.f + li * (int64_t)M * D.mlp;
         unsigned short* ga = w.gact + li * (int64_t)M * D.mlp;
         // A2c: ln_1 -> packed QKV projection
-        TRY(swat_layernorm_fwd(xin, d, params + lo[LN1W], params + lo[LN1B], h1, nullptr, w.mean1 + li * M, w.rstd1 + li * M, M, d, eps, s));
+        TRY(swat_layernorm_fwd_split(pending > 1 ? w.xsplit : xin, d, pending, (int64_t)M * d, xin, params + lo[LN1W], params + lo[LN1B], h1,
+                                     nullptr, w.mean1 + li * M, w.rstd1 + li * M, M, d, eps, s));
         {
             GemmArgs a = G(h1, sh + lo[QKVW], qkv, M, 3 * d, d, d, d, 3 * d, 0);
             a.bias = params + lo[QKVB];
@@ -281,14 +285,24 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
             TRY(gemm_dispatch(L_NT, a, 1, s));
         }
         {
-            GemmArgs a = G(ga, sh + lo[PRW], xout, M, d, D.mlp, D.mlp, D.mlp, d, 1);
-            a.bias = params + lo[PRB]; a.residual = x1;
-            TRY(gemm_dispatch(L_NT, a, 1, s));
+            // c_proj: K = mlp is 48 k-steps on only ~300 tiles: split the reduction, the next LayerNorm sums the planes
+            pending = 1;
+            // (measured on MI355X, B/32 B=32: 5.35 ms/step with the split vs 5.29 without — the extra plane traffic eats the
+            //  gain of the forward direction, unlike the dgrad case — so it stays off; the plumbing is kept for larger K)
+            constexpr bool kFwdSplit = false;
+            if (kFwdSplit && (int64_t)((M + 63) / 64) * ((d + 63) / 64) < 600)
+                for (int cand = 4; cand >= 2; --cand)
+                    if (D.mlp % cand == 0 && (D.mlp / cand) % 64 == 0 && D.mlp / cand >= 512) { pending = cand; break; }
+            GemmArgs a = G(ga, sh + lo[PRW], pending > 1 ? w.xsplit : xout, M, d, D.mlp / pending, D.mlp, D.mlp, d, 1);
+            a.bias = params + lo[PRB]; a.residual = x1; a.epi0 = 1;
+            a.inner = pending; a.sA1 = D.mlp / pending; a.sB1 = D.mlp / pending; a.sC1 = (int64_t)M * d;
+            TRY(gemm_dispatch(L_NT, a, pending, s));
         }
     }
     // A2g: ln_post on the class token only, then the bias-free projection (fp32)
-    const float* xl = w.xs + (D.save ? (int64_t)D.L : (int64_t)(D.L & 1)) * M * d;
-    TRY(swat_layernorm_fwd(xl, (int64_t)T * d, params + O.lnpost_w, params + O.lnpost_b, nullptr, w.u, w.mean_post, w.rstd_post, D.B, d, eps, s));
+    float* xl = w.xs + (D.save ? (int64_t)D.L : (int64_t)(D.L & 1)) * M * d;
+    TRY(swat_layernorm_fwd_split(pending > 1 ? w.xsplit : xl, (int64_t)T * d, pending, (int64_t)M * d, xl, params + O.lnpost_w, params + O.lnpost_b,
+                                 nullptr, w.u, w.mean_post, w.rstd_post, D.B, d, eps, s));
     TRY(swat_sgemm_small(w.u, params + O.proj, feats, D.B, D.E, d, d, 1, D.E, 1, D.E, 1.0f, 0, s));
     return 0;
 }

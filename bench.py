@@ -40,7 +40,7 @@ class _Lg:
         pass
 
 
-def build_job(dev, world, bsz=32, n_cls=200, arch="ViT-B-32-quickgelu", total_iter=10000):
+def build_job(dev, world, bsz=32, n_cls=200, arch="ViT-B-32-quickgelu", total_iter=10000, trail=True):
     from swat_amd import optimizers
     from swat_amd.clip_model import CLIP
     from swat_amd.models import MyLinear
@@ -54,7 +54,7 @@ def build_job(dev, world, bsz=32, n_cls=200, arch="ViT-B-32-quickgelu", total_it
                                  optim="AdamW", wd=1e-2, epochs=1, cutmix_beta=1.0, mix_prob=0.5, loss_name="CE")
     params, logit_scale = optimizers.set_params(args, model, head, _Lg())
     opt, sched, _ = optimizers.set_optimizer(args, params, [None] * total_iter)
-    step = FusedTrainStep(model, head, logit_scale, opt, world_size=world)
+    step = FusedTrainStep(model, head, logit_scale, opt, world_size=world, trail=trail)
     return args, model, head, step, sched
 
 
@@ -70,12 +70,16 @@ def run_steps(args, step, sched, images, labels, n):
         sched.step()
 
 
-def gemm_roofline(args, step, sched, images, labels, n_steps, bsz):
+def gemm_roofline(args, step, sched, images, labels, n_steps, bsz, overlap=1):
     from swat_amd import _lib
     lib = _lib.lib()
+    trail, step.trail = step.trail, False
+    lib.swat_vit_set_overlap(0)  # per-launch durations of kernels running alone (the timed region overlaps streams)
     lib.swat_gemm_prof_begin(400 * n_steps)
     run_steps(args, step, sched, images, labels, n_steps)
     torch.cuda.synchronize()
+    lib.swat_vit_set_overlap(min(overlap, 1))
+    step.trail = trail
     ms = (ctypes.c_double * 6)()
     cnt = (ctypes.c_int64 * 6)()
     fl = (ctypes.c_double * 6)()
@@ -210,6 +214,8 @@ def main():
     ap.add_argument("--bsz", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--overlap", type=int, default=2, help="0: one stream; 1: weight-gradient lane in the backward; "
+                    "2 (default, what swat_amd.training runs): lane + per-stage all-reduce / AdamW trailing the backward")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,7 +230,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    args, model, head, step, sched = build_job(dev, world, a.bsz)
+    args, model, head, step, sched = build_job(dev, world, a.bsz, trail=a.overlap == 2)
+    from swat_amd import _lib
+    _lib.lib().swat_vit_set_overlap(min(a.overlap, 1))
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(a.bsz, 3, 224, 224, device=dev, generator=g)
     labels = torch.randint(0, 200, (a.bsz,), device=dev, generator=g)
@@ -263,7 +271,7 @@ def main():
                "final_loss": round(loss, 4),
                "step_mfma_frac": round(GFLOP_PER_IMG_STEP * 1e9 * a.bsz / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
     if world == 1:
-        out["roofline"] = gemm_roofline(args, step, sched, images, labels, min(a.steps, 10), a.bsz)
+        out["roofline"] = gemm_roofline(args, step, sched, images, labels, min(a.steps, 10), a.bsz, a.overlap)
         if not a.no_cpu_baseline:
             del step, model
             torch.cuda.empty_cache()

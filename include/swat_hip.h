@@ -201,6 +201,17 @@ int swat_vit_forward(const int32_t* dims, const int64_t* offs, const float* para
 int swat_vit_backward(const int32_t* dims, const int64_t* offs, const float* params,
                       const void* shadow_bf16, void* workspace, const float* dfeats, float* grads,
                       int stage_hi, int stage_lo, swat_stream_t stream);
+/* Weight-gradient lane of swat_vit_backward.  mode 1 (default): the weight-gradient GEMMs and bias column
+ *     sums run on an internal lower-priority stream, ordered by events against the data-gradient chain on
+ *     `stream`, and the call joins that lane before it returns.  mode 2: as 1 but the caller joins
+ *     (swat_vit_backward_join) after its last stage call; after each call, work ordered behind
+ *     swat_vit_lane_stream() sees every gradient of the stages issued so far, so a per-stage all-reduce /
+ *     optimizer slice can trail the backward without stalling it.  mode 0: everything on `stream`.
+ *     Same kernels and buffers in every mode: the gradients are bit-identical. */
+int swat_vit_set_overlap(int mode);
+swat_stream_t swat_vit_lane_stream(void);
+int swat_vit_lane_order(swat_stream_t stream); /* `stream` waits for what the lane holds now; the lane is not joined */
+int swat_vit_backward_join(swat_stream_t stream);
 /* A3+A4+A6 fused with their backward (ref utils/training.py:1475-1481): loss, d/dfeats, d/dW_head,
  *     d/dlogit_scale.  want_grad = 0: forward only (validate, testing.py:430-447); z_out / feat_norm_out
  *     optionally receive the un-scaled head output and the normalised features.  normalize = 0: feats are

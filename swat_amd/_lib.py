@@ -28,7 +28,8 @@ def _parse_header():
             else:
                 argtypes.append(_CTYPES[a.replace("const", "").split()[0]])
         protos[name] = argtypes
-        restypes[name] = ctypes.c_char_p if "char" in ret else (c_int64 if "int64_t" in ret else c_int)
+        restypes[name] = (ctypes.c_char_p if "char" in ret else c_void_p if "swat_stream_t" in ret
+                          else c_int64 if "int64_t" in ret else c_int)
     return protos, restypes
 
 

@@ -8,6 +8,7 @@
 //
 // Numerics: fp32 master weights + bf16 shadow weights; GEMMs read bf16 operands and accumulate in fp32; the
 // residual stream, LayerNorm statistics, softmax, proj and everything after it are fp32.
+#include <vector>
 #include "kernels.hpp"
 #include "../../include/swat_hip.h"
 
@@ -67,7 +68,8 @@ struct VitWs {
     float* xsplit;            // 4 x [M,d] forward split-K planes
     unsigned short* dS;       // [B*H,T,ldp]
     float* dx;                // [M,d] residual-stream gradient
-    unsigned short* dxb;      // [M,d] its bf16 copy
+    unsigned short* dxb;      // [M,d] its bf16 copy (block input side: feeds c_proj)
+    unsigned short* dxb2;     // [M,d] bf16 copy of the mid-block gradient (feeds out_proj)
     float* dh;                // [M,d] LN-input gradient
     unsigned short* dfb;      // [M,mlp]
     unsigned short* dab;      // [M,d]
@@ -112,6 +114,7 @@ static VitWs carve(const VitDims& D, void* base) {
         w.dS = (unsigned short*)take(pbytes * 2);
         w.dx = (float*)take(M * d * 4);
         w.dxb = (unsigned short*)take(M * d * 2);
+        w.dxb2 = (unsigned short*)take(M * d * 2);
         w.dh = (float*)take(4 * M * d * 4);  // up to 4 split-K partial planes of the dgrad that feeds a LayerNorm backward
         w.dfb = (unsigned short*)take(M * D.mlp * 2);
         w.dab = (unsigned short*)take(M * d * 2);
@@ -307,6 +310,67 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
     return 0;
 }
 
+// Weight-gradient GEMMs and bias column sums feed nothing but the optimizer, while the data-gradient chain is the
+// critical path and each of its GEMMs alone leaves CUs idle (300-1200 tiles on 256 CUs).  The backward therefore
+// forks the weight-gradient work onto a second, lower-priority stream: events order it after the producer of its
+// operand and order the next overwrite of that operand buffer after it.  Mode 1 joins the lane before the call
+// returns; mode 2 leaves the join to the caller (swat_vit_backward_join), so a stage-by-stage caller can hang its
+// own per-stage work (gradient all-reduce, optimizer slice) behind the lane without stalling the main chain.
+struct SideLane {
+    hipStream_t st = nullptr;
+    std::vector<hipEvent_t> ev;  // ring: an event is re-recorded only ~a whole backward later
+    size_t used = 0;
+    hipEvent_t doneA = nullptr, doneB = nullptr, doneF = nullptr, doneQ = nullptr;  // last lane read of dxb / dxb2 / dfb / dqkv
+    bool open = false;           // lane work issued and not joined yet
+    hipEvent_t next() {
+        if (ev.size() < 1024) {
+            hipEvent_t e;
+            hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            ev.push_back(e);
+            return e;
+        }
+        return ev[used++ % ev.size()];
+    }
+    int ensure() {
+        if (st) return 0;
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        return hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) == hipSuccess ? 0 : 1;
+    }
+};
+static SideLane g_side;
+static int g_overlap = 1;
+
+SWAT_API int swat_vit_set_overlap(int mode) {
+    SWAT_REQUIRE(mode >= 0 && mode <= 2, "swat_vit_set_overlap: mode must be 0, 1 or 2");
+    SWAT_REQUIRE(!g_side.open, "swat_vit_set_overlap: join the open backward first");
+    g_overlap = mode;
+    return 0;
+}
+
+SWAT_API swat_stream_t swat_vit_lane_stream(void) {
+    if (g_side.ensure()) return nullptr;
+    return (swat_stream_t)g_side.st;
+}
+
+SWAT_API int swat_vit_lane_order(swat_stream_t stream) {
+    SWAT_REQUIRE(g_side.ensure() == 0, "swat_vit_lane_order: cannot create the weight-gradient stream");
+    hipEvent_t e = g_side.next();
+    hipEventRecord(e, g_side.st);
+    hipStreamWaitEvent((hipStream_t)stream, e, 0);
+    return 0;
+}
+
+SWAT_API int swat_vit_backward_join(swat_stream_t stream) {
+    if (!g_side.open) return 0;
+    hipEvent_t e = g_side.next();
+    hipEventRecord(e, g_side.st);
+    hipStreamWaitEvent((hipStream_t)stream, e, 0);
+    g_side.open = false;
+    g_side.doneA = g_side.doneB = g_side.doneF = g_side.doneQ = nullptr;
+    return 0;
+}
+
 // Backward in stages so the host can overlap gradient reduction with the remaining backward:
 //   stage L+1 : proj + ln_post (needs dfeats);  stage l+1 : block l;  stage 0 : ln_pre + embeddings + conv1.
 // Call with stage_hi >= stage_lo; stages run from stage_hi down to stage_lo.  Gradients are WRITTEN (not
@@ -323,12 +387,35 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
     const unsigned short* sh = (const unsigned short*)shadow_bf16;
     const int M = D.M, d = D.d, T = D.T, np = D.B * D.g * D.g, mlp = D.mlp;
 
+    const bool fork = g_overlap != 0;
+    if (fork) SWAT_REQUIRE(g_side.ensure() == 0, "swat_vit_backward: cannot create the weight-gradient stream");
+    hipStream_t ws = fork ? g_side.st : s;  // weight-gradient lane
+    hipEvent_t &doneA = g_side.doneA, &doneB = g_side.doneB, &doneF = g_side.doneF, &doneQ = g_side.doneQ;
+    if (fork) g_side.open = true;
+    auto to_lane = [&]() {  // everything issued so far on the main stream precedes what the lane runs next
+        if (!fork) return;
+        hipEvent_t e = g_side.next();
+        hipEventRecord(e, s);
+        hipStreamWaitEvent(ws, e, 0);
+    };
+    auto lane_done = [&](hipEvent_t& slot) {
+        if (!fork) return;
+        slot = g_side.next();
+        hipEventRecord(slot, ws);
+    };
+    auto wait_lane = [&](hipEvent_t& slot) {
+        if (!slot) return;
+        hipStreamWaitEvent(s, slot, 0);
+        slot = nullptr;
+    };
+
     for (int stage = stage_hi; stage >= stage_lo; --stage) {
         if (stage == D.L + 1) {
             SWAT_REQUIRE(dfeats, "swat_vit_backward: dfeats is null");
             // dproj[c,e] = sum_b u[b,c] df[b,e] ; du[b,c] = sum_e df[b,e] proj[c,e]
             TRY(swat_sgemm_small(w.u, dfeats, grads + O.proj, d, D.E, D.B, 1, d, D.E, 1, D.E, 1.0f, 0, s));
             TRY(swat_sgemm_small(dfeats, params + O.proj, w.du, D.B, d, D.E, D.E, 1, 1, D.E, d, 1.0f, 0, s));
+            wait_lane(doneA);
             hipMemsetAsync(w.dx, 0, (size_t)M * d * 4, s);
             hipMemsetAsync(w.dxb, 0, (size_t)M * d * 2, s);
             const float* xl = w.xs + (int64_t)D.L * M * d;
@@ -348,33 +435,45 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             const unsigned short* f = w.f + (int64_t)l * M * mlp;
             const unsigned short* ga = w.gact + (int64_t)l * M * mlp;
             // c_proj: dW = dx^T g, db = colsum(dx), dF = (dx W) * act'(F)
-            TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, M, d, mlp, mlp, 1), 1, s));
+            to_lane();
+            TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, M, d, mlp, mlp, 1), 1, ws));
+            lane_done(doneA);
             // (c_proj bias gradient = column sums of dx: produced by the LayerNorm backward that wrote dx)
+            wait_lane(doneF);
             {
                 GemmArgs a = G(w.dxb, sh + lo[PRW], w.dfb, M, mlp, d, d, mlp, mlp, 0);
                 a.actin = f; a.ldact = mlp; a.act = D.act;
                 TRY(gemm_dispatch(L_NN, a, 1, s));
             }
             // c_fc: dW = dF^T h2, db = colsum(dF), dh2 = dF W
-            TRY(gemm_dispatch(L_TN, G(w.dfb, h2, grads + lo[FCW], mlp, d, M, mlp, d, d, 1), 1, s));
-            TRY(swat_colsum_bf16(w.dfb, M, mlp, mlp, grads + lo[FCB], w.csws, s));
+            to_lane();
+            TRY(gemm_dispatch(L_TN, G(w.dfb, h2, grads + lo[FCW], mlp, d, M, mlp, d, d, 1), 1, ws));
+            TRY(swat_colsum_bf16(w.dfb, M, mlp, mlp, grads + lo[FCB], w.csws, ws));
+            lane_done(doneF);
             int S2 = 1;
             TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
             // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
+            wait_lane(doneB);
             TRY(swat_layernorm_bwd_split(w.dh, d, S2, (int64_t)M * d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
-                                   w.dx, d, w.dxb, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], w.lnws, M, d, s));
+                                   w.dx, d, w.dxb2, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], w.lnws, M, d, s));
             // out_proj: dW = dx1^T a, db = colsum(dx1), da = dx1 W
-            TRY(gemm_dispatch(L_TN, G(w.dxb, at, grads + lo[OUTW], d, d, M, d, d, d, 1), 1, s));
+            to_lane();
+            TRY(gemm_dispatch(L_TN, G(w.dxb2, at, grads + lo[OUTW], d, d, M, d, d, d, 1), 1, ws));
+            lane_done(doneB);
             // (out_proj bias gradient: produced by the ln_2 backward above)
-            TRY(gemm_dispatch(L_NN, G(w.dxb, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
+            TRY(gemm_dispatch(L_NN, G(w.dxb2, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
             // attention backward -> dqkv
+            wait_lane(doneQ);
             TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s));
             // in_proj: dW = dqkv^T h1, db = colsum(dqkv), dh1 = dqkv W
-            TRY(gemm_dispatch(L_TN, G(w.dqkv, h1, grads + lo[QKVW], 3 * d, d, M, 3 * d, d, d, 1), 1, s));
-            TRY(swat_colsum_bf16(w.dqkv, M, 3 * d, 3 * d, grads + lo[QKVB], w.csws, s));
+            to_lane();
+            TRY(gemm_dispatch(L_TN, G(w.dqkv, h1, grads + lo[QKVW], 3 * d, d, M, 3 * d, d, d, 1), 1, ws));
+            TRY(swat_colsum_bf16(w.dqkv, M, 3 * d, 3 * d, grads + lo[QKVB], w.csws, ws));
+            lane_done(doneQ);
             int S1 = 1;
             TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));
             // ln_1 backward: dx0 = dx1 + LN'(dh1)
+            wait_lane(doneA);
             TRY(swat_layernorm_bwd_split(w.dh, d, S1, (int64_t)M * d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
                                    w.dx, d, w.dxb, d, grads + lo[LN1W], grads + lo[LN1B],
                                    l > 0 ? grads + (O.layer + 12 * (l - 1))[PRB] : nullptr, w.lnws, M, d, s));
@@ -384,10 +483,13 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                                    grads + O.lnpre_w, grads + O.lnpre_b, nullptr, w.lnws, M, d, s));
             TRY(swat_colsum(w.dh, SWAT_F32, D.B, T * d, T * d, grads + O.pos, 0, 0, 0, s));  // dpos[t,:] = sum_b
             TRY(swat_colsum(w.dh, SWAT_F32, D.B, d, T * d, grads + O.cls, 0, 0, 0, s));      // dcls = sum_b row 0
+            wait_lane(doneA);
             TRY(swat_gather_cast_bf16(w.dh, w.dxb, np, d, D.g * D.g, T, 1, s));              // drop the cls rows
             TRY(gemm_dispatch(L_TN, G(w.dxb, w.patches, grads + O.conv1, d, D.Kp, np, d, D.ldk, D.Kp, 1), 1, s));
         }
+        to_lane();  // the lane's tail now also follows everything this stage ran on the main stream
     }
+    if (g_overlap == 1) TRY(swat_vit_backward_join(stream));  // the caller's stream sees every gradient of the requested stages
     return 0;
 }
 

@@ -95,25 +95,52 @@ class FusedAdamW:
                 g['swat_tower'].adopt_arena(self.arena)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.step_count = 0
-        self._host = torch.zeros(6, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(6)
+        # step scalars (group LRs, bias corrections) go up through a ring of pinned rows: the host may run several
+        # steps ahead of the GPU, so a row is rewritten only after the copy that read it has executed
+        self._host = torch.zeros(8, 6, dtype=torch.float32).pin_memory()
+        self._host_ev = [None] * 8
         self._dev = torch.zeros(6, dtype=torch.float32, device=dev)
         self.grad_scale = 1.0
 
     def zero_grad(self, set_to_none=True):
         pass  # every backward WRITES the arena gradient; nothing accumulates
 
-    def step(self):
+    def begin_step(self):
+        """Bump the step count and upload this step's scalars (current stream)."""
         self.step_count += 1
         t = self.step_count
+        slot = t % len(self._host_ev)
+        if self._host_ev[slot] is not None:
+            self._host_ev[slot].synchronize()
+        row = self._host[slot]
         for i, g in enumerate(self.param_groups):
-            self._host[i] = g['lr']
-        self._host[4] = 1.0 - self.betas[0] ** t
-        self._host[5] = 1.0 - self.betas[1] ** t
-        self._dev.copy_(self._host, non_blocking=True)
+            row[i] = g['lr']
+        row[4] = 1.0 - self.betas[0] ** t
+        row[5] = 1.0 - self.betas[1] ** t
+        self._dev.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._host_ev[slot] = ev
+
+    def step_slice(self, lo, hi):
+        """AdamW on arena elements [lo, hi) (inside ONE LR group) on the current stream: the per-stage form the fused
+        step trails behind the backward.  Call begin_step() first and end_step() after the last slice."""
+        a = self.arena
+        gi = max(i for i, b in enumerate(self.seg_begin) if b <= lo)
+        assert gi + 1 == len(self.seg_begin) or hi <= self.seg_begin[gi + 1], "slice crosses an LR group"
+        ops.adamw_step(a.flat[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], a.shadow[lo:hi], [0],
+                       self._dev[gi:], self._dev[4:], self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                       self.grad_scale)
+
+    def end_step(self):
+        self.arena.mark_shadow_fresh()
+
+    def step(self):
+        self.begin_step()
         a = self.arena
         ops.adamw_step(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, a.shadow, self.seg_begin, self._dev, self._dev[4:],
                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.grad_scale)
-        a.mark_shadow_fresh()
+        self.end_step()
 
     def import_grads(self):
         """Copy autograd-produced p.grad tensors into the arena (compatibility path: loss.backward() by torch)."""

@@ -11,7 +11,7 @@ from .ddp import SliceReducer
 
 
 class FusedTrainStep:
-    def __init__(self, model, classifier_head, logit_scale, optimizer, world_size=None, staged=None):
+    def __init__(self, model, classifier_head, logit_scale, optimizer, world_size=None, staged=None, trail=True):
         self.visual = model.visual
         self.head = classifier_head
         self.logit_scale = logit_scale
@@ -45,6 +45,16 @@ class FusedTrainStep:
                 lo = self.arena.offset_of(ps[0])
                 hi = self.arena.offset_of(ps[-1]) + (ps[-1].numel() + 63) // 64 * 64
                 self._stage_slices.append((lo, hi))
+        # trailing mode: per backward stage, the slice's all-reduce and AdamW run on a third stream behind the
+        # weight-gradient lane (swat_hip.h: swat_vit_set_overlap mode 2), so the HBM-bound optimizer overlaps the
+        # GEMM-bound backward of the stages below.  Needs the slices to tile the whole arena.
+        self.trail = False
+        if trail and self.train_visual:
+            sl = sorted(self._stage_slices + [(self.off_head, self.off_head + (self.C * self.E + 63) // 64 * 64)]
+                        + ([(self.off_ls, self.off_ls + 64)] if self.off_ls is not None else []))
+            self.trail = sl[0][0] == 0 and sl[-1][1] == self.arena.numel and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+        if self.trail:
+            self._opt_stream = torch.cuda.Stream(device=dev, priority=0)
 
     def _head_ws(self, B, dev):
         ws = self._ws.get(B)
@@ -75,6 +85,8 @@ class FusedTrainStep:
                                        _lib.ptr(dfeats), g.data_ptr() + 4 * self.off_head, dls_ptr, None,
                                        None, _lib.ptr(self.loss_accum), B, self.E, self.C, 1, int(self.train_visual), _lib.stream())
         _lib.check(rc, "swat_head_loss")
+        if self.trail:
+            return self._trailing_backward(g, dfeats)
         if self.reduce:
             red.reduce(g, self.off_head, self.off_head + self.C * self.E)  # head group (first in the arena)
             if self.off_ls is not None:
@@ -92,6 +104,62 @@ class FusedTrainStep:
                 self.visual.backward_raw(dfeats)
         red.wait()
         self.opt.step()
+        return self.loss
+
+    def _slice_args(self):
+        """Raw-pointer argument tuples of the per-slice AdamW launches (rebuilt when the arena moves)."""
+        import ctypes
+        a, opt = self.arena, self.opt
+        key = (a.flat.data_ptr(), a.grad.data_ptr(), opt.grad_scale)
+        if getattr(self, "_slice_key", None) != key:
+            zero = (ctypes.c_int64 * 1)(0)
+            self._zero_seg = zero
+
+            def mk(lo, hi):
+                gi = max(i for i, b in enumerate(opt.seg_begin) if b <= lo)
+                assert gi + 1 == len(opt.seg_begin) or hi <= opt.seg_begin[gi + 1], "slice crosses an LR group"
+                return (a.flat.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo, a.exp_avg.data_ptr() + 4 * lo,
+                        a.exp_avg_sq.data_ptr() + 4 * lo, a.shadow.data_ptr() + 2 * lo, hi - lo,
+                        ctypes.cast(zero, ctypes.c_void_p), 1, opt._dev.data_ptr() + 4 * gi, float(opt.betas[0]),
+                        float(opt.betas[1]), float(opt.eps), float(opt.weight_decay), opt._dev.data_ptr() + 16,
+                        float(opt.grad_scale))
+            self._slice_cache = {"head": mk(self.off_head, self.off_head + (self.C * self.E + 63) // 64 * 64),
+                                 "ls": mk(self.off_ls, self.off_ls + 64) if self.off_ls is not None else None,
+                                 "stages": [mk(lo, hi) for lo, hi in self._stage_slices]}
+            self._slice_key = key
+        return self._slice_cache
+
+    def _trailing_backward(self, g, dfeats):
+        lib = _lib.lib()
+        main = torch.cuda.current_stream()
+        side = self._opt_stream
+        side_h = side.cuda_stream
+        opt = self.opt
+        sl = self._slice_args()
+
+        def finish(args, lo, n):  # on `side`: sum over ranks (RCCL, stream-ordered), then this slice's AdamW
+            if self.reduce:
+                with torch.cuda.stream(side):
+                    dist.all_reduce(g[lo:lo + n], op=dist.ReduceOp.SUM)
+            _lib.check(lib.swat_adamw(*args, side_h), "swat_adamw")
+
+        opt.begin_step()
+        side.wait_stream(main)  # head gradients + this step's scalars
+        finish(sl["head"], self.off_head, self.C * self.E)
+        if self.off_ls is not None:
+            finish(sl["ls"], self.off_ls, 1)
+        _lib.check(lib.swat_vit_set_overlap(2), "swat_vit_set_overlap")
+        try:
+            for s in range(self.visual.layers + 1, -1, -1):
+                self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
+                lib.swat_vit_lane_order(side_h)  # the lane's tail follows everything stage s ran on either stream
+                lo, hi = self._stage_slices[s]
+                finish(sl["stages"][s], lo, hi - lo)
+        finally:
+            lib.swat_vit_backward_join(main.cuda_stream)
+            lib.swat_vit_set_overlap(1)
+        main.wait_stream(side)
+        opt.end_step()
         return self.loss
 
     def pop_loss_sum(self):

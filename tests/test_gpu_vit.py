@@ -212,8 +212,9 @@ def test_validate_matches_oracle_eval():
 
 
 def test_staged_backward_with_process_group_equals_monolithic_step():
-    """The N > 1 code path (stage-by-stage backward + a slice all-reduce after every stage) run on ONE GPU inside a
-    1-rank RCCL process group must reproduce the monolithic step bit for bit (same kernels, same order per tensor)."""
+    """The N > 1 code paths run on ONE GPU inside a 1-rank RCCL process group must reproduce the monolithic
+    single-stream step bit for bit (same kernels, same order per tensor): stage-by-stage backward + a slice all-reduce
+    after every stage, and the trailing form (weight-gradient lane + per-stage all-reduce / AdamW on a third stream)."""
     import os
     import torch.distributed as dist
     from swat_amd import optimizers
@@ -228,7 +229,7 @@ def test_staged_backward_with_process_group_equals_monolithic_step():
         created = True
     try:
         results = []
-        for staged in (False, True):
+        for staged, trail in ((False, False), (True, False), (True, True), (False, True)):
             torch.manual_seed(3)
             model = CLIP(vision_cfg=TINY, text_cfg=(8, 64, 64, 1, 1)).to(dev())
             W = torch.randn(10, TINY[5])
@@ -236,7 +237,10 @@ def test_staged_backward_with_process_group_equals_monolithic_step():
             args = _args()
             params, ls = optimizers.set_params(args, model, head, _Lg())
             opt, sched, _ = optimizers.set_optimizer(args, params, [None] * 50)
-            step = FusedTrainStep(model, head, ls, opt, world_size=1, staged=staged)
+            step = FusedTrainStep(model, head, ls, opt, world_size=1, staged=staged, trail=trail)
+            assert step.trail == trail
+            if trail:
+                step.reduce = True  # all-reduce every slice on the trailing stream (1-rank group)
             g = torch.Generator().manual_seed(9)
             for it in range(3):
                 x = torch.randn(8, 3, 64, 64, generator=g).to(dev())
@@ -244,9 +248,9 @@ def test_staged_backward_with_process_group_equals_monolithic_step():
                 step(x, y, y.flip(0), 0.6, perm=torch.arange(7, -1, -1, device=dev()), box=(3, 9, 40, 50))
                 sched.step()
             results.append((opt.arena.flat.clone(), opt.arena.grad.clone(), step.loss.clone()))
-        assert torch.equal(results[0][0], results[1][0])
-        assert torch.equal(results[0][1], results[1][1])
-        assert torch.equal(results[0][2], results[1][2])
+        for other in results[1:]:
+            for a, b in zip(results[0], other):
+                assert torch.equal(a, b)
     finally:
         if created:
             dist.destroy_process_group()

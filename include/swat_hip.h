@@ -93,6 +93,7 @@ int swat_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int
  *     4 128x64x64, 5 64x128x64; -1 = automatic) — tests and tuning. */
 int swat_gemm_set_tile(int cfg);
 int swat_gemm_set_exp(int bits); /* tuning only: ablate loads / MFMA / epilogue of the LDS-DMA kernel (results wrong) */
+int swat_gemm_set_trace(void* dev_buf); /* tuning only: per-workgroup timeline of the LDS-DMA kernel (exp bit 16) */
 int swat_gemm_set_swizzle(int mode); /* 0 = plain 2-D grid, -1 = XCD-aware tile order (default) */
 int swat_gemm_prof_begin(int max_launches);
 int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind);

@@ -77,15 +77,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ln_bwd_reduce sums them in a fixed order (deterministic, no float atomics).
 // Each block = 4 waves; each wave walks rows  wave_global, wave_global + nwaves, ...
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int64_t dy_stride,
+constexpr int LNB_WAVES = 8;  // one row per wave and pass: M = 1600 rows -> 200 blocks, every wave exactly one row
+template <int NSPLIT>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __restrict__ dy, int64_t dy_stride,
                                                      const float* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* dx_add,
                                                      int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
                                                      unsigned short* __restrict__ dx_bf, int64_t dxb_stride,
-                                                     float* __restrict__ part, int rows, int d, int nsplit,
-                                                     int64_t split_stride) {
-    __shared__ float sh[3][4][64 * 4 * LN_MAXV];  // [dgamma / dbeta / colsum(dx_bf16)][wave][d]
+                                                     float* __restrict__ part, int rows, int d, int64_t split_stride) {
+    __shared__ float sh[LNB_WAVES][64 * 4 * LN_MAXV];  // [wave][d], reused for dgamma / dbeta / colsum(dx_bf16)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
     float4 dg[LN_MAXV], db[LN_MAXV], dcs[LN_MAXV], gm[LN_MAXV];
@@ -95,24 +96,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         db[i] = dg[i];
         dcs[i] = dg[i];
         const int c = lane + 64 * i;
-        gm[i] = c < nv ? reinterpret_cast<const float4*>(gamma)[c] : dg[i];
+        gm[i] = dg[i];
+        if (c < nv) gm[i] = reinterpret_cast<const float4*>(gamma)[c];
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
         const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * dy_stride);
         const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * x_stride);
         const float mu = mean[row], rs = rstd[row];
-        float4 dyv[LN_MAXV], xh[LN_MAXV];
+        float4 dyv[LN_MAXV], xh[LN_MAXV], pl[NSPLIT > 1 ? NSPLIT - 1 : 1][LN_MAXV], add[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
+        // every load of the row is issued before the first use: one memory latency per row, not one per plane
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
                 dyv[i] = dyr[c];
-                for (int sp = 1; sp < nsplit; ++sp) {  // split-K partial planes of the producing dgrad GEMM, fixed order
-                    const float4 t = reinterpret_cast<const float4*>(dy + sp * split_stride + (int64_t)row * dy_stride)[c];
+#pragma unroll
+                for (int sp = 1; sp < NSPLIT; ++sp)
+                    pl[sp - 1][i] = reinterpret_cast<const float4*>(dy + sp * split_stride + (int64_t)row * dy_stride)[c];
+                xh[i] = xr[c];
+                if (dx_add) add[i] = reinterpret_cast<const float4*>(dx_add + (int64_t)row * dxa_stride)[c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+#pragma unroll
+                for (int sp = 1; sp < NSPLIT; ++sp) {  // split-K partial planes of the producing dgrad GEMM, fixed order
+                    const float4 t = pl[sp - 1][i];
                     dyv[i].x += t.x; dyv[i].y += t.y; dyv[i].z += t.z; dyv[i].w += t.w;
                 }
-                const float4 xv = xr[c];
+                const float4 xv = xh[i];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 const float a0 = dyv[i].x * gm[i].x, a1 = dyv[i].y * gm[i].y, a2 = dyv[i].z * gm[i].z, a3 = dyv[i].w * gm[i].w;
                 s1 += a0 + a1 + a2 + a3;
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 o.z = rs * (dyv[i].z * gm[i].z - m1 - xh[i].z * m2);
                 o.w = rs * (dyv[i].w * gm[i].w - m1 - xh[i].w * m2);
                 if (dx_add) {
-                    const float4 a = reinterpret_cast<const float4*>(dx_add + (int64_t)row * dxa_stride)[c];
+                    const float4 a = add[i];
                     o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
                 }
                 if (dx_out) reinterpret_cast<float4*>(dx_out + (int64_t)row * dxo_stride)[c] = o;
@@ -147,50 +162,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            reinterpret_cast<float4*>(sh[0][wave])[c] = dg[i];
-            reinterpret_cast<float4*>(sh[1][wave])[c] = db[i];
-            reinterpret_cast<float4*>(sh[2][wave])[c] = dcs[i];
+    for (int q = 0; q < 3; ++q) {  // cross-wave sums in wave order, one quantity at a time through the same 40 KB
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) reinterpret_cast<float4*>(sh[wave])[c] = q == 0 ? dg[i] : (q == 1 ? db[i] : dcs[i]);
         }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < d; c += 256) {
-        part[((int64_t)blockIdx.x * 3 + 0) * d + c] = ((sh[0][0][c] + sh[0][1][c]) + sh[0][2][c]) + sh[0][3][c];
-        part[((int64_t)blockIdx.x * 3 + 1) * d + c] = ((sh[1][0][c] + sh[1][1][c]) + sh[1][2][c]) + sh[1][3][c];
-        part[((int64_t)blockIdx.x * 3 + 2) * d + c] = ((sh[2][0][c] + sh[2][1][c]) + sh[2][2][c]) + sh[2][3][c];
+        __syncthreads();
+        for (int c = threadIdx.x; c < d; c += 64 * LNB_WAVES) {
+            float v = sh[0][c];
+#pragma unroll
+            for (int w = 1; w < LNB_WAVES; ++w) v += sh[w][c];
+            part[((int64_t)blockIdx.x * 3 + q) * d + c] = v;
+        }
+        __syncthreads();
     }
 }
-
-// block = 64 columns x 16 partial-lanes (1024 threads); lane j sums partials j, j+16, ... then the 16 lanes combine in
-// lane order -> deterministic
+// grid (ceil(d / 32), 3): 32 columns x 32 strided groups of partial blocks per workgroup, groups summed in a fixed order
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int d,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              float* __restrict__ dcolsum) {
-    __shared__ float sh[3][16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j = threadIdx.x >> 6;
-    float a = 0.f, b = 0.f, e = 0.f;
-    if (c < d) {
-        for (int i = j; i < nblk; i += 16) {
-            a += part[((int64_t)i * 3 + 0) * d + c];
-            b += part[((int64_t)i * 3 + 1) * d + c];
-            e += part[((int64_t)i * 3 + 2) * d + c];
-        }
-    }
-    sh[0][j][threadIdx.x & 63] = a;
-    sh[1][j][threadIdx.x & 63] = b;
-    sh[2][j][threadIdx.x & 63] = e;
+    __shared__ float sh[32][33];
+    const int q = blockIdx.y;
+    float* out = q == 0 ? dgamma : (q == 1 ? dbeta : dcolsum);
+    if (!out) return;
+    const int t = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + t;
+    float a = 0.f;
+    if (c < d)
+        for (int i = j; i < nblk; i += 32) a += part[((int64_t)i * 3 + q) * d + c];
+    sh[j][t] = a;
     __syncthreads();
-    if (j < 3 && c < d) {
-        const int t = threadIdx.x & 63;
+    if (j == 0 && c < d) {
         float v = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v += sh[j][q][t];
-        if (j == 0) dgamma[c] = v;
-        else if (j == 1) dbeta[c] = v;
-        else if (dcolsum) dcolsum[c] = v;
+        for (int g = 0; g < 32; ++g) v += sh[g][t];
+        out[c] = v;
     }
 }
 
@@ -472,11 +479,11 @@ SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float*
                                 float* dbeta, float* dcolsum, void* workspace, int rows, int d, swat_stream_t s) {
     SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV, "swat_layernorm_bwd: d=%d unsupported", d);
     if (rows <= 0) return 0;
-    int nblk = (rows + 3) / 4;
+    int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
     if (nblk > 256) nblk = 256;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
-                       dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d, 1, 0);
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 63) / 64), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
+    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nblk), dim3(64 * LNB_WAVES), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
+                       dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d, 0);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 31) / 32, 3), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
     return check_launch("swat_layernorm_bwd");
 }
@@ -486,14 +493,22 @@ SWAT_API int swat_layernorm_bwd_split(const float* dy, int64_t dy_stride, int ns
                                       const float* dx_add, int64_t dxa_stride, float* dx_out, int64_t dxo_stride, void* dx_bf16,
                                       int64_t dxb_stride, float* dgamma, float* dbeta, float* dcolsum, void* workspace, int rows,
                                       int d, swat_stream_t s) {
-    SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && nsplit >= 1, "swat_layernorm_bwd_split: bad arguments");
+    SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && nsplit >= 1 && nsplit <= 4, "swat_layernorm_bwd_split: bad arguments");
     if (rows <= 0) return 0;
-    int nblk = (rows + 3) / 4;
+    int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
     if (nblk > 256) nblk = 256;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
-                       dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d,
-                       nsplit, split_stride);
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 63) / 64), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
+#define LNB_LAUNCH(NS)                                                                                                       \
+    hipLaunchKernelGGL(ln_bwd_kernel<NS>, dim3(nblk), dim3(64 * LNB_WAVES), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, \
+                       mean, rstd, dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride,             \
+                       (float*)workspace, rows, d, split_stride)
+    switch (nsplit) {
+        case 1: LNB_LAUNCH(1); break;
+        case 2: LNB_LAUNCH(2); break;
+        case 3: LNB_LAUNCH(3); break;
+        default: LNB_LAUNCH(4); break;
+    }
+#undef LNB_LAUNCH
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 31) / 32, 3), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
     return check_launch("swat_layernorm_bwd_split");
 }

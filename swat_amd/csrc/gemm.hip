@@ -32,6 +32,7 @@ namespace swat {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
@@ -89,61 +90,211 @@ __device__ __forceinline__ bf16x8_t read_frag(const unsigned char* tile, int bas
 }
 
 // ---- epilogue shared by both kernels: lane holds C[m][n..n+3], m = mbase + 16 i + (lane & 15), n = nbase + 16 j + 4 (lane >> 4)
+// bf16-output epilogue with 16-byte stores.  The store tail of an MFMA epilogue is bound by the NUMBER of store
+// instructions a CU issues, not by bytes (measured: ~0.5 us per wave-level store in the burst at the end of a round),
+// so two accumulator tiles that are neighbours in n trade halves with v_permlane16_swap: afterwards lane (r16, g) holds
+// row r16 of tile j + (g & 1), columns 8 * (g >> 1) .. + 7 — eight consecutive n — and every bf16 output is ONE
+// global_store_dwordx4 per lane where the 4-column layout needs two dwordx2.  Loads of the row-wise operands run one
+// accumulator row ahead of the stores (loads and stores share the in-order vmcnt counter).
 template <int FM, int FN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int mbase, int nbase, int lane,
-                                              int zo, int zi) {
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int mbase, int nbase, int lane,
+                                                   int zo, int zi) {
+    static_assert(FN % 2 == 0, "tile pairs");
+    constexpr int NP = FN / 2;
     const int M = p.M, N = p.N;
     const int r16 = lane & 15, g = lane >> 4;
-    const int Np4 = (N + 3) & ~3;
+    const int ncol = nbase + 16 * (g & 1) + 8 * (g >> 1);  // + 32 * pair
     const int64_t coff = zo * p.sC0 + zi * p.sC1;
+    const bool full_epi = !(p.epi0 && zi != 0);
+    const bool has_bias = p.bias && full_epi, has_rb = p.rowbias && full_epi, has_res = p.residual && full_epi;
+    struct RowIn {
+        float4 rb[NP][2], res[NP][2];
+        u32x4_t f[NP];
+        int orow;
+    };
+    float4 bias4[NP][2];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
+    for (int q = 0; q < NP; ++q) {
+        const int n = ncol + 32 * q;
+        bias4[q][0] = bias4[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_bias && n < N) {
+            bias4[q][0] = *reinterpret_cast<const float4*>(p.bias + n);
+            bias4[q][1] = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        }
+    }
+    auto load_row = [&](int i, RowIn& in) {
         const int m = mbase + 16 * i + r16;
-        if (m >= M) continue;
-        int orow = m;
-        int brow = 0;
+        int orow = m, brow = 0;
         if (p.rpg > 0) {
             brow = (m % p.rpg) + p.roff;
             orow = (m / p.rpg) * p.gstride + brow;
         }
+        in.orow = orow;
+        if (m >= M) return;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int n = ncol + 32 * q;
+            if (n >= N) continue;
+            if (has_rb) {
+                in.rb[q][0] = *reinterpret_cast<const float4*>(p.rowbias + (int64_t)brow * N + n);
+                in.rb[q][1] = *reinterpret_cast<const float4*>(p.rowbias + (int64_t)brow * N + n + 4);
+            }
+            if (has_res) {
+                in.res[q][0] = *reinterpret_cast<const float4*>(p.residual + coff + (int64_t)orow * p.ldc + n);
+                in.res[q][1] = *reinterpret_cast<const float4*>(p.residual + coff + (int64_t)orow * p.ldc + n + 4);
+            }
+            if (p.actin) in.f[q] = *reinterpret_cast<const u32x4_t*>(p.actin + (int64_t)m * p.ldact + n);
+        }
+    };
+    RowIn cur, nxt;
+    load_row(0, cur);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        if (i + 1 < FM) load_row(i + 1, nxt);
+        const int m = mbase + 16 * i + r16;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // every lane takes part in the swap (no divergence above this point)
+                // inline asm: hipcc (ROCm 7.2) folds a run of __builtin_amdgcn_permlane16_swap calls into the first one.
+                // The two v_nop are the wait states the swap needs after a VALU write of its operands.
+                float lo = acc[i][2 * q][e], hi = acc[i][2 * q + 1][e];
+                asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                v[e] = lo * p.alpha;
+                v[4 + e] = hi * p.alpha;
+            }
+            const int n = ncol + 32 * q;
+            if (m >= M || n >= N) continue;
+            if (has_bias) {
+                v[0] += bias4[q][0].x; v[1] += bias4[q][0].y; v[2] += bias4[q][0].z; v[3] += bias4[q][0].w;
+                v[4] += bias4[q][1].x; v[5] += bias4[q][1].y; v[6] += bias4[q][1].z; v[7] += bias4[q][1].w;
+            }
+            if (has_rb) {
+                v[0] += cur.rb[q][0].x; v[1] += cur.rb[q][0].y; v[2] += cur.rb[q][0].z; v[3] += cur.rb[q][0].w;
+                v[4] += cur.rb[q][1].x; v[5] += cur.rb[q][1].y; v[6] += cur.rb[q][1].z; v[7] += cur.rb[q][1].w;
+            }
+            if (has_res) {
+                v[0] += cur.res[q][0].x; v[1] += cur.res[q][0].y; v[2] += cur.res[q][0].z; v[3] += cur.res[q][0].w;
+                v[4] += cur.res[q][1].x; v[5] += cur.res[q][1].y; v[6] += cur.res[q][1].z; v[7] += cur.res[q][1].w;
+            }
+            if (p.actin) {  // dgrad through the activation: dF = dG * act'(F)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const unsigned w = cur.f[q][h];
+                    v[2 * h] *= act_bwd(bf2f((unsigned short)(w & 0xffffu)), p.act);
+                    v[2 * h + 1] *= act_bwd(bf2f((unsigned short)(w >> 16)), p.act);
+                }
+            }
+            const int64_t o = coff + (int64_t)cur.orow * p.ldc + n;
+            unsigned short ob[8];
+            u32x4_t pk;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) ob[h] = f2bf(v[h]);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) pk[h] = (unsigned)ob[2 * h] | ((unsigned)ob[2 * h + 1] << 16);
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(p.C) + o) = pk;
+            if (p.C2) {  // second output: activation of the ROUNDED pre-activation (what backward re-reads)
+                u32x4_t pk2;
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+                    pk2[h] = (unsigned)f2bf(act_fwd(bf2f(ob[2 * h]), p.act)) | ((unsigned)f2bf(act_fwd(bf2f(ob[2 * h + 1]), p.act)) << 16);
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(p.C2) + o) = pk2;
+            }
+        }
+        cur = nxt;
+    }
+}
+
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int mbase, int nbase, int lane,
+                                              int zo, int zi) {
+    if constexpr (FN % 2 == 0) {
+        // 16-byte rows: every pointer the wide form touches with 16-B accesses is 16-B aligned at n % 8 == 0
+        if (!p.out_f32 && p.N % 8 == 0 && p.ldc % 8 == 0 && (p.sC0 | p.sC1) % 8 == 0 && (!p.actin || p.ldact % 8 == 0) &&
+            (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.C2) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(p.actin) & 15) == 0) {
+            gemm_epilogue_wide<FM, FN>(p, acc, mbase, nbase, lane, zo, zi);
+            return;
+        }
+    }
+    // Loads and stores share one in-order counter (vmcnt): a load issued after a store cannot be waited for without
+    // also waiting for that store's acknowledgement (~0.5 us in a burst).  So every operand this epilogue reads is
+    // requested BEFORE the stores it could queue behind: the bias vectors once, and the row-wise operands (row bias,
+    // residual, activation input) of accumulator row i+1 ahead of the stores of row i.
+    const int M = p.M, N = p.N;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int Np4 = (N + 3) & ~3;
+    const int64_t coff = zo * p.sC0 + zi * p.sC1;
+    const bool full_epi = !(p.epi0 && zi != 0);
+    const bool has_bias = p.bias && full_epi, has_rb = p.rowbias && full_epi, has_res = p.residual && full_epi;
+    struct RowIn {
+        float4 rb[FN], res[FN];
+        ushort4 f[FN];
+        int orow;
+    };
+    float4 bias4[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = nbase + 16 * j + 4 * g;
+        bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_bias && n < Np4) bias4[j] = *reinterpret_cast<const float4*>(p.bias + n);
+    }
+    auto load_row = [&](int i, RowIn& in) {
+        const int m = mbase + 16 * i + r16;
+        int orow = m, brow = 0;
+        if (p.rpg > 0) {
+            brow = (m % p.rpg) + p.roff;
+            orow = (m / p.rpg) * p.gstride + brow;
+        }
+        in.orow = orow;
+        if (m >= M) return;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = nbase + 16 * j + 4 * g;
             if (n >= Np4) continue;
-            float v[4];
+            if (has_rb) in.rb[j] = *reinterpret_cast<const float4*>(p.rowbias + (int64_t)brow * N + n);
+            if (has_res) in.res[j] = *reinterpret_cast<const float4*>(p.residual + coff + (int64_t)orow * p.ldc + n);
+            if (p.actin) in.f[j] = *reinterpret_cast<const ushort4*>(p.actin + (int64_t)m * p.ldact + n);
+        }
+    };
+    RowIn cur, nxt;
+    load_row(0, cur);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
-            const bool full_epi = !(p.epi0 && zi != 0);
-            if (p.bias && full_epi) {
-                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-            }
-            if (p.rowbias && full_epi) {
-                const float4 b4 = *reinterpret_cast<const float4*>(p.rowbias + (int64_t)brow * N + n);
-                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-            }
-            const int64_t o = coff + (int64_t)orow * p.ldc + n;
-            if (p.residual && full_epi) {
-                const float4 r4 = *reinterpret_cast<const float4*>(p.residual + o);
-                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-            }
-            if (p.actin) {  // dgrad through the activation: dF = dG * act'(F)
-                const ushort4 f4 = *reinterpret_cast<const ushort4*>(p.actin + (int64_t)m * p.ldact + n);
-                v[0] *= act_bwd(bf2f(f4.x), p.act); v[1] *= act_bwd(bf2f(f4.y), p.act);
-                v[2] *= act_bwd(bf2f(f4.z), p.act); v[3] *= act_bwd(bf2f(f4.w), p.act);
-            }
-            if (p.out_f32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + o) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                ushort4 o4 = make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
-                *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(p.C) + o) = o4;
-                if (p.C2) {  // second output: activation of the ROUNDED pre-activation (what backward re-reads)
-                    ushort4 a4 = make_ushort4(f2bf(act_fwd(bf2f(o4.x), p.act)), f2bf(act_fwd(bf2f(o4.y), p.act)),
-                                              f2bf(act_fwd(bf2f(o4.z), p.act)), f2bf(act_fwd(bf2f(o4.w), p.act)));
-                    *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(p.C2) + o) = a4;
+    for (int i = 0; i < FM; ++i) {
+        if (i + 1 < FM) load_row(i + 1, nxt);
+        const int m = mbase + 16 * i + r16;
+        if (m < M) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = nbase + 16 * j + 4 * g;
+                if (n >= Np4) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
+                if (has_bias) { v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w; }
+                if (has_rb) { v[0] += cur.rb[j].x; v[1] += cur.rb[j].y; v[2] += cur.rb[j].z; v[3] += cur.rb[j].w; }
+                if (has_res) { v[0] += cur.res[j].x; v[1] += cur.res[j].y; v[2] += cur.res[j].z; v[3] += cur.res[j].w; }
+                if (p.actin) {  // dgrad through the activation: dF = dG * act'(F)
+                    const ushort4 f4 = cur.f[j];
+                    v[0] *= act_bwd(bf2f(f4.x), p.act); v[1] *= act_bwd(bf2f(f4.y), p.act);
+                    v[2] *= act_bwd(bf2f(f4.z), p.act); v[3] *= act_bwd(bf2f(f4.w), p.act);
+                }
+                const int64_t o = coff + (int64_t)cur.orow * p.ldc + n;
+                if (p.out_f32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    ushort4 o4 = make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
+                    *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(p.C) + o) = o4;
+                    if (p.C2) {  // second output: activation of the ROUNDED pre-activation (what backward re-reads)
+                        ushort4 a4 = make_ushort4(f2bf(act_fwd(bf2f(o4.x), p.act)), f2bf(act_fwd(bf2f(o4.y), p.act)),
+                                                  f2bf(act_fwd(bf2f(o4.z), p.act)), f2bf(act_fwd(bf2f(o4.w), p.act)));
+                        *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(p.C2) + o) = a4;
+                    }
                 }
             }
         }
+        cur = nxt;
     }
 }
 
@@ -518,8 +669,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmArg
 // first version issuing ~95 VALU + 60 SALU per 8 MFMAs (SQ_ACTIVE_INST_ANY 38 %, MFMA busy 17 %): the loop was
 // bound by its own address arithmetic, not by memory, LDS or the matrix pipe.
 // --------------------------------------------------------------------------------------------
+// tuning only (exp bit 16): per-workgroup timeline {start, main loop done, end} in 100 MHz ticks + HW_ID / XCC_ID
+__device__ unsigned long long* g_gemm_trace = nullptr;
+__device__ __forceinline__ void trace_block(const GemmArgs& p, unsigned long long t0, unsigned long long t1) {
+    if (!(p.exp & 16) || threadIdx.x != 0 || !g_gemm_trace) return;
+    const unsigned long long t2 = wall_clock64();
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    g_gemm_trace[4 * b + 0] = t0; g_gemm_trace[4 * b + 1] = t1; g_gemm_trace[4 * b + 2] = t2;
+    g_gemm_trace[4 * b + 3] = ((unsigned long long)xcc << 32) | hw;
+}
+
 template <int LAYOUT, int BM, int BN, int NSTAGE, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmArgs p) {
+    const unsigned long long tr0 = (p.exp & 16) ? wall_clock64() : 0ull;
     constexpr int NW = WGM * WGN;
     constexpr bool A_KC = (LAYOUT != L_TN);
     constexpr bool B_KC = (LAYOUT == L_NT);
@@ -663,7 +828,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmArgs
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (t + NSTAGE - 1 < nk) issue((u + NSTAGE - 1) % NSTAGE, gA, gB);
+                if (t + NSTAGE - 1 < nk && !(p.exp & 1)) issue((u + NSTAGE - 1) % NSTAGE, gA, gB);
                 advance();
                 const unsigned char* st = smem + u * STAGE;  // immediate after unrolling
                 if (p.exp & 2) continue;  // tuning only: DMA streaming without LDS reads / MFMA
@@ -683,7 +848,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmArgs
             }
         }
     }
-    gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+    const unsigned long long tr1 = (p.exp & 16) ? wall_clock64() : 0ull;
+    if (!(p.exp & 4)) gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+    if (p.exp & 16) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trace_block(p, tr0, tr1);
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -854,7 +1024,7 @@ __global__ __launch_bounds__(256) void gemm_ring2_kernel(const GemmArgs p) {
             }
         }
     }
-    gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+    if (!(p.exp & 4)) gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
 }
 
 static int g_exp = 0;
@@ -922,6 +1092,15 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
         hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, b); \
     }
+#define SWAT_DMA_TALL(BM_, BN_, NS_)                                                                     \
+    {                                                                                                     \
+        if constexpr (LAYOUT != L_TN) {  /* 80-row wave slabs: A must be k-contiguous */                  \
+            GemmArgs b = a;                                                                               \
+            dim3 grid = plan_grid(b, BM_, BN_, batch);                                                    \
+            hipLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_, 2, 2>), grid, dim3(256), 0, s, b); \
+        }                                                                                                 \
+    }
+    if (cfg >= 40 && (LAYOUT == L_TN || a.K % 64 != 0 || a.K < 192)) cfg = 20;
     if (cfg >= 25 && cfg <= 28 && a.K % 64 != 0) cfg = 20;
     if (cfg >= 30 && (a.K % 64 != 0 || a.K < 64 * 6)) cfg = 20;  // lean ring needs whole, >= D k-steps
     if (cfg >= 6 && cfg < 20 && a.K % 64 != 0) cfg = (cfg == 6 || (cfg >= 10 && cfg != 14 && cfg != 17 && cfg != 18 && cfg != 19)) ? 1 : (cfg == 8 ? 2 : 0);  // the LDS-DMA kernel has no K tail
@@ -937,6 +1116,9 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
         case 11: SWAT_GLDS8(128, 128, 3, 4, 2) break;
         case 12: SWAT_GLDS8(128, 64, 4, 4, 2) break;
         case 13: SWAT_GLDS8(256, 128, 2, 4, 2) break;
+        case 40: SWAT_DMA_TALL(160, 128, 3) break;
+        case 41: SWAT_DMA_TALL(160, 64, 3) break;
+        case 42: SWAT_DMA_TALL(160, 128, 2) break;
         case 14: SWAT_DMA(64, 64, 3) break;
         case 15: SWAT_DMA(128, 128, 3) break;
         case 16: SWAT_DMA(128, 64, 3) break;
@@ -1012,6 +1194,11 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
 }
 
 }  // namespace swat
+
+SWAT_API int swat_gemm_set_trace(void* dev_buf) {  /* tuning only: 4 x uint64 per workgroup, see trace_block() */
+    unsigned long long* ptr = (unsigned long long*)dev_buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(swat::g_gemm_trace), &ptr, sizeof(ptr)) == hipSuccess ? 0 : -1;
+}
 
 SWAT_API int swat_gemm_set_exp(int e) {
     swat::g_exp = e;

@@ -27,11 +27,14 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // bf16 <-> f32 on raw bits (round-to-nearest-even; NaN kept NaN)
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // quiet NaN
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
+typedef __bf16 swat_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float swat_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const swat_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, swat_bf16x2_t));
 }
+__device__ __forceinline__ unsigned short f2bf(float f) { return (unsigned short)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
 }  // namespace swat
 

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Each block = 4 waves; each wave walks rows  wave_global, wave_global + nwaves, ...
 // --------------------------------------------------------------------------------------------
 constexpr int LNB_WAVES = 8;  // one row per wave and pass: M = 1600 rows -> 200 blocks, every wave exactly one row
-template <int NSPLIT>
+template <int NSPLIT, int VPL>  // VPL float4 per lane: d <= 256 * VPL
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __restrict__ dy, int64_t dy_stride,
                                                      const float* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -86,12 +86,12 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
                                                      int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
                                                      unsigned short* __restrict__ dx_bf, int64_t dxb_stride,
                                                      float* __restrict__ part, int rows, int d, int64_t split_stride) {
-    __shared__ float sh[LNB_WAVES][64 * 4 * LN_MAXV];  // [wave][d], reused for dgamma / dbeta / colsum(dx_bf16)
+    __shared__ float sh[LNB_WAVES][64 * 4 * VPL];  // [wave][d], reused for dgamma / dbeta / colsum(dx_bf16)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
-    float4 dg[LN_MAXV], db[LN_MAXV], dcs[LN_MAXV], gm[LN_MAXV];
+    float4 dg[VPL], db[VPL], dcs[VPL], gm[VPL];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < VPL; ++i) {
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[i] = dg[i];
         dcs[i] = dg[i];
@@ -103,11 +103,11 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
         const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * dy_stride);
         const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * x_stride);
         const float mu = mean[row], rs = rstd[row];
-        float4 dyv[LN_MAXV], xh[LN_MAXV], pl[NSPLIT > 1 ? NSPLIT - 1 : 1][LN_MAXV], add[LN_MAXV];
+        float4 dyv[VPL], xh[VPL], pl[NSPLIT > 1 ? NSPLIT - 1 : 1][VPL], add[VPL];
         float s1 = 0.f, s2 = 0.f;
         // every load of the row is issued before the first use: one memory latency per row, not one per plane
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < VPL; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
                 dyv[i] = dyr[c];
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
             }
         }
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < VPL; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
         }
         const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < VPL; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
                 float4 o;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
 #pragma unroll
     for (int q = 0; q < 3; ++q) {  // cross-wave sums in wave order, one quantity at a time through the same 40 KB
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < VPL; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) reinterpret_cast<float4*>(sh[wave])[c] = q == 0 ? dg[i] : (q == 1 ? db[i] : dcs[i]);
         }
@@ -473,6 +473,24 @@ SWAT_API int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d) {
     return (int64_t)256 * 3 * d * sizeof(float);
 }
 
+#define LNB_LAUNCH(NS, V)                                                                                                    \
+    hipLaunchKernelGGL((ln_bwd_kernel<NS, V>), dim3(nblk), dim3(64 * LNB_WAVES), 0, (hipStream_t)s, dy, dy_stride, x, x_stride,  \
+                       gamma, mean, rstd, dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride,      \
+                       (float*)workspace, rows, d, split_stride)
+#define LNB_SPLITS(V)                       \
+    switch (nsplit) {                       \
+        case 1: LNB_LAUNCH(1, V); break;    \
+        case 2: LNB_LAUNCH(2, V); break;    \
+        case 3: LNB_LAUNCH(3, V); break;    \
+        default: LNB_LAUNCH(4, V); break;   \
+    }
+#define LNB_DISPATCH()                      \
+    do {                                    \
+        if (d <= 768) { LNB_SPLITS(3) }     \
+        else if (d <= 1024) { LNB_SPLITS(4) } \
+        else { LNB_SPLITS(5) }              \
+    } while (0)
+
 SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float* x, int64_t x_stride, const float* gamma,
                                 const float* mean, const float* rstd, const float* dx_add, int64_t dxa_stride,
                                 float* dx_out, int64_t dxo_stride, void* dx_bf16, int64_t dxb_stride, float* dgamma,
@@ -481,8 +499,9 @@ SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float*
     if (rows <= 0) return 0;
     int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
     if (nblk > 256) nblk = 256;
-    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nblk), dim3(64 * LNB_WAVES), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, mean, rstd,
-                       dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride, (float*)workspace, rows, d, 0);
+    const int nsplit = 1;
+    const int64_t split_stride = 0;
+    LNB_DISPATCH();
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 31) / 32, 3), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
     return check_launch("swat_layernorm_bwd");
@@ -497,17 +516,7 @@ SWAT_API int swat_layernorm_bwd_split(const float* dy, int64_t dy_stride, int ns
     if (rows <= 0) return 0;
     int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
     if (nblk > 256) nblk = 256;
-#define LNB_LAUNCH(NS)                                                                                                       \
-    hipLaunchKernelGGL(ln_bwd_kernel<NS>, dim3(nblk), dim3(64 * LNB_WAVES), 0, (hipStream_t)s, dy, dy_stride, x, x_stride, gamma, \
-                       mean, rstd, dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride,             \
-                       (float*)workspace, rows, d, split_stride)
-    switch (nsplit) {
-        case 1: LNB_LAUNCH(1); break;
-        case 2: LNB_LAUNCH(2); break;
-        case 3: LNB_LAUNCH(3); break;
-        default: LNB_LAUNCH(4); break;
-    }
-#undef LNB_LAUNCH
+    LNB_DISPATCH();
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 31) / 32, 3), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
     return check_launch("swat_layernorm_bwd_split");

@@ -37,13 +37,13 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 __device__ __forceinline__ float act_fwd(float x, int act) {
-    if (act == 1) return x / (1.0f + __expf(-1.702f * x));
+    if (act == 1) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));  // v_exp + v_rcp, no IEEE division
     if (act == 2) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
     return x;
 }
 __device__ __forceinline__ float act_bwd(float x, int act) {
     if (act == 1) {
-        const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
         return s * (1.0f + 1.702f * x * (1.0f - s));
     }
     if (act == 2) {
@@ -90,12 +90,14 @@ __device__ __forceinline__ bf16x8_t read_frag(const unsigned char* tile, int bas
 }
 
 // ---- epilogue shared by both kernels: lane holds C[m][n..n+3], m = mbase + 16 i + (lane & 15), n = nbase + 16 j + 4 (lane >> 4)
-// bf16-output epilogue with 16-byte stores.  The store tail of an MFMA epilogue is bound by the NUMBER of store
-// instructions a CU issues, not by bytes (measured: ~0.5 us per wave-level store in the burst at the end of a round),
-// so two accumulator tiles that are neighbours in n trade halves with v_permlane16_swap: afterwards lane (r16, g) holds
-// row r16 of tile j + (g & 1), columns 8 * (g >> 1) .. + 7 — eight consecutive n — and every bf16 output is ONE
-// global_store_dwordx4 per lane where the 4-column layout needs two dwordx2.  Loads of the row-wise operands run one
-// accumulator row ahead of the stores (loads and stores share the in-order vmcnt counter).
+// bf16-output epilogue with 16-byte stores.  Two accumulator tiles that are neighbours in n trade halves with
+// v_permlane16_swap: afterwards lane (r16, g) holds row r16 of tile j + (g & 1), columns 8 * (g >> 1) .. + 7 — eight
+// consecutive n — so every bf16 output is ONE global_store_dwordx4 per lane where the 4-column layout needs two dwordx2
+// (and the activation input one 16-B load).  Measured on the 1600 x 3072 outputs (tools/block_timeline.py): halving the
+// store count took ~15 % off the epilogue; most of its time was arithmetic (IEEE division and software bf16 rounding,
+// now v_rcp_f32 and v_cvt_pk_bf16_f32), 4.8 -> 2.8 us per round.  Staging the tile through LDS for whole-line stores
+// bought nothing on top.  Loads of the row-wise operands run one accumulator row ahead of the stores (loads and stores
+// share the in-order vmcnt counter).
 template <int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int mbase, int nbase, int lane,
                                                    int zo, int zi) {
@@ -187,18 +189,15 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x4_t (&
                 }
             }
             const int64_t o = coff + (int64_t)cur.orow * p.ldc + n;
-            unsigned short ob[8];
             u32x4_t pk;
 #pragma unroll
-            for (int h = 0; h < 8; ++h) ob[h] = f2bf(v[h]);
-#pragma unroll
-            for (int h = 0; h < 4; ++h) pk[h] = (unsigned)ob[2 * h] | ((unsigned)ob[2 * h + 1] << 16);
+            for (int h = 0; h < 4; ++h) pk[h] = pack_bf16x2(v[2 * h], v[2 * h + 1]);
             *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(p.C) + o) = pk;
             if (p.C2) {  // second output: activation of the ROUNDED pre-activation (what backward re-reads)
                 u32x4_t pk2;
 #pragma unroll
                 for (int h = 0; h < 4; ++h)
-                    pk2[h] = (unsigned)f2bf(act_fwd(bf2f(ob[2 * h]), p.act)) | ((unsigned)f2bf(act_fwd(bf2f(ob[2 * h + 1]), p.act)) << 16);
+                    pk2[h] = pack_bf16x2(act_fwd(__uint_as_float(pk[h] << 16), p.act), act_fwd(__uint_as_float(pk[h] & 0xffff0000u), p.act));
                 *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(p.C2) + o) = pk2;
             }
         }
@@ -297,6 +296,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
         cur = nxt;
     }
 }
+
+
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, speed only — never correctness).
 // Give each XCD a CONTIGUOUS chunk of the tile list, ordered so its tiles share A-row / B-column panels.
@@ -1100,7 +1101,8 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
             hipLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_, 2, 2>), grid, dim3(256), 0, s, b); \
         }                                                                                                 \
     }
-    if (cfg >= 40 && (LAYOUT == L_TN || a.K % 64 != 0 || a.K < 192)) cfg = 20;
+    if (cfg >= 40 && cfg < 43 && (LAYOUT == L_TN || a.K % 64 != 0 || a.K < 192)) cfg = 20;
+    if (cfg >= 43 && a.K % 64 != 0) cfg = 20;
     if (cfg >= 25 && cfg <= 28 && a.K % 64 != 0) cfg = 20;
     if (cfg >= 30 && (a.K % 64 != 0 || a.K < 64 * 6)) cfg = 20;  // lean ring needs whole, >= D k-steps
     if (cfg >= 6 && cfg < 20 && a.K % 64 != 0) cfg = (cfg == 6 || (cfg >= 10 && cfg != 14 && cfg != 17 && cfg != 18 && cfg != 19)) ? 1 : (cfg == 8 ? 2 : 0);  // the LDS-DMA kernel has no K tail
@@ -1119,6 +1121,9 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
         case 40: SWAT_DMA_TALL(160, 128, 3) break;
         case 41: SWAT_DMA_TALL(160, 64, 3) break;
         case 42: SWAT_DMA_TALL(160, 128, 2) break;
+        case 43: SWAT_DMA(128, 64, 2) break;
+        case 44: SWAT_DMA(64, 128, 2) break;
+        case 45: SWAT_DMA(64, 64, 2) break;
         case 14: SWAT_DMA(64, 64, 3) break;
         case 15: SWAT_DMA(128, 128, 3) break;
         case 16: SWAT_DMA(128, 64, 3) break;
@@ -1155,14 +1160,19 @@ static int g_force_cfg = -1;  // swat_gemm_set_tile(): experiments / tests pin o
 
 static int pick_cfg(int layout, const GemmArgs& a, int batch) {
     if (g_force_cfg >= 0) return g_force_cfg;
-    // Measured on MI355X (tools/perf_gemm.py; M = B*T = 1600, ~1-5 blocks per CU).  The launches are short (10-30 us):
-    // ramp, first-touch latency and the epilogue are comparable to the k-loop, so 64x64 tiles (more blocks in
-    // flight, shorter tails) beat 128x128 everywhere; LDS-DMA (14/16) wins the k-contiguous NT products, the lean
-    // register ring (30) wins the deep-K dgrad / small wgrad products; everything ragged goes to the staged ring (20).
+    // Measured on MI355X (rocprofv3 kernel durations, tools/exp_trace.py; M = B*T = 1600).  The launches are short
+    // (10-30 us) and run as lock-step rounds of resident workgroups (tools/block_timeline.py), each round paying its
+    // own epilogue burst: wide outputs (N >= 2048, K <= 1024) want ONE round, which 128x64 tiles with a 2-stage ring
+    // (48 KB: three workgroups per CU, 468-624 tiles resident at once) give (43); elsewhere 64x64 tiles (more
+    // workgroups in flight) win: LDS-DMA (14) for the k-contiguous NT products and the large wgrads, the lean
+    // register ring (30) for the deep-K dgrad / small wgrad products; everything ragged goes to the staged ring (20).
     const bool whole = a.K % 64 == 0;
     if (!whole || batch > 1) return a.K % 64 == 0 && batch > 1 ? 14 : 20;
-    if (layout == L_NT) return (a.N >= 2048 && a.K <= 1024 && a.M >= 128) ? 16 : 14;
-    if (layout == L_NN) return (a.K >= 1024 || a.N >= 2048) && a.K >= 384 ? 30 : 14;
+    if (layout == L_NT) return (a.N >= 2048 && a.K <= 1024 && a.M >= 128) ? 43 : 14;
+    if (layout == L_NN) {
+        if (a.N >= 2048 && a.K <= 1024 && a.M >= 128) return 43;
+        return a.K >= 384 ? 30 : 14;
+    }
     return ((int64_t)a.M * a.N >= (1 << 21)) ? 14 : (a.K >= 384 ? 30 : 14);
 }
 
@@ -1186,7 +1196,7 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     else rc = launch_gemm<L_TN>(a, batch, tile, s);
     if (prof) {
         hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
-        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || (tile >= 10 && tile < 14) || tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28));
+        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || (tile >= 10 && tile < 14) || tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43 || tile == 40 || tile == 41 || tile == 42);
         g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
         ++g_prof.n;
     }

@@ -38,10 +38,9 @@ def run(name, lay, m, n, k, epi, cfg, exp=0):
                   f"  epilogue {np.median(en[sel] - ml[sel]):5.2f} us (p90 {np.percentile(en[sel] - ml[sel], 90):5.2f})")
     per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
     print(f"   workgroups per CU: min {per_cu.min()} max {per_cu.max()}  hist {np.bincount(per_cu)}")
-run("fc fwd NT 1600x3072x768 dual", "NT", 1600, 3072, 768, "fc", 14)
-run("fc fwd NT 1600x3072x768 dual", "NT", 1600, 3072, 768, "fc", 40)
-run("qkv fwd NT 1600x2304x768", "NT", 1600, 2304, 768, "bias", 14)
-run("qkv fwd NT 1600x2304x768", "NT", 1600, 2304, 768, "bias", 16)
-run("proj fwd NT 1600x768x3072 res", "NT", 1600, 768, 3072, "res", 14)
-run("proj dgrad NN 1600x3072x768 act'", "NN", 1600, 3072, 768, "actin", 14)
-run("fc wgrad TN 3072x768x1600", "TN", 3072, 768, 1600, "f32", 14)
+for cfg in (14, 16, 43, 44, 45):
+    run("fc fwd NT 1600x3072x768 dual", "NT", 1600, 3072, 768, "fc", cfg)
+for cfg in (14, 16, 43, 44):
+    run("qkv fwd NT 1600x2304x768", "NT", 1600, 2304, 768, "bias", cfg)
+for cfg in (14, 43, 44):
+    run("proj dgrad NN 1600x3072x768 act'", "NN", 1600, 3072, 768, "actin", cfg)

@@ -12,9 +12,15 @@ SHAPES = [("fc fwd  NT 1600x3072x768 bias+gelu dual bf16", "NT", 1600, 3072, 768
           ("proj fwd NT 1600x768x3072 bias+res f32", "NT", 1600, 768, 3072, "res"),
           ("fc dgrad NN 1600x768x3072 f32", "NN", 1600, 768, 3072, "f32"),
           ("proj dgrad NN 1600x3072x768 act' bf16", "NN", 1600, 3072, 768, "actin"),
-          ("fc wgrad TN 3072x768x1600 f32", "TN", 3072, 768, 1600, "f32")]
-CFGS = {"NT": (14, 16, 40, 41, 42), "NN": (14, 30, 40, 41, 42), "TN": (14, 30)}
-EXPS = (0, 4, 2, 6, 1, 5, 7)
+          ("fc wgrad TN 3072x768x1600 f32", "TN", 3072, 768, 1600, "f32"),
+          ("proj wgrad TN 768x3072x1600 f32", "TN", 768, 3072, 1600, "f32"),
+          ("qkv wgrad TN 2304x768x1600 f32", "TN", 2304, 768, 1600, "f32"),
+          ("out wgrad TN 768x768x1600 f32", "TN", 768, 768, 1600, "f32"),
+          ("out fwd NT 1600x768x768 bias+res f32", "NT", 1600, 768, 768, "res"),
+          ("qkv dgrad NN 1600x768x2304 f32", "NN", 1600, 768, 2304, "f32"),
+          ("out dgrad NN 1600x768x768 bf16", "NN", 1600, 768, 768, "bf16")]
+CFGS = {"NT": (14, 16, 43, 30), "NN": (14, 30, 43, 16), "TN": (14, 30, 43, 16)}
+EXPS = (0,)
 
 def plan():
     out = []

@@ -1121,6 +1121,9 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s) {
         case 40: SWAT_DMA_TALL(160, 128, 3) break;
         case 41: SWAT_DMA_TALL(160, 64, 3) break;
         case 42: SWAT_DMA_TALL(160, 128, 2) break;
+        case 46: SWAT_DMA8(64, 64, 3, 2, 4) break;
+        case 47: SWAT_DMA8(64, 64, 4, 2, 4) break;
+        case 48: SWAT_DMA8(64, 64, 6, 2, 4) break;
         case 43: SWAT_DMA(128, 64, 2) break;
         case 44: SWAT_DMA(64, 128, 2) break;
         case 45: SWAT_DMA(64, 64, 2) break;

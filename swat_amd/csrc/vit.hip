@@ -204,7 +204,11 @@ static int dgrad_split(const VitDims& D, const unsigned short* dY, int Kred, con
     S = 1;
     const int64_t base_blocks = (int64_t)((M + 63) / 64) * ((d + 63) / 64);
     if (base_blocks < 600) {
-        for (int cand = 4; cand >= 2; --cand)
+        // Measured on MI355X (ViT-B/32, B = 32, ms/step): split 4: 4.61, 3: 4.54, 2: 4.55, none: 4.43 — since the lean
+        // register-ring kernel took over the deep-K dgrads, the extra fp32 planes cost more than the added workgroups
+        // buy.  The plumbing (planes summed inside the LayerNorm backward) stays for shapes with far fewer tiles.
+        constexpr int kDgradSplitMax = 1;
+        for (int cand = kDgradSplitMax; cand >= 2; --cand)
             if (Kred % cand == 0 && (Kred / cand) % 64 == 0 && Kred / cand >= 512) { S = cand; break; }
     }
     GemmArgs a = G(dY, W, planes, M, d, Kred / S, Kred, d, d, 1);
@@ -290,11 +294,9 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
         {
             // c_proj: K = mlp is 48 k-steps on only ~300 tiles: split the reduction, the next LayerNorm sums the planes
             pending = 1;
-            // (measured on MI355X, B/32 B=32: 5.35 ms/step with the split vs 5.29 without — the extra plane traffic eats the
-            //  gain of the forward direction, unlike the dgrad case — so it stays off; the plumbing is kept for larger K)
-            constexpr bool kFwdSplit = false;
+            constexpr int kFwdSplit = 0;  // re-measured with the current kernels: 2-way split 4.48 vs 4.43 ms/step without
             if (kFwdSplit && (int64_t)((M + 63) / 64) * ((d + 63) / 64) < 600)
-                for (int cand = 4; cand >= 2; --cand)
+                for (int cand = kFwdSplit; cand >= 2; --cand)
                     if (D.mlp % cand == 0 && (D.mlp / cand) % 64 == 0 && D.mlp / cand >= 512) { pending = cand; break; }
             GemmArgs a = G(ga, sh + lo[PRW], pending > 1 ? w.xsplit : xout, M, d, D.mlp / pending, D.mlp, D.mlp, d, 1);
             a.bias = params + lo[PRB]; a.residual = x1; a.epi0 = 1;

@@ -36,11 +36,11 @@ def run(name, lay, m, n, k, epi, cfg, exp=0):
         if sel.sum():
             print(f"   {lab:12s}: n={sel.sum():4d}  main loop {np.median(ml[sel] - st[sel]):5.2f} us (p90 {np.percentile(ml[sel] - st[sel], 90):5.2f})"
                   f"  epilogue {np.median(en[sel] - ml[sel]):5.2f} us (p90 {np.percentile(en[sel] - ml[sel], 90):5.2f})")
+    ids = np.nonzero(buf.cpu().numpy().reshape(-1, 4)[:, 0])[0]
+    print("   xcc of the first 24 workgroups:", xcc[:24].tolist(), " fraction with xcc == id % 8:", float(np.mean(xcc == ids % 8)))
     per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
     print(f"   workgroups per CU: min {per_cu.min()} max {per_cu.max()}  hist {np.bincount(per_cu)}")
-for cfg in (14, 16, 43, 44, 45):
-    run("fc fwd NT 1600x3072x768 dual", "NT", 1600, 3072, 768, "fc", cfg)
-for cfg in (14, 16, 43, 44):
-    run("qkv fwd NT 1600x2304x768", "NT", 1600, 2304, 768, "bias", cfg)
-for cfg in (14, 43, 44):
-    run("proj dgrad NN 1600x3072x768 act'", "NN", 1600, 3072, 768, "actin", cfg)
+run("proj fwd NT 1600x768x3072 res", "NT", 1600, 768, 3072, "res", 14)
+lib.swat_gemm_set_swizzle(0)
+run("proj fwd NT 1600x768x3072 res (plain 2-D grid)", "NT", 1600, 768, 3072, "res", 14)
+lib.swat_gemm_set_swizzle(-1)

@@ -72,13 +72,13 @@ __global__ __launch_bounds__(256) void pull(const unsigned short* __restrict__ A
 
 // generic tile walk: BM x BN tile (rows multiple of 8), NST stages, 4 waves, pieces dealt round-robin, full drain per step
 // replaced by a conservative counted wait (pieces per wave differ by at most one)
-template <int BM, int BN, int NST>
-__global__ __launch_bounds__(256) void pull_tile(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, int M,
+template <int BM, int BN, int NST, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void pull_tile(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, int M,
                                                  int N, int K, unsigned* sink, int reps) {
     extern __shared__ char lds[];
     constexpr int PA = BM / 8, PB = BN / 8, P = PA + PB;      // 1 KB pieces per stage
     constexpr int STAGE = P * 1024;
-    constexpr int MAXP = (P + 3) / 4;
+    constexpr int MAXP = (P + NWV - 1) / NWV;
     const int tiles_n = N / BN;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void pull_tile(const unsigned short* __restric
                 char* dst = lds + (ti % NST) * STAGE;
 #pragma unroll
                 for (int i = 0; i < MAXP; ++i) {
-                    const int pc = wave + 4 * i;
+                    const int pc = wave + NWV * i;
                     if (pc < P) {
                         const bool isA = pc < PA;
                         const int row = (isA ? pc : pc - PA) * 8 + (lane >> 3);
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256) void pull_tile(const unsigned short* __restric
             if (t >= 0) {
                 // stage t must have landed: allow the (NST-1) younger stages' pieces of this wave to fly (upper bound MAXP each
                 // would be unsafe; use the lower bound of pieces per wave so the wait is conservative)
-                if (t + NST - 1 < nk) { if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (P / 4)) : "memory");
-                                        else if (NST == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (P / 4)) : "memory");
-                                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P / 4)) : "memory"); }
+                if (t + NST - 1 < nk) { if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (P / NWV)) : "memory");
+                                        else if (NST == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (P / NWV)) : "memory");
+                                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P / NWV)) : "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -117,16 +117,16 @@ __global__ __launch_bounds__(256) void pull_tile(const unsigned short* __restric
     acc ^= ((unsigned*)lds)[threadIdx.x];
     if (acc == 0x12345678u) sink[0] = 1;
 }
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int NWV = 4>
 static void bench_tile(const char* name, const unsigned short* A, const unsigned short* B, int M, int N, int K, unsigned* sink, int reps) {
     constexpr int STAGE = (BM / 8 + BN / 8) * 1024;
     const int grid = ((M + BM - 1) / BM) * (N / BN);
-    hipFuncSetAttribute((const void*)pull_tile<BM, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE);
+    hipFuncSetAttribute((const void*)pull_tile<BM, BN, NST, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int it = 0; it < 5; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((pull_tile<BM, BN, NST>), dim3(grid), dim3(256), NST * STAGE, 0, A, B, M, N, K, sink, reps);
+        hipLaunchKernelGGL((pull_tile<BM, BN, NST, NWV>), dim3(grid), dim3(64 * NWV), NST * STAGE, 0, A, B, M, N, K, sink, reps);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
@@ -161,14 +161,11 @@ int main(int argc, char** argv) {
         printf("mode %d: %.1f us per GEMM-equivalent pass, %.2f TB/s requested, %.1f GB/s per CU\n", mode, best * 1e3 / reps,
                tile_bytes / (best * 1e-3) / 1e12, tile_bytes / (best * 1e-3) / 1e9 / 256);
     }
-    bench_tile<64, 64, 3>("N=3072 64x64 s3", A, B, M, N, K, sink, reps);
-    bench_tile<80, 128, 3>("N=3072 80x128 s3", A, B, M, N, K, sink, reps);
-    bench_tile<80, 128, 2>("N=3072 80x128 s2", A, B, M, N, K, sink, reps);
-    bench_tile<128, 128, 3>("N=3072 128x128 s3", A, B, M, N, K, sink, reps);
-    bench_tile<160, 128, 3>("N=3072 160x128 s3", A, B, M, N, K, sink, reps);
-    bench_tile<80, 256, 3>("N=3072 80x256 s3", A, B, M, N, K, sink, reps);
-    bench_tile<80, 64, 3>("N=768 80x64 s3", A, B, M, 768, K, sink, reps);
-    bench_tile<80, 64, 6>("N=768 80x64 s6", A, B, M, 768, K, sink, reps);
-    bench_tile<64, 64, 3>("N=768 64x64 s3", A, B, M, 768, K, sink, reps);
+    bench_tile<64, 64, 3, 4>("N=768 64x64 s3 4 waves", A, B, M, 768, K, sink, reps);
+    bench_tile<64, 64, 3, 8>("N=768 64x64 s3 8 waves", A, B, M, 768, K, sink, reps);
+    bench_tile<64, 64, 3, 16>("N=768 64x64 s3 16 waves", A, B, M, 768, K, sink, reps);
+    bench_tile<64, 64, 6, 8>("N=768 64x64 s6 8 waves", A, B, M, 768, K, sink, reps);
+    bench_tile<64, 64, 6, 16>("N=768 64x64 s6 16 waves", A, B, M, 768, K, sink, reps);
+    bench_tile<64, 64, 8, 16>("N=768 64x64 s8 16 waves", A, B, M, 768, K, sink, reps);
     return 0;
 }

@@ -8,7 +8,7 @@ from swat_amd import _lib
 
 dev = torch.device("cuda", 0)
 BS = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-for mode in (0, 2, 2, 0):
+for mode in (2, 2):
     args, model, head, step, sched = bench.build_job(dev, 1, BS, trail=mode == 2)
     _lib.lib().swat_vit_set_overlap(min(mode, 1))
     _lib.lib().swat_gemm_set_exp(int(os.environ.get('SWAT_GEMM_EXP', '0')))

@@ -8,9 +8,9 @@ B = 32 images / GPU, 200 classes, synthetic N(0,1) 224x224 images resident in HB
 normalise + head + scaled mixed CE + backward + (gradient all-reduce over RCCL) + fused AdamW + LR step.
 bf16 MFMA operands, fp32 accumulation / residual stream / master weights.
 
-Prints ONE JSON line (rank 0): whole-job img/s, the MFMA roofline of the GEMM kernels (HIP events around every GEMM
-launch in an instrumented replay of the same steps), a CPU baseline (the fp32 oracle on the host cores, N = 1 only) and,
-as a secondary record, the retrieval scan (path B).
+Prints ONE JSON line (rank 0): whole-job img/s, the MFMA roofline of the GEMM kernels (HIP start/stop events attached to
+every GEMM dispatch in an instrumented replay of the same steps, lanes serialised), a CPU baseline (the fp32 oracle on
+the host cores, N = 1 only) and, as secondary records, the retrieval scan and the dense exact top-k (path B).
 """
 import argparse
 import ctypes
@@ -270,17 +270,18 @@ def main():
                           "parallelism": f"dp{world}" if world > 1 else "single"},
                "final_loss": round(loss, 4),
                "step_mfma_frac": round(GFLOP_PER_IMG_STEP * 1e9 * a.bsz / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    # the instrumented replay runs on every rank (its steps contain the gradient all-reduces); rank 0 reports its own
+    roof = gemm_roofline(args, step, sched, images, labels, min(a.steps, 10), a.bsz, a.overlap)
+    if rank == 0:
+        out["roofline"] = roof
+        out["cpu_baseline"] = None
     if world == 1:
-        out["roofline"] = gemm_roofline(args, step, sched, images, labels, min(a.steps, 10), a.bsz, a.overlap)
         if not a.no_cpu_baseline:
             del step, model
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(a.bsz)
         if not a.no_secondary:
             out["secondary"] = [retrieval_secondary(dev), retrieval_dense_secondary(dev)]
-    elif rank == 0:
-        out["roofline"] = None
-        out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

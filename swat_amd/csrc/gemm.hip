@@ -1094,16 +1094,7 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s, hip
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
         hipExtLaunchKernelGGL((gemm_glds_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, ev0, ev1, 0, b); \
     }
-#define SWAT_DMA_TALL(BM_, BN_, NS_)                                                                     \
-    {                                                                                                     \
-        if constexpr (LAYOUT != L_TN) {  /* 80-row wave slabs: A must be k-contiguous */                  \
-            GemmArgs b = a;                                                                               \
-            dim3 grid = plan_grid(b, BM_, BN_, batch);                                                    \
-            hipExtLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_, 2, 2>), grid, dim3(256), 0, s, ev0, ev1, 0, b); \
-        }                                                                                                 \
-    }
-    if (cfg >= 40 && cfg < 43 && (LAYOUT == L_TN || a.K % 64 != 0 || a.K < 192)) cfg = 20;
-    if (cfg >= 43 && a.K % 64 != 0) cfg = 20;
+    if (cfg == 43 && a.K % 64 != 0) cfg = 20;
     if (cfg >= 25 && cfg <= 28 && a.K % 64 != 0) cfg = 20;
     if (cfg >= 30 && (a.K % 64 != 0 || a.K < 64 * 6)) cfg = 20;  // lean ring needs whole, >= D k-steps
     if (cfg >= 6 && cfg < 20 && a.K % 64 != 0) cfg = (cfg == 6 || (cfg >= 10 && cfg != 14 && cfg != 17 && cfg != 18 && cfg != 19)) ? 1 : (cfg == 8 ? 2 : 0);  // the LDS-DMA kernel has no K tail
@@ -1119,15 +1110,7 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s, hip
         case 11: SWAT_GLDS8(128, 128, 3, 4, 2) break;
         case 12: SWAT_GLDS8(128, 64, 4, 4, 2) break;
         case 13: SWAT_GLDS8(256, 128, 2, 4, 2) break;
-        case 40: SWAT_DMA_TALL(160, 128, 3) break;
-        case 41: SWAT_DMA_TALL(160, 64, 3) break;
-        case 42: SWAT_DMA_TALL(160, 128, 2) break;
-        case 46: SWAT_DMA8(64, 64, 3, 2, 4) break;
-        case 47: SWAT_DMA8(64, 64, 4, 2, 4) break;
-        case 48: SWAT_DMA8(64, 64, 6, 2, 4) break;
         case 43: SWAT_DMA(128, 64, 2) break;
-        case 44: SWAT_DMA(64, 128, 2) break;
-        case 45: SWAT_DMA(64, 64, 2) break;
         case 14: SWAT_DMA(64, 64, 3) break;
         case 15: SWAT_DMA(128, 128, 3) break;
         case 16: SWAT_DMA(128, 64, 3) break;
@@ -1201,7 +1184,7 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     else if (layout == L_NN) rc = launch_gemm<L_NN>(a, batch, tile, s, ev0, ev1);
     else rc = launch_gemm<L_TN>(a, batch, tile, s, ev0, ev1);
     if (prof) {
-        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || (tile >= 10 && tile < 14) || tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43 || tile == 40 || tile == 41 || tile == 42);
+        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || (tile >= 10 && tile < 14) || tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43);
         g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
         ++g_prof.n;
     }

@@ -40,7 +40,10 @@ def run(name, lay, m, n, k, epi, cfg, exp=0):
     print("   xcc of the first 24 workgroups:", xcc[:24].tolist(), " fraction with xcc == id % 8:", float(np.mean(xcc == ids % 8)))
     per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
     print(f"   workgroups per CU: min {per_cu.min()} max {per_cu.max()}  hist {np.bincount(per_cu)}")
+run("fc fwd NT 1600x3072x768 dual", "NT", 1600, 3072, 768, "fc", 14)
+run("fc fwd NT 1600x3072x768 dual", "NT", 1600, 3072, 768, "fc", 43)
+run("qkv fwd NT 1600x2304x768", "NT", 1600, 2304, 768, "bias", 43)
 run("proj fwd NT 1600x768x3072 res", "NT", 1600, 768, 3072, "res", 14)
-lib.swat_gemm_set_swizzle(0)
-run("proj fwd NT 1600x768x3072 res (plain 2-D grid)", "NT", 1600, 768, 3072, "res", 14)
-lib.swat_gemm_set_swizzle(-1)
+run("proj dgrad NN 1600x3072x768 act'", "NN", 1600, 3072, 768, "actin", 43)
+run("fc dgrad NN 1600x768x3072", "NN", 1600, 768, 3072, "f32", 14)
+run("fc wgrad TN 3072x768x1600", "TN", 3072, 768, 1600, "f32", 14)

@@ -19,7 +19,7 @@ SHAPES = [("fc fwd  NT 1600x3072x768 bias+gelu dual bf16", "NT", 1600, 3072, 768
           ("out fwd NT 1600x768x768 bias+res f32", "NT", 1600, 768, 768, "res"),
           ("qkv dgrad NN 1600x768x2304 f32", "NN", 1600, 768, 2304, "f32"),
           ("out dgrad NN 1600x768x768 bf16", "NN", 1600, 768, 768, "bf16")]
-CFGS = {"NT": (14, 46, 47, 48), "NN": (14, 30, 46, 47, 48), "TN": (14, 30, 46, 47, 48)}
+CFGS = {"NT": (14, 16, 43, 30), "NN": (14, 30, 43, 16), "TN": (14, 30, 43, 16)}
 EXPS = (0,)
 
 def plan():

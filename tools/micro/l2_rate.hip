@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void pull(const unsigned short* __restrict__ A
 // replaced by a conservative counted wait (pieces per wave differ by at most one)
 template <int BM, int BN, int NST, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV) void pull_tile(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, int M,
-                                                 int N, int K, unsigned* sink, int reps) {
+                                                 int N, int K, unsigned* sink, int reps, int ld) {
     extern __shared__ char lds[];
     constexpr int PA = BM / 8, PB = BN / 8, P = PA + PB;      // 1 KB pieces per stage
     constexpr int STAGE = P * 1024;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * NWV) void pull_tile(const unsigned short* __re
                         int gr = isA ? tm * BM + row : tn * BN + row;
                         const int R = isA ? M : N;
                         if (gr >= R) gr = R - 1;
-                        dma16((isA ? A : B) + (size_t)gr * K + ti * 64 + kb, dst + pc * 1024);
+                        dma16((isA ? A : B) + (size_t)gr * ld + ti * 64 + kb, dst + pc * 1024);
                     }
                 }
             }
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(64 * NWV) void pull_tile(const unsigned short* __re
     if (acc == 0x12345678u) sink[0] = 1;
 }
 template <int BM, int BN, int NST, int NWV = 4>
-static void bench_tile(const char* name, const unsigned short* A, const unsigned short* B, int M, int N, int K, unsigned* sink, int reps) {
+static void bench_tile(const char* name, const unsigned short* A, const unsigned short* B, int M, int N, int K, unsigned* sink, int reps, int ld = 0) {
+    if (!ld) ld = K;
     constexpr int STAGE = (BM / 8 + BN / 8) * 1024;
     const int grid = ((M + BM - 1) / BM) * (N / BN);
     hipFuncSetAttribute((const void*)pull_tile<BM, BN, NST, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE);
@@ -126,7 +127,7 @@ static void bench_tile(const char* name, const unsigned short* A, const unsigned
     float best = 1e9f;
     for (int it = 0; it < 5; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((pull_tile<BM, BN, NST, NWV>), dim3(grid), dim3(64 * NWV), NST * STAGE, 0, A, B, M, N, K, sink, reps);
+        hipLaunchKernelGGL((pull_tile<BM, BN, NST, NWV>), dim3(grid), dim3(64 * NWV), NST * STAGE, 0, A, B, M, N, K, sink, reps, ld);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
@@ -161,11 +162,18 @@ int main(int argc, char** argv) {
         printf("mode %d: %.1f us per GEMM-equivalent pass, %.2f TB/s requested, %.1f GB/s per CU\n", mode, best * 1e3 / reps,
                tile_bytes / (best * 1e-3) / 1e12, tile_bytes / (best * 1e-3) / 1e9 / 256);
     }
-    bench_tile<64, 64, 3, 4>("N=768 64x64 s3 4 waves", A, B, M, 768, K, sink, reps);
-    bench_tile<64, 64, 3, 8>("N=768 64x64 s3 8 waves", A, B, M, 768, K, sink, reps);
-    bench_tile<64, 64, 3, 16>("N=768 64x64 s3 16 waves", A, B, M, 768, K, sink, reps);
-    bench_tile<64, 64, 6, 8>("N=768 64x64 s6 8 waves", A, B, M, 768, K, sink, reps);
-    bench_tile<64, 64, 6, 16>("N=768 64x64 s6 16 waves", A, B, M, 768, K, sink, reps);
-    bench_tile<64, 64, 8, 16>("N=768 64x64 s8 16 waves", A, B, M, 768, K, sink, reps);
+    // deep-K products: K = 3072 with the natural row stride (6144 B) and with padded strides
+    unsigned short *A2, *B2;
+    hipMalloc(&A2, (size_t)1600 * 3328 * 2); hipMalloc(&B2, (size_t)3072 * 3328 * 2);
+    hipMemset(A2, 1, (size_t)1600 * 3328 * 2); hipMemset(B2, 2, (size_t)3072 * 3328 * 2);
+    bench_tile<64, 64, 3, 4>("N=768 K=3072 ld 3072", A2, B2, M, 768, 3072, sink, reps, 3072);
+    bench_tile<64, 64, 3, 4>("N=768 K=3072 ld 3136 (+128 B)", A2, B2, M, 768, 3072, sink, reps, 3136);
+    bench_tile<64, 64, 3, 4>("N=768 K=3072 ld 3104 (+64 B)", A2, B2, M, 768, 3072, sink, reps, 3104);
+    bench_tile<64, 64, 3, 4>("N=768 K=3072 ld 3200 (+256 B)", A2, B2, M, 768, 3072, sink, reps, 3200);
+    bench_tile<64, 64, 3, 4>("N=768 K=3072 ld 3328 (+512 B)", A2, B2, M, 768, 3072, sink, reps, 3328);
+    bench_tile<64, 64, 3, 4>("N=3072 K=768 ld 768", A2, B2, M, 3072, 768, sink, reps, 768);
+    bench_tile<64, 64, 3, 4>("N=3072 K=768 ld 832 (+128 B)", A2, B2, M, 3072, 768, sink, reps, 832);
+    bench_tile<64, 64, 3, 4>("N=768 K=768 ld 768", A2, B2, M, 768, 768, sink, reps, 768);
+    bench_tile<64, 64, 3, 4>("N=768 K=768 ld 832", A2, B2, M, 768, 768, sink, reps, 832);
     return 0;
 }

@@ -154,6 +154,12 @@ int swat_colsum(const void* X, int dtype, int64_t rows, int n, int ld, float* ou
 int64_t swat_colsum_bf16_workspace_bytes(int n);
 int swat_colsum_bf16(const void* X_bf16, int64_t rows, int n, int ld, float* out, void* workspace,
                      swat_stream_t stream);
+/* A2h  weight gradient and bias gradient of one linear layer (autograd of nn.Linear in the reference):
+ *     dW [n_out, n_in] = dY^T X, dbias [n_out] = column sums of dY; dY [rows, ld_dy], X [rows, ld_x] bf16.
+ *     One launch when rows % 64 == 0 (the GEMM's n-tile-0 workgroups add an MFMA against a ones fragment per k-step),
+ *     else GEMM + the two-stage column sum; workspace: swat_colsum_bf16_workspace_bytes(n_out). */
+int swat_linear_wgrad_bias(const void* dY_bf16, const void* X_bf16, float* dW, float* dbias, int rows, int n_out,
+                           int n_in, int ld_dy, int ld_x, void* workspace, swat_stream_t stream);
 int swat_gather_cast_bf16(const float* in, void* out_bf16, int64_t rows, int d, int64_t group_rows,
                           int64_t group_stride_rows, int64_t row_off, swat_stream_t stream);
 int swat_cast_bf16(const float* in, void* out_bf16, int64_t n, swat_stream_t stream);

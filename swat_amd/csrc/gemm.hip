@@ -788,6 +788,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmArgs
                                              (__attribute__((address_space(3))) void*)(sb + (wave + NW * i) * 1024), 16, 0, 0);
     };
 
+    // bias gradient beside a weight gradient: column sums of A = A^T 1, one MFMA against a ones fragment per k-step
+    const bool do_cs = LAYOUT == L_TN && p.colsum && n0 == 0 && wn0 == 0;
+    const s16x8_t ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
+    f32x4_t accs[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) accs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     f32x4_t acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -846,12 +853,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmArgs
 #pragma unroll
                         for (int j = 0; j < FN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    if (do_cs) {
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accs[i], 0, 0, 0);
+                    }
                 }
             }
         }
     }
     const unsigned long long tr1 = (p.exp & 16) ? wall_clock64() : 0ull;
     if (!(p.exp & 4)) gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+    if (do_cs && (lane >> 4) == 0) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm0 + 16 * i + (lane & 15);
+            if (m < p.M) p.colsum[m] = accs[i][0];
+        }
+    }
     if (p.exp & 16) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         trace_block(p, tr0, tr1);
@@ -954,6 +972,13 @@ __global__ __launch_bounds__(256) void gemm_ring2_kernel(const GemmArgs p) {
         return __builtin_bit_cast(bf16x8_t, v);
     };
 
+    // bias gradient beside a weight gradient: column sums of A = A^T 1, one MFMA against a ones fragment per k-step
+    const bool do_cs = LAYOUT == L_TN && p.colsum && n0 == 0 && wn0 == 0;
+    const s16x8_t ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
+    f32x4_t accs[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) accs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     f32x4_t acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -989,6 +1014,10 @@ __global__ __launch_bounds__(256) void gemm_ring2_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accs[i], 0, 0, 0);
+            }
         }
     };
 
@@ -1027,6 +1056,13 @@ __global__ __launch_bounds__(256) void gemm_ring2_kernel(const GemmArgs p) {
         }
     }
     if (!(p.exp & 4)) gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
+    if (do_cs && (lane >> 4) == 0) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm0 + 16 * i + (lane & 15);
+            if (m < p.M) p.colsum[m] = accs[i][0];
+        }
+    }
 }
 
 static int g_exp = 0;
@@ -1175,6 +1211,11 @@ static GemmProf g_prof;
 
 int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     const int tile = pick_cfg(layout, a, batch);
+    if (a.colsum) {
+        const bool lean = tile == 14 || (tile >= 15 && tile <= 19) || (tile >= 25 && tile <= 28) || (tile >= 30 && tile <= 34) || tile == 43;
+        SWAT_REQUIRE(layout == L_TN && batch == 1 && lean && a.K % 64 == 0 && a.K >= 384,
+                     "gemm: fused column sums need a TN product on one of the lean kernels (tile %d)", tile);
+    }
     const bool prof = g_prof.on && g_prof.n < g_prof.cap;
     // profiling: the events ride on the kernel's own dispatch packet (hipExtLaunchKernel), so their difference is the
     // kernel's execution time as rocprofv3 reports it, without the ~2-3 us each separately recorded event adds

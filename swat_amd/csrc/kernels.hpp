@@ -27,6 +27,8 @@ struct GemmArgs {
     // XCD-aware tile order (filled by the launcher): 0 = 2-D grid as is; 1 / 2 = 1-D grid, consecutive tiles of one
     // XCD walk M first / N first, so the tiles an XCD's L2 serves share operand panels.
     int swz, tiles_m, tiles_n;
+    float* colsum;  // TN only, lean kernels: colsum[m] = sum_k A[k, m] (the bias gradient that goes with a weight gradient
+                    // dW = dY^T X), produced by the n-tile-0 workgroups with one extra MFMA against a ones fragment per k-step
     int epi0;  // split-K: apply bias / residual / rowbias on batch slice 0 only (the other slices are raw partial planes)
     int exp;  // tuning experiments (bit 0: no loads after the prologue, bit 1: no MFMA, bit 2: no epilogue); 0 in production
 };

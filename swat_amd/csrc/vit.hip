@@ -219,6 +219,24 @@ static int dgrad_split(const VitDims& D, const unsigned short* dY, int Kred, con
 }  // namespace swat
 using namespace swat;
 
+// dW = dY^T X and db = column sums of dY in one launch when the reduction (rows) is a whole number of 64-deep k-steps
+// (the lean TN kernels add one MFMA against a ones fragment per k-step in their n-tile-0 workgroups); otherwise the
+// two-stage column-sum kernels run beside the GEMM.  workspace: swat_colsum_bf16_workspace_bytes(n_out).
+SWAT_API int swat_linear_wgrad_bias(const void* dY_bf16, const void* X_bf16, float* dW, float* dbias, int rows, int n_out,
+                                    int n_in, int ld_dy, int ld_x, void* workspace, swat_stream_t stream) {
+    SWAT_REQUIRE(dY_bf16 && X_bf16 && dW && dbias, "swat_linear_wgrad_bias: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs a = G(dY_bf16, X_bf16, dW, n_out, n_in, rows, ld_dy, ld_x, n_in, 1);
+    const bool fused = rows % 64 == 0 && rows >= 384;
+    if (fused) a.colsum = dbias;
+    TRY(gemm_dispatch(L_TN, a, 1, s));
+    if (!fused) {
+        SWAT_REQUIRE(workspace, "swat_linear_wgrad_bias: workspace is null");
+        TRY(swat_colsum_bf16(dY_bf16, rows, n_out, ld_dy, dbias, workspace, s));
+    }
+    return 0;
+}
+
 SWAT_API int64_t swat_vit_workspace_bytes(const int32_t* dims) {
     VitDims D;
     if (parse_dims(dims, D)) return -1;
@@ -449,8 +467,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             }
             // c_fc: dW = dF^T h2, db = colsum(dF), dh2 = dF W
             to_lane();
-            TRY(gemm_dispatch(L_TN, G(w.dfb, h2, grads + lo[FCW], mlp, d, M, mlp, d, d, 1), 1, ws));
-            TRY(swat_colsum_bf16(w.dfb, M, mlp, mlp, grads + lo[FCB], w.csws, ws));
+            TRY(swat_linear_wgrad_bias(w.dfb, h2, grads + lo[FCW], grads + lo[FCB], M, mlp, d, mlp, d, w.csws, ws));
             lane_done(doneF);
             int S2 = 1;
             TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
@@ -469,8 +486,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s));
             // in_proj: dW = dqkv^T h1, db = colsum(dqkv), dh1 = dqkv W
             to_lane();
-            TRY(gemm_dispatch(L_TN, G(w.dqkv, h1, grads + lo[QKVW], 3 * d, d, M, 3 * d, d, d, 1), 1, ws));
-            TRY(swat_colsum_bf16(w.dqkv, M, 3 * d, 3 * d, grads + lo[QKVB], w.csws, ws));
+            TRY(swat_linear_wgrad_bias(w.dqkv, h1, grads + lo[QKVW], grads + lo[QKVB], M, 3 * d, d, 3 * d, d, w.csws, ws));
             lane_done(doneQ);
             int S1 = 1;
             TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));

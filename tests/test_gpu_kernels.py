@@ -66,6 +66,23 @@ def test_gemm_tn_wgrad(M, N, K):
     close(dw, dy.float().t() @ x.float(), False, M)
 
 
+@pytest.mark.parametrize("M,N,K", [(1600, 3072, 768), (1600, 2304, 768), (1600, 768, 768), (448, 192, 128), (100, 72, 96),
+                                   (8224, 1024, 1024)])
+def test_linear_wgrad_bias(M, N, K):
+    """dW and the bias gradient of one linear layer: fused into the TN GEMM (rows % 64 == 0) or GEMM + column sums."""
+    from swat_amd import _lib
+    lib = _lib.lib()
+    dy, x = rnd(M, N, seed=8, dtype=BF), rnd(M, K, seed=9, dtype=BF)
+    dw = torch.empty(N, K, device=dy.device)
+    db = torch.full((N,), float("nan"), device=dy.device)
+    ws = torch.empty(lib.swat_colsum_bf16_workspace_bytes(N), dtype=torch.uint8, device=dy.device)
+    _lib.check(lib.swat_linear_wgrad_bias(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), M, N, K, N, K, _lib.ptr(ws),
+                                          _lib.stream()), "swat_linear_wgrad_bias")
+    close(dw, dy.float().t() @ x.float(), False, M)
+    ref = dy.float().sum(0)
+    assert (db - ref).abs().max().item() <= 1e-5 * math.sqrt(M) * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
 def test_gemm_epilogues(act):
     from swat_amd import ops

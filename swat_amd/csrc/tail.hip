@@ -129,11 +129,93 @@ __global__ void ce_finish_kernel(const float* __restrict__ per_loss, const float
 }  // namespace swat
 using namespace swat;
 
+// ---- the two shapes the finetuning tail actually uses, each with the memory-contiguous dimension across the lanes ----
+// (a) B n-contiguous (sbn == 1):  C[m, n] = sum_k A[m, k] B[k, n].  64 columns x 16 k-groups per workgroup, 4 rows of A
+//     per workgroup so a B element is loaded once for 4 outputs; the A operands are wave-uniform (scalar loads).
+__global__ __launch_bounds__(1024) void sgemm_small_ncontig_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                   float* __restrict__ C, int M, int N, int K, int64_t sam,
+                                                                   int64_t sak, int64_t sbk, int64_t ldc, float alpha,
+                                                                   int accumulate) {
+    __shared__ float sh[16][4][64];
+    const int t = threadIdx.x & 63;
+    const int n = blockIdx.x * 64 + t;
+    const int m0 = blockIdx.y * 4;
+    const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // k-group, wave-uniform
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nn = n < N ? n : N - 1;
+    const float* a[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = A + (int64_t)(m0 + r < M ? m0 + r : M - 1) * sam;
+#pragma unroll 4
+    for (int k = j; k < K; k += 16) {
+        const float b = B[(int64_t)k * sbk + nn];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fmaf(a[r][(int64_t)k * sak], b, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[j][r][t] = acc[r];
+    __syncthreads();
+    if (j < 4 && n < N && m0 + j < M) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += sh[q][j][t];  // fixed order
+        float* c = C + (int64_t)(m0 + j) * ldc + n;
+        *c = accumulate ? *c + alpha * v : alpha * v;
+    }
+}
+
+// (b) A and B k-contiguous (sak == sbk == 1):  C[m, n] = <A[m, :], B[n, :]>.  One wave per column n keeps B's row in
+//     registers (K <= 1024) and walks the rows of A with the lanes along k; wave-level reduction per output.
+__global__ __launch_bounds__(256) void sgemm_small_kcontig_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                  float* __restrict__ C, int M, int N, int K, int64_t sam,
+                                                                  int64_t sbn, int64_t ldc, float alpha, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float b[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int k = lane + 64 * q;
+        b[q] = k < K ? B[(int64_t)n * sbn + k] : 0.f;
+    }
+    for (int m0 = 0; m0 < M; m0 += 8) {  // 8 rows of A in flight: one memory latency per 8 outputs
+        float av[8][16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float* a = A + (int64_t)(m0 + r < M ? m0 + r : M - 1) * sam;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = lane + 64 * q;
+                av[r][q] = k < K ? a[k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc = fmaf(av[r][q], b[q], acc);
+            acc = wave_sum(acc);
+            if (lane == 0 && m0 + r < M) {
+                float* c = C + (int64_t)(m0 + r) * ldc + n;
+                *c = accumulate ? *c + alpha * acc : alpha * acc;
+            }
+        }
+    }
+}
+
 SWAT_API int swat_sgemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak,
                               int64_t sbk, int64_t sbn, int64_t ldc, float alpha, int accumulate, swat_stream_t s) {
     if (M <= 0 || N <= 0) return 0;
-    hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 63) / 64, M), dim3(256), 0, (hipStream_t)s, A, B, C, M, N, K,
-                       sam, sak, sbk, sbn, ldc, alpha, accumulate);
+    if (sbn == 1 && K >= 64) {
+        hipLaunchKernelGGL(sgemm_small_ncontig_kernel, dim3((N + 63) / 64, (M + 3) / 4), dim3(1024), 0, (hipStream_t)s, A, B, C, M,
+                           N, K, sam, sak, sbk, ldc, alpha, accumulate);
+    } else if (sak == 1 && sbk == 1 && K <= 1024 && M <= 256) {
+        hipLaunchKernelGGL(sgemm_small_kcontig_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)s, A, B, C, M, N, K, sam, sbn,
+                           ldc, alpha, accumulate);
+    } else {
+        hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 63) / 64, M), dim3(256), 0, (hipStream_t)s, A, B, C, M, N, K, sam, sak,
+                           sbk, sbn, ldc, alpha, accumulate);
+    }
     return check_launch("swat_sgemm_small");
 }
 

@@ -33,6 +33,14 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
+def vit_gflop_per_img(d, L, T, patch_cols, embed, mlp_ratio=4):
+    """fwd + bwd matmul flops of one image (3 x forward; the patch embedding has no data gradient), as SURVEY 8(d) counts."""
+    per_tok = 2 * d * (3 * d) + 2 * d * d + 2 * 2 * d * (mlp_ratio * d)         # qkv, out, fc, proj
+    attn = 2 * 2 * T * d                                                        # QK^T and PV per token
+    fwd = L * T * (per_tok + attn) + 2 * (T - 1) * patch_cols * d + 2 * d * embed
+    return round(3 * fwd / 1e9 - 2 * (T - 1) * patch_cols * d / 1e9, 3)
+
+
 class _Lg:
     handlers = []
 
@@ -181,6 +189,28 @@ def retrieval_secondary(dev, steps=5):
                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(ms_sim, 4)}}
 
 
+def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=8, warmup=3):
+    """The same fused step on another BASELINE config (configs[2] ViT-B/16, configs[4] ViT-L/14), one GPU, B = 32."""
+    args, model, head, step, sched = build_job(dev, 1, bsz, arch=arch)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    images = torch.randn(bsz, 3, 224, 224, device=dev, generator=g)
+    labels = torch.randint(0, 200, (bsz,), device=dev, generator=g)
+    run_steps(args, step, sched, images, labels, warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args, step, sched, images, labels, steps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert math.isfinite(step.loss.item()), "training diverged"
+    del step, model, head
+    torch.cuda.empty_cache()
+    return {"metric": f"finetune img/s ({arch} bsz={bsz})", "value": round(bsz / dt, 1), "unit": "img/s",
+            "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "config": {"workload": f"{arch} (random init) --method cutmix finetune step, 200 classes, one GPU"},
+            "step_mfma_frac": round(gflop_per_img * 1e9 * bsz / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_gflop_per_img": gflop_per_img}
+
+
 def retrieval_dense_secondary(dev, steps=3):
     """BASELINE config 4 on one shard: N_query = 200 random unit queries against 1.25 M x 512 fp32 rows (the per-GPU share
     of 10 M), k = 500, exact (value desc, row asc) top-k on the fp32 matrix cores (157.3 TF peak)."""
@@ -281,7 +311,9 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(a.bsz)
         if not a.no_secondary:
-            out["secondary"] = [retrieval_secondary(dev), retrieval_dense_secondary(dev)]
+            out["secondary"] = [retrieval_secondary(dev), retrieval_dense_secondary(dev),
+                                finetune_secondary(dev, "ViT-B-16", vit_gflop_per_img(768, 12, 197, 3 * 16 * 16, 512)),
+                                finetune_secondary(dev, "ViT-L-14", vit_gflop_per_img(1024, 24, 257, 3 * 14 * 14, 768))]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

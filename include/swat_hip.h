@@ -197,7 +197,9 @@ int swat_ce_mixed(const float* z, const float* logit_scale_dev, const int64_t* y
  *     positional_embedding, ln_pre.{w,b}, ln_post.{w,b}, proj, then per block ln_1.{w,b},
  *     attn.in_proj_{weight,bias}, attn.out_proj.{weight,bias}, ln_2.{w,b}, mlp.c_fc.{weight,bias},
  *     mlp.c_proj.{weight,bias}.  params = fp32 master, shadow_bf16 = bf16 copy at the same offsets.
- *     perm/x1..y2: CutMix permutation and box (ref utils/training.py:1462-1466), perm NULL = none. */
+ *     perm/x1..y2: CutMix permutation and box (ref utils/training.py:1462-1466), perm NULL = none.
+ *     workspace: swat_vit_workspace_bytes(dims) bytes, ZEROED ONCE by the caller before its first use (the buffers a
+ *     weight gradient reduces over are padded to a multiple of 64 rows; the kernels never write the padding). */
 int64_t swat_vit_workspace_bytes(const int32_t* dims);
 int swat_vit_forward(const int32_t* dims, const int64_t* offs, const float* params,
                      const void* shadow_bf16, const float* images, const int64_t* perm, int x1, int x2,

@@ -205,7 +205,7 @@ class VisionTransformer(nn.Module):
             nbytes = _lib.lib().swat_vit_workspace_bytes(dims)
             if nbytes < 0:
                 raise _lib.SwatHipError("swat_vit_workspace_bytes: unsupported model dimensions")
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)  # zero once: the row padding of the wgrad operands must read as 0
             self._ws[key] = ws
         return ws
 

@@ -1191,12 +1191,20 @@ static int pick_cfg(int layout, const GemmArgs& a, int batch) {
     // register ring (30) for the deep-K dgrad / small wgrad products; everything ragged goes to the staged ring (20).
     const bool whole = a.K % 64 == 0;
     if (!whole || batch > 1) return a.K % 64 == 0 && batch > 1 ? 14 : 20;
-    if (layout == L_NT) return (a.N >= 2048 && a.K <= 1024 && a.M >= 128) ? 43 : 14;
+    // thousands of rows (ViT-B/16: 6 304, ViT-L/14: 8 224 at B = 32) fill several rounds with any tile: there the
+    // 128-wide tiles' lower operand traffic wins the deep-K products (register ring 128x128 / 128x64) and the wgrads
+    const bool many_rows = (layout == L_TN ? a.K : a.M) >= 4096;
+    if (layout == L_NT) {
+        if (a.N >= 2048 && a.K <= 1024 && a.M >= 128) return 43;
+        return many_rows && a.K >= 2048 ? 33 : 14;
+    }
     if (layout == L_NN) {
         if (a.N >= 2048 && a.K <= 1024 && a.M >= 128) return 43;
+        if (many_rows && a.K >= 2048) return 32;
         return a.K >= 384 ? 30 : 14;
     }
-    return ((int64_t)a.M * a.N >= (1 << 21)) ? 14 : (a.K >= 384 ? 30 : 14);
+    if ((int64_t)a.M * a.N >= (1 << 21)) return many_rows ? 16 : 14;
+    return a.K >= 384 ? 30 : 14;
 }
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around every GEMM ----

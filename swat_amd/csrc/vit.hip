@@ -25,6 +25,7 @@ __global__ void pad_cast_rows_kernel(const float* __restrict__ in, unsigned shor
 struct VitDims {
     int B, img, patch, d, L, H, mlp, E, act, save;
     int g, T, M, Kp, ldk, dh, ldp;
+    int Mp;  // M rounded up to 64: row count of every buffer a weight gradient reduces over (pad rows stay zero)
 };
 
 static int parse_dims(const int32_t* v, VitDims& D) {
@@ -32,7 +33,7 @@ static int parse_dims(const int32_t* v, VitDims& D) {
     D.save = v[9];
     if (D.B <= 0 || D.patch <= 0 || D.img % D.patch || D.d % 64 || D.H <= 0 || D.d % D.H || D.L <= 0 || D.L > 64) return -1;
     D.g = D.img / D.patch; D.T = D.g * D.g + 1; D.M = D.B * D.T; D.Kp = 3 * D.patch * D.patch; D.ldk = (D.Kp + 7) / 8 * 8;
-    D.dh = D.d / D.H; D.ldp = (D.T + 7) / 8 * 8;
+    D.dh = D.d / D.H; D.ldp = (D.T + 7) / 8 * 8; D.Mp = (D.M + 63) / 64 * 64;
     if (D.dh % 8) return -1;
     return 0;
 }
@@ -89,7 +90,7 @@ static VitWs carve(const VitDims& D, void* base) {
         off += (bytes + 255) / 256 * 256;
         return r;
     };
-    const int64_t M = D.M, d = D.d, Ls = D.save ? D.L : 1;
+    const int64_t M = D.M, Mp = D.Mp, d = D.d, Ls = D.save ? D.L : 1;
     const int64_t pbytes = (int64_t)D.B * D.H * D.T * D.ldp;
     w.patches = (unsigned short*)take((int64_t)D.B * D.g * D.g * D.ldk * 2);
     w.convw = (unsigned short*)take((int64_t)d * D.ldk * 2);
@@ -99,13 +100,15 @@ static VitWs carve(const VitDims& D, void* base) {
     w.u = (float*)take((int64_t)D.B * d * 4);
     w.xs = (float*)take((D.save ? D.L + 1 : 2) * M * d * 4);
     w.x1 = (float*)take(Ls * M * d * 4);
-    w.h1 = (unsigned short*)take(Ls * M * d * 2);
-    w.h2 = (unsigned short*)take(Ls * M * d * 2);
-    w.a = (unsigned short*)take(Ls * M * d * 2);
+    // operands of the weight-gradient GEMMs (reduction over rows) carry Mp rows per layer: the lean TN kernels take
+    // whole 64-deep k-steps only, and rows M..Mp-1 are never written (the workspace is zero-initialised once)
+    w.h1 = (unsigned short*)take(Ls * Mp * d * 2);
+    w.h2 = (unsigned short*)take(Ls * Mp * d * 2);
+    w.a = (unsigned short*)take(Ls * Mp * d * 2);
     w.qkv = (unsigned short*)take(Ls * M * 3 * d * 2);
     w.P = (unsigned short*)take(Ls * pbytes * 2);
     w.f = (unsigned short*)take(Ls * M * D.mlp * 2);
-    w.gact = (unsigned short*)take(Ls * M * D.mlp * 2);
+    w.gact = (unsigned short*)take(Ls * Mp * D.mlp * 2);
     w.mean1 = (float*)take(Ls * M * 4); w.rstd1 = (float*)take(Ls * M * 4);
     w.mean2 = (float*)take(Ls * M * 4); w.rstd2 = (float*)take(Ls * M * 4);
     w.S = (float*)take(pbytes * 4);
@@ -113,12 +116,12 @@ static VitWs carve(const VitDims& D, void* base) {
     if (D.save) {
         w.dS = (unsigned short*)take(pbytes * 2);
         w.dx = (float*)take(M * d * 4);
-        w.dxb = (unsigned short*)take(M * d * 2);
-        w.dxb2 = (unsigned short*)take(M * d * 2);
+        w.dxb = (unsigned short*)take(Mp * d * 2);
+        w.dxb2 = (unsigned short*)take(Mp * d * 2);
         w.dh = (float*)take(4 * M * d * 4);  // up to 4 split-K partial planes of the dgrad that feeds a LayerNorm backward
-        w.dfb = (unsigned short*)take(M * D.mlp * 2);
+        w.dfb = (unsigned short*)take(Mp * D.mlp * 2);
         w.dab = (unsigned short*)take(M * d * 2);
-        w.dqkv = (unsigned short*)take(M * 3 * d * 2);
+        w.dqkv = (unsigned short*)take(Mp * 3 * d * 2);
         w.du = (float*)take((int64_t)D.B * d * 4);
         w.lnws = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
         w.csws = take(swat_colsum_bf16_workspace_bytes(D.mlp > 3 * D.d ? D.mlp : 3 * D.d));
@@ -279,13 +282,13 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
         float* xin = w.xs + (D.save ? (int64_t)l : (int64_t)(l & 1)) * M * d;
         float* xout = w.xs + (D.save ? (int64_t)(l + 1) : (int64_t)((l + 1) & 1)) * M * d;
         float* x1 = w.x1 + li * M * d;
-        unsigned short* h1 = w.h1 + li * M * d;
-        unsigned short* h2 = w.h2 + li * M * d;
-        unsigned short* at = w.a + li * M * d;
+        unsigned short* h1 = w.h1 + li * (int64_t)D.Mp * d;
+        unsigned short* h2 = w.h2 + li * (int64_t)D.Mp * d;
+        unsigned short* at = w.a + li * (int64_t)D.Mp * d;
         unsigned short* qkv = w.qkv + li * M * 3 * d;
         unsigned short* P = w.P + li * (int64_t)D.B * D.H * T * D.ldp;
         unsigned short* f = w.f + li * (int64_t)M * D.mlp;
-        unsigned short* ga = w.gact + li * (int64_t)M * D.mlp;
+        unsigned short* ga = w.gact + li * (int64_t)D.Mp * D.mlp;
         // A2c: ln_1 -> packed QKV projection
         TRY(swat_layernorm_fwd_split(pending > 1 ? w.xsplit : xin, d, pending, (int64_t)M * d, xin, params + lo[LN1W], params + lo[LN1B], h1,
                                      nullptr, w.mean1 + li * M, w.rstd1 + li * M, M, d, eps, s));
@@ -447,16 +450,16 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             const int64_t* lo = O.layer + 12 * l;
             const float* xin = w.xs + (int64_t)l * M * d;
             const float* x1 = w.x1 + (int64_t)l * M * d;
-            const unsigned short* h1 = w.h1 + (int64_t)l * M * d;
-            const unsigned short* h2 = w.h2 + (int64_t)l * M * d;
-            const unsigned short* at = w.a + (int64_t)l * M * d;
+            const unsigned short* h1 = w.h1 + (int64_t)l * D.Mp * d;
+            const unsigned short* h2 = w.h2 + (int64_t)l * D.Mp * d;
+            const unsigned short* at = w.a + (int64_t)l * D.Mp * d;
             const unsigned short* qkv = w.qkv + (int64_t)l * M * 3 * d;
             const unsigned short* P = w.P + (int64_t)l * D.B * D.H * T * D.ldp;
             const unsigned short* f = w.f + (int64_t)l * M * mlp;
-            const unsigned short* ga = w.gact + (int64_t)l * M * mlp;
+            const unsigned short* ga = w.gact + (int64_t)l * D.Mp * mlp;
             // c_proj: dW = dx^T g, db = colsum(dx), dF = (dx W) * act'(F)
             to_lane();
-            TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, M, d, mlp, mlp, 1), 1, ws));
+            TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, D.Mp, d, mlp, mlp, 1), 1, ws));  // reduction over Mp rows (pad rows are zero)
             lane_done(doneA);
             // (c_proj bias gradient = column sums of dx: produced by the LayerNorm backward that wrote dx)
             wait_lane(doneF);
@@ -467,7 +470,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             }
             // c_fc: dW = dF^T h2, db = colsum(dF), dh2 = dF W
             to_lane();
-            TRY(swat_linear_wgrad_bias(w.dfb, h2, grads + lo[FCW], grads + lo[FCB], M, mlp, d, mlp, d, w.csws, ws));
+            TRY(swat_linear_wgrad_bias(w.dfb, h2, grads + lo[FCW], grads + lo[FCB], D.Mp, mlp, d, mlp, d, w.csws, ws));
             lane_done(doneF);
             int S2 = 1;
             TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
@@ -477,7 +480,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                                    w.dx, d, w.dxb2, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], w.lnws, M, d, s));
             // out_proj: dW = dx1^T a, db = colsum(dx1), da = dx1 W
             to_lane();
-            TRY(gemm_dispatch(L_TN, G(w.dxb2, at, grads + lo[OUTW], d, d, M, d, d, d, 1), 1, ws));
+            TRY(gemm_dispatch(L_TN, G(w.dxb2, at, grads + lo[OUTW], d, d, D.Mp, d, d, d, 1), 1, ws));
             lane_done(doneB);
             // (out_proj bias gradient: produced by the ln_2 backward above)
             TRY(gemm_dispatch(L_NN, G(w.dxb2, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
@@ -486,7 +489,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s));
             // in_proj: dW = dqkv^T h1, db = colsum(dqkv), dh1 = dqkv W
             to_lane();
-            TRY(swat_linear_wgrad_bias(w.dqkv, h1, grads + lo[QKVW], grads + lo[QKVB], M, 3 * d, d, 3 * d, d, w.csws, ws));
+            TRY(swat_linear_wgrad_bias(w.dqkv, h1, grads + lo[QKVW], grads + lo[QKVB], D.Mp, 3 * d, d, 3 * d, d, w.csws, ws));
             lane_done(doneQ);
             int S1 = 1;
             TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));

@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
 TINY = (64, 16, 128, 2, 2, 64, "quick_gelu")  # image, patch, width, layers, heads, embed, act
 TINY_GELU = (56, 14, 128, 2, 2, 64, "gelu")   # patch 14: 3*14*14 = 588 columns (not a multiple of 8) like ViT-L/14
 B32 = (224, 32, 768, 12, 12, 512, "quick_gelu")
+B16 = (224, 16, 768, 12, 12, 512, "gelu")      # BASELINE config 3: T = 197 (ragged against the 64-wide tiles)
+L14 = (224, 14, 1024, 24, 16, 768, "gelu")     # BASELINE config 5: T = 257, 24 blocks, patch columns 588
 
 
 def dev():
@@ -45,7 +47,7 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
 
 
-@pytest.mark.parametrize("cfg,B", [(TINY, 5), (TINY_GELU, 3), (B32, 4)])
+@pytest.mark.parametrize("cfg,B", [(TINY, 5), (TINY_GELU, 3), (B32, 4), (B16, 2), (L14, 2)])
 def test_forward_backward_match_oracle(cfg, B):
     ref, mine = make_pair(cfg)
     g = torch.Generator().manual_seed(1)

@@ -189,6 +189,13 @@ int swat_ce_mixed(const float* z, const float* logit_scale_dev, const int64_t* y
                   float lam, float* per_sample_ws, float* loss, float* dlogit_scale, float* dz,
                   float* logits_out, double* loss_accum, int B, int C, swat_stream_t stream);
 
+/* A2d  nn.MultiheadAttention core for short sequences (T <= 64, head width 64: ViT-B/32 at 224 px has T = 50): one
+ *     workgroup per (image, head) does QK^T, softmax, PV on the matrix cores; the backward recomputes P from Q and K.
+ *     qkv [B*T, 3d] packed as in_proj leaves it, out / dout [B*T, d], dqkv [B*T, 3d]; all bf16. */
+int swat_attn_fwd_small(const void* qkv_bf16, void* out_bf16, int B, int T, int d, int H, swat_stream_t stream);
+int swat_attn_bwd_small(const void* qkv_bf16, const void* dout_bf16, void* dqkv_bf16, int B, int T, int d, int H,
+                        swat_stream_t stream);
+
 /* A2 (whole)  model.encode_image(images) as one call: CutMix-aware patch embed, cls/pos, ln_pre, L
  *     pre-LN blocks, ln_post(cls), proj -> feats [B,E] fp32 (un-normalised).
  *     dims (HOST int32[10]): B, image_size, patch, width d, layers L, heads H, mlp width, embed E,

@@ -148,6 +148,7 @@ static GemmArgs G(const void* A, const void* B, void* C, int M, int N, int K, in
 static int attn_forward(const VitDims& D, const unsigned short* qkv, float* S, unsigned short* P, unsigned short* out,
                         hipStream_t s, int causal = 0) {
     const int T = D.T, d = D.d, dh = D.dh, H = D.H, ldp = D.ldp;
+    if (T <= 64 && dh == 64 && !causal) return swat_attn_fwd_small(qkv, out, D.B, T, d, H, s);  // one workgroup per head
     GemmArgs a = G(qkv, qkv + d, S, T, T, dh, 3 * d, 3 * d, ldp, 1);
     a.inner = H; a.sA0 = (int64_t)T * 3 * d; a.sA1 = dh; a.sB0 = a.sA0; a.sB1 = dh; a.sC0 = (int64_t)H * T * ldp; a.sC1 = (int64_t)T * ldp;
     TRY(gemm_dispatch(L_NT, a, D.B * H, s));
@@ -160,6 +161,7 @@ static int attn_forward(const VitDims& D, const unsigned short* qkv, float* S, u
 static int attn_backward(const VitDims& D, const unsigned short* qkv, const unsigned short* P, const unsigned short* dout,
                          float* dP, unsigned short* dS, unsigned short* dqkv, hipStream_t s) {
     const int T = D.T, d = D.d, dh = D.dh, H = D.H, ldp = D.ldp, BH = D.B * D.H;
+    if (T <= 64 && dh == 64) return swat_attn_bwd_small(qkv, dout, dqkv, D.B, T, d, H, s);  // recomputes P from Q, K
     const int64_t sP0 = (int64_t)H * T * ldp, sP1 = (int64_t)T * ldp, sQ0 = (int64_t)T * 3 * d, sO0 = (int64_t)T * d;
     {   // dV = P^T dO
         GemmArgs a = G(P, dout, dqkv + 2 * d, T, dh, T, ldp, d, 3 * d, 0);

@@ -130,6 +130,32 @@ def test_attention_as_batched_gemms(B, H, T, dh):
     assert (got - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("B,H,T", [(2, 12, 50), (3, 4, 64), (2, 3, 17), (1, 2, 1), (32, 12, 50)])
+def test_attention_one_workgroup_per_head(B, H, T):
+    """T <= 64, head width 64: QK^T / softmax / PV and the whole backward in one workgroup per (image, head), vs torch
+    autograd in fp32 (same tolerances as the batched-GEMM form) — and within bf16 rounding of that form."""
+    from swat_amd import _lib, attention
+    lib = _lib.lib()
+    dh, d = 64, H * 64
+    qkv = rnd(B * T, 3 * d, seed=21, dtype=BF)
+    do = rnd(B * T, d, seed=22, dtype=BF)
+    out = torch.full((B * T, d), float("nan"), device=qkv.device, dtype=BF)
+    dqkv = torch.full((B * T, 3 * d), float("nan"), device=qkv.device, dtype=BF)
+    _lib.check(lib.swat_attn_fwd_small(_lib.ptr(qkv), _lib.ptr(out), B, T, d, H, _lib.stream()), "swat_attn_fwd_small")
+    _lib.check(lib.swat_attn_bwd_small(_lib.ptr(qkv), _lib.ptr(do), _lib.ptr(dqkv), B, T, d, H, _lib.stream()), "swat_attn_bwd_small")
+    q, k, v = [t.reshape(B, T, H, dh).permute(0, 2, 1, 3).float().requires_grad_(True) for t in qkv.float().split(d, dim=1)]
+    p = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+    assert (out.float() - o).abs().max().item() <= 2.0 ** -7 * o.abs().max().item() + 1e-3
+    o.backward(do.float())
+    ref = torch.cat([g.grad.permute(0, 2, 1, 3).reshape(B * T, d) for g in (q, k, v)], dim=1)
+    assert (dqkv.float() - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 1e-3
+    out2, P = attention.attn_fwd(qkv, B, T, H, dh)
+    dqkv2 = attention.attn_bwd(qkv, P, do, B, T, H, dh)
+    assert (out.float() - out2.float()).abs().max().item() <= 2.0 ** -7 * o.abs().max().item()
+    assert (dqkv.float() - dqkv2.float()).abs().max().item() <= 0.02 * ref.abs().max().item() + 1e-3
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_softmax_kernels(causal):
     from swat_amd import ops

@@ -345,7 +345,7 @@ struct SideLane {
     hipStream_t st = nullptr;
     std::vector<hipEvent_t> ev;  // ring: an event is re-recorded only ~a whole backward later
     size_t used = 0;
-    hipEvent_t doneA = nullptr, doneB = nullptr, doneF = nullptr, doneQ = nullptr;  // last lane read of dxb / dxb2 / dfb / dqkv
+    hipEvent_t doneA = nullptr, doneB = nullptr;  // last lane read of {dxb, dfb} / {dxb2, dqkv}
     bool open = false;           // lane work issued and not joined yet
     hipEvent_t next() {
         if (ev.size() < 1024) {
@@ -392,7 +392,7 @@ SWAT_API int swat_vit_backward_join(swat_stream_t stream) {
     hipEventRecord(e, g_side.st);
     hipStreamWaitEvent((hipStream_t)stream, e, 0);
     g_side.open = false;
-    g_side.doneA = g_side.doneB = g_side.doneF = g_side.doneQ = nullptr;
+    g_side.doneA = g_side.doneB = nullptr;
     return 0;
 }
 
@@ -415,7 +415,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
     const bool fork = g_overlap != 0;
     if (fork) SWAT_REQUIRE(g_side.ensure() == 0, "swat_vit_backward: cannot create the weight-gradient stream");
     hipStream_t ws = fork ? g_side.st : s;  // weight-gradient lane
-    hipEvent_t &doneA = g_side.doneA, &doneB = g_side.doneB, &doneF = g_side.doneF, &doneQ = g_side.doneQ;
+    hipEvent_t &doneA = g_side.doneA, &doneB = g_side.doneB;
     if (fork) g_side.open = true;
     auto to_lane = [&]() {  // everything issued so far on the main stream precedes what the lane runs next
         if (!fork) return;
@@ -459,40 +459,35 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             const unsigned short* P = w.P + (int64_t)l * D.B * D.H * T * D.ldp;
             const unsigned short* f = w.f + (int64_t)l * M * mlp;
             const unsigned short* ga = w.gact + (int64_t)l * D.Mp * mlp;
-            // c_proj: dW = dx^T g, db = colsum(dx), dF = (dx W) * act'(F)
-            to_lane();
-            TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, D.Mp, d, mlp, mlp, 1), 1, ws));  // reduction over Mp rows (pad rows are zero)
-            lane_done(doneA);
+            // c_proj: dF = (dx W) * act'(F); its weight gradient joins c_fc's on the lane below (one fork per pair)
             // (c_proj bias gradient = column sums of dx: produced by the LayerNorm backward that wrote dx)
-            wait_lane(doneF);
             {
                 GemmArgs a = G(w.dxb, sh + lo[PRW], w.dfb, M, mlp, d, d, mlp, mlp, 0);
                 a.actin = f; a.ldact = mlp; a.act = D.act;
                 TRY(gemm_dispatch(L_NN, a, 1, s));
             }
-            // c_fc: dW = dF^T h2, db = colsum(dF), dh2 = dF W
+            // lane: c_proj dW = dx^T g and c_fc dW = dF^T h2, db = colsum(dF) (reductions over Mp rows: pad rows are zero)
             to_lane();
+            TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, D.Mp, d, mlp, mlp, 1), 1, ws));
             TRY(swat_linear_wgrad_bias(w.dfb, h2, grads + lo[FCW], grads + lo[FCB], D.Mp, mlp, d, mlp, d, w.csws, ws));
-            lane_done(doneF);
+            lane_done(doneA);  // last lane read of dxb and dfb
+            // c_fc: dh2 = dF W
             int S2 = 1;
             TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
             // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
             wait_lane(doneB);
             TRY(swat_layernorm_bwd_split(w.dh, d, S2, (int64_t)M * d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
                                    w.dx, d, w.dxb2, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], w.lnws, M, d, s));
-            // out_proj: dW = dx1^T a, db = colsum(dx1), da = dx1 W
-            to_lane();
-            TRY(gemm_dispatch(L_TN, G(w.dxb2, at, grads + lo[OUTW], d, d, D.Mp, d, d, d, 1), 1, ws));
-            lane_done(doneB);
-            // (out_proj bias gradient: produced by the ln_2 backward above)
+            // out_proj: da = dx1 W (its weight gradient joins in_proj's on the lane below; bias gradient: from the ln_2 backward)
             TRY(gemm_dispatch(L_NN, G(w.dxb2, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
             // attention backward -> dqkv
-            wait_lane(doneQ);
             TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s));
-            // in_proj: dW = dqkv^T h1, db = colsum(dqkv), dh1 = dqkv W
+            // lane: out_proj dW = dx1^T a and in_proj dW = dqkv^T h1, db = colsum(dqkv)
             to_lane();
+            TRY(gemm_dispatch(L_TN, G(w.dxb2, at, grads + lo[OUTW], d, d, D.Mp, d, d, d, 1), 1, ws));
             TRY(swat_linear_wgrad_bias(w.dqkv, h1, grads + lo[QKVW], grads + lo[QKVB], D.Mp, 3 * d, d, 3 * d, d, w.csws, ws));
-            lane_done(doneQ);
+            lane_done(doneB);  // last lane read of dxb2 and dqkv
+            // in_proj: dh1 = dqkv W
             int S1 = 1;
             TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));
             // ln_1 backward: dx0 = dx1 + LN'(dh1)

@@ -6,6 +6,10 @@ that each class is one contiguous segment (classes ascending by integer id, file
 inside a class — the order the reference's samplers visit them, :738-739 / :789-790) and the
 samplers work on CSR offsets.
 """
+import json
+import os
+
+import numpy as np
 import torch
 
 from . import ops
@@ -63,3 +67,50 @@ class SegmentedIndex:
             raise NotImplementedError(rank_by)
         idx, val, cnt = ops.segment_topk(sims, self.offsets, k, thr=thr, t2i=t2i, t2i_thr=t2i_thr, excluded=excluded)
         return idx, val, cnt, sims, t2i
+
+
+    # ---- on-disk form: one directory of raw .npy arrays in GROUPED row order, so a rank can memory-map
+    # the files and move only its own row range [lo, hi) to HBM (the reference keeps one pickled dict, mined.pth,
+    # retrieval/extract_mined_feature.py:270-279, which every process would have to unpickle whole) ----
+    def save(self, path):
+        os.makedirs(path, exist_ok=True)
+        np.save(os.path.join(path, "order.npy"), self.order.cpu().numpy())
+        np.save(os.path.join(path, "class_ids.npy"), self.class_ids.cpu().numpy())
+        np.save(os.path.join(path, "offsets.npy"), self.offsets.cpu().numpy())
+        for name in ("image_features", "caption_features"):
+            t = getattr(self, name)
+            if t is not None:
+                np.save(os.path.join(path, name + ".npy"), t.cpu().numpy())
+        if self.filepath is not None:
+            with open(os.path.join(path, "filepath.txt"), "w") as f:
+                f.write("\n".join(self.filepath))
+        meta = {"format": "swat_amd.SegmentedIndex/1", "n_rows": self.n_rows, "n_seg": self.n_seg,
+                "dim": int(self.caption_features.shape[1] if self.caption_features is not None else self.image_features.shape[1]),
+                "dtype": "float32", "row_order": "grouped by class id ascending, file order inside a class"}
+        with open(os.path.join(path, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+
+    @classmethod
+    def load(cls, path, device="cuda", rows=None):
+        """rows = (lo, hi): keep only that range of grouped rows (a shard); offsets are clipped and rebased to it."""
+        meta = json.load(open(os.path.join(path, "meta.json")))
+        assert meta["format"] == "swat_amd.SegmentedIndex/1", meta["format"]
+        lo, hi = rows if rows is not None else (0, meta["n_rows"])
+        self = cls.__new__(cls)
+        self.order = torch.from_numpy(np.load(os.path.join(path, "order.npy"), mmap_mode="r")[lo:hi].copy()).to(device)
+        self.class_ids = torch.from_numpy(np.load(os.path.join(path, "class_ids.npy"))).to(device)
+        offsets = torch.from_numpy(np.load(os.path.join(path, "offsets.npy")))
+        self.offsets = (offsets.clamp(lo, hi) - lo).to(device).contiguous()
+        for name in ("image_features", "caption_features"):
+            f = os.path.join(path, name + ".npy")
+            setattr(self, name, torch.from_numpy(np.load(f, mmap_mode="r")[lo:hi].copy()).to(device) if os.path.exists(f) else None)
+        counts = self.offsets[1:] - self.offsets[:-1]
+        self.row_seg = torch.repeat_interleave(torch.arange(self.class_ids.numel(), device=device, dtype=torch.int32), counts)
+        self.filepath = None
+        fp = os.path.join(path, "filepath.txt")
+        if os.path.exists(fp):
+            self.filepath = open(fp).read().split("\n")[lo:hi]
+        self.n_rows = hi - lo
+        self.n_seg = int(self.class_ids.numel())
+        self.row_base = lo
+        return self

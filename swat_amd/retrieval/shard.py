@@ -43,3 +43,23 @@ def gather_and_merge(idx, val, k, group=None):
     dist.all_gather(idxs, idx.contiguous(), group=group)
     dist.all_gather(vals, val.contiguous(), group=group)
     return merge_topk(idxs, vals, k)
+
+
+class ShardedIndex:
+    """One rank's row range of a saved SegmentedIndex (index.SegmentedIndex.save) plus the gather + merge that finishes
+    a query.  Every rank calls sample() with the same queries; every rank gets the global lists (grouped global rows)."""
+
+    def __init__(self, path, device="cuda", group=None):
+        import json
+        import os
+        from .index import SegmentedIndex
+        self.group = group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        n = json.load(open(os.path.join(path, "meta.json")))["n_rows"]
+        self.lo, self.hi = shard_bounds(n, world, rank)
+        self.local = SegmentedIndex.load(path, device=device, rows=(self.lo, self.hi))
+
+    def sample(self, queries, k, **kw):
+        idx, val, cnt, _, _ = self.local.sample(queries, k, **kw)
+        gidx = torch.where(idx >= 0, idx + self.lo, idx)
+        return gather_and_merge(gidx, val, k, group=self.group)

@@ -227,3 +227,38 @@ def test_sampling_driver_writes_reference_bytes(golden_dir, tmp_path, kind, meth
     path_to_row = {p: i for i, p in enumerate(case["paths"])}
     rows = np.array([path_to_row[p] for p in files], np.int64)
     assert torch.equal(torch.cat(split["feature_list"]), torch.from_numpy(case["img"][rows]))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_saved_index_shards_merge_to_the_single_gpu_answer(tmp_path, world):
+    """SURVEY 8(e) on one GPU: save the grouped index, load every rank's row range from disk, run the local filtered
+    top-k per shard on the HIP kernels and merge the [n_seg, k] lists in rank order — bit-identical (rows and values,
+    ties included) to the unsharded index."""
+    from swat_amd.retrieval import shard
+    from swat_amd.retrieval.index import SegmentedIndex
+    dev = _dev()
+    rs = np.random.RandomState(77)
+    n, d, ncls, k = 30000, 512, 23, 500
+    cap, img = synth.unit_rows(rs, n, d), synth.unit_rows(rs, n, d)
+    for _ in range(2000):  # exact ties, many of them across shard boundaries
+        a, b = rs.randint(n), rs.randint(n)
+        cap[a] = cap[b]
+    labels = torch.from_numpy(rs.randint(0, ncls, size=n))
+    full = SegmentedIndex(torch.from_numpy(img), torch.from_numpy(cap), labels, filepath=[str(i) for i in range(n)], device=dev)
+    q = torch.from_numpy(synth.unit_rows(rs, full.n_seg, d)).to(dev)
+    kw = dict(rank_by="t2t", use_t2i_thr=True, thr=0.0, t2i_thr=0.0)
+    w_idx, w_val, w_cnt, _, _ = full.sample(q, k, **kw)
+    full.save(str(tmp_path / "ix"))
+    idxs, vals = [], []
+    for rank in range(world):
+        lo, hi = shard.shard_bounds(n, world, rank)
+        loc = SegmentedIndex.load(str(tmp_path / "ix"), device=dev, rows=(lo, hi))
+        assert loc.filepath == full.filepath[lo:hi]
+        i, v, _, _, _ = loc.sample(q, k, **kw)
+        idxs.append(torch.where(i >= 0, i + lo, i))
+        vals.append(v)
+    m_idx, m_val, m_cnt = shard.merge_topk(idxs, vals, k)
+    assert torch.equal(m_cnt, w_cnt)
+    assert torch.equal(m_idx, w_idx)
+    valid = w_idx >= 0
+    assert torch.equal(m_val[valid], w_val[valid])

@@ -112,3 +112,21 @@ def test_tower_refuses_cpu():
     m = CLIP(vision_cfg=(64, 16, 128, 2, 2, 64, "quick_gelu"), text_cfg=(8, 64, 64, 1, 1))
     with pytest.raises(_lib.SwatHipError):
         m.encode_image(torch.zeros(1, 3, 64, 64))
+
+
+def test_segmented_index_save_load_round_trip(tmp_path):
+    """The on-disk index (raw .npy arrays in grouped row order): whole and as a row-range shard."""
+    from swat_amd.retrieval.index import SegmentedIndex
+    g = torch.Generator().manual_seed(0)
+    n = 1000
+    lab = torch.randint(0, 17, (n,), generator=g)
+    img, cap = torch.randn(n, 64, generator=g), torch.randn(n, 64, generator=g)
+    ix = SegmentedIndex(img, cap, lab, filepath=[f"p{i}" for i in range(n)], device="cpu")
+    ix.save(str(tmp_path / "ix"))
+    full = SegmentedIndex.load(str(tmp_path / "ix"), device="cpu")
+    assert torch.equal(full.caption_features, ix.caption_features) and torch.equal(full.image_features, ix.image_features)
+    assert torch.equal(full.offsets, ix.offsets) and torch.equal(full.order, ix.order) and full.filepath == ix.filepath
+    sh = SegmentedIndex.load(str(tmp_path / "ix"), device="cpu", rows=(300, 700))
+    assert torch.equal(sh.image_features, ix.image_features[300:700]) and sh.filepath == ix.filepath[300:700]
+    assert int(sh.offsets[0]) == 0 and int(sh.offsets[-1]) == 400 and torch.equal(sh.row_seg, ix.row_seg[300:700])
+    assert torch.equal(sh.offsets, ix.offsets.clamp(300, 700) - 300)

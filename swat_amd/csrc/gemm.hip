@@ -1201,9 +1201,13 @@ static int pick_cfg(int layout, const GemmArgs& a, int batch) {
     if (layout == L_NN) {
         if (a.N >= 2048 && a.K <= 1024 && a.M >= 128) return 43;
         if (many_rows && a.K >= 2048) return 32;
-        return a.K >= 384 ? 30 : 14;
+        return a.K >= 384 ? 30 : 14;  // (re-checked inside the overlapped step: 43 / 30 stay the best pair)
     }
-    if ((int64_t)a.M * a.N >= (1 << 21)) return many_rows ? 16 : 14;
+    // weight gradients run on the backward's second stream beside the data-gradient chain: alone the LDS-DMA 64x64
+    // kernel is the fastest for the large ones (21 vs 22 us), but in the step the 128x128 register ring disturbs the
+    // main chain least (3.65 vs 3.79 ms/step; 15 / 16 / 30 / 32 in between) — half the operand traffic through L2
+    if ((int64_t)a.M * a.N >= (1 << 21)) return many_rows ? 16 : (a.K >= 384 ? 33 : 14);
+    return a.K >= 384 ? 30 : 14;
     return a.K >= 384 ? 30 : 14;
 }
 

@@ -125,6 +125,15 @@ int swat_layernorm_bwd_split(const float* dy, int64_t dy_stride, int nsplit, int
                              const float* dx_add, int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
                              void* dx_bf16, int64_t dxb_stride, float* dgamma, float* dbeta, float* dcolsum,
                              void* workspace, int rows, int d, swat_stream_t stream);
+/*     the same in two calls — the row pass, then the reduction of its per-workgroup partial sums (`workspace`) to
+ *     dgamma / dbeta / dcolsum; the reduction may be issued on another stream that is ordered after the row pass. */
+int swat_layernorm_bwd_partial(const float* dy, int64_t dy_stride, int nsplit, int64_t split_stride, const float* x,
+                               int64_t x_stride, const float* gamma, const float* mean, const float* rstd,
+                               const float* dx_add, int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
+                               void* dx_bf16, int64_t dxb_stride, void* workspace, int rows, int d,
+                               swat_stream_t stream);
+int swat_layernorm_bwd_finish(const void* workspace, int rows, int d, float* dgamma, float* dbeta, float* dcolsum,
+                              swat_stream_t stream);
 
 /* A2d  attention softmax over score rows (fp32 S, ld = padded T): P = softmax(scale*S[:, :T]) bf16,
  *     pad columns zeroed; causal!=0 for the text tower.  Backward: dS = scale*P o (dP - rowsum(P o dP)). */

@@ -512,14 +512,35 @@ SWAT_API int swat_layernorm_bwd_split(const float* dy, int64_t dy_stride, int ns
                                       const float* dx_add, int64_t dxa_stride, float* dx_out, int64_t dxo_stride, void* dx_bf16,
                                       int64_t dxb_stride, float* dgamma, float* dbeta, float* dcolsum, void* workspace, int rows,
                                       int d, swat_stream_t s) {
-    SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && nsplit >= 1 && nsplit <= 4, "swat_layernorm_bwd_split: bad arguments");
+    int rc = swat_layernorm_bwd_partial(dy, dy_stride, nsplit, split_stride, x, x_stride, gamma, mean, rstd, dx_add, dxa_stride,
+                                        dx_out, dxo_stride, dx_bf16, dxb_stride, workspace, rows, d, s);
+    if (rc) return rc;
+    return swat_layernorm_bwd_finish(workspace, rows, d, dgamma, dbeta, dcolsum, s);
+}
+
+// The two halves of swat_layernorm_bwd_split as separate calls: the row pass (dx, its bf16 copy, per-workgroup partial
+// sums into `workspace`) and the fixed-order reduction of those partials to dgamma / dbeta / dcolsum.  The second half
+// feeds nothing but the optimizer, so a caller may run it on another stream once the first has been ordered before it.
+SWAT_API int swat_layernorm_bwd_partial(const float* dy, int64_t dy_stride, int nsplit, int64_t split_stride, const float* x,
+                                        int64_t x_stride, const float* gamma, const float* mean, const float* rstd,
+                                        const float* dx_add, int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
+                                        void* dx_bf16, int64_t dxb_stride, void* workspace, int rows, int d, swat_stream_t s) {
+    SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && nsplit >= 1 && nsplit <= 4, "swat_layernorm_bwd_partial: bad arguments");
     if (rows <= 0) return 0;
     int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
     if (nblk > 256) nblk = 256;
     LNB_DISPATCH();
+    return check_launch("swat_layernorm_bwd_partial");
+}
+
+SWAT_API int swat_layernorm_bwd_finish(const void* workspace, int rows, int d, float* dgamma, float* dbeta, float* dcolsum,
+                                       swat_stream_t s) {
+    if (rows <= 0) return 0;
+    int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
+    if (nblk > 256) nblk = 256;
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 31) / 32, 3), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
-    return check_launch("swat_layernorm_bwd_split");
+    return check_launch("swat_layernorm_bwd_finish");
 }
 
 SWAT_API int swat_softmax_fwd(const float* S, void* P_bf16, int64_t rows, int Tq, int T, int ld, float scale, int causal,

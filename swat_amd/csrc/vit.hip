@@ -76,7 +76,7 @@ struct VitWs {
     unsigned short* dab;      // [M,d]
     unsigned short* dqkv;     // [M,3d]
     float* du;                // [B,d]
-    void* lnws;
+    void *lnws, *lnws1, *lnws2;  // LayerNorm-backward partial sums: stem / tail, ln_1, ln_2 (their reductions run on the lane)
     void* csws;               // column-sum partials
     int64_t total;
 };
@@ -124,6 +124,8 @@ static VitWs carve(const VitDims& D, void* base) {
         w.dqkv = (unsigned short*)take(Mp * 3 * d * 2);
         w.du = (float*)take((int64_t)D.B * d * 4);
         w.lnws = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
+        w.lnws1 = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
+        w.lnws2 = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
         w.csws = take(swat_colsum_bf16_workspace_bytes(D.mlp > 3 * D.d ? D.mlp : 3 * D.d));
     }
     w.total = off;
@@ -434,6 +436,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
         slot = nullptr;
     };
 
+    int ln1_pending = -1;
     for (int stage = stage_hi; stage >= stage_lo; --stage) {
         if (stage == D.L + 1) {
             SWAT_REQUIRE(dfeats, "swat_vit_backward: dfeats is null");
@@ -476,14 +479,16 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
             // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
             wait_lane(doneB);
-            TRY(swat_layernorm_bwd_split(w.dh, d, S2, (int64_t)M * d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
-                                   w.dx, d, w.dxb2, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], w.lnws, M, d, s));
+            // (row pass here; the reduction of its partial sums to d(ln_2.weight / bias) and d(out_proj.bias) runs on the lane)
+            TRY(swat_layernorm_bwd_partial(w.dh, d, S2, (int64_t)M * d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
+                                           w.dx, d, w.dxb2, d, w.lnws2, M, d, s));
             // out_proj: da = dx1 W (its weight gradient joins in_proj's on the lane below; bias gradient: from the ln_2 backward)
             TRY(gemm_dispatch(L_NN, G(w.dxb2, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
             // attention backward -> dqkv
             TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s));
             // lane: out_proj dW = dx1^T a and in_proj dW = dqkv^T h1, db = colsum(dqkv)
             to_lane();
+            TRY(swat_layernorm_bwd_finish(w.lnws2, M, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], ws));
             TRY(gemm_dispatch(L_TN, G(w.dxb2, at, grads + lo[OUTW], d, d, D.Mp, d, d, d, 1), 1, ws));
             TRY(swat_linear_wgrad_bias(w.dqkv, h1, grads + lo[QKVW], grads + lo[QKVB], D.Mp, 3 * d, d, 3 * d, d, w.csws, ws));
             lane_done(doneB);  // last lane read of dxb2 and dqkv
@@ -492,9 +497,9 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));
             // ln_1 backward: dx0 = dx1 + LN'(dh1)
             wait_lane(doneA);
-            TRY(swat_layernorm_bwd_split(w.dh, d, S1, (int64_t)M * d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
-                                   w.dx, d, w.dxb, d, grads + lo[LN1W], grads + lo[LN1B],
-                                   l > 0 ? grads + (O.layer + 12 * (l - 1))[PRB] : nullptr, w.lnws, M, d, s));
+            TRY(swat_layernorm_bwd_partial(w.dh, d, S1, (int64_t)M * d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
+                                           w.dx, d, w.dxb, d, w.lnws1, M, d, s));
+            ln1_pending = l;  // its reduction is queued on the lane at the end of this stage
         } else {
             // stem: ln_pre backward, positional / class embedding, conv1 weight
             TRY(swat_layernorm_bwd(w.dx, d, w.xpre, d, params + O.lnpre_w, w.mean_pre, w.rstd_pre, nullptr, 0, w.dh, d, nullptr, 0,
@@ -506,6 +511,12 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(gemm_dispatch(L_TN, G(w.dxb, w.patches, grads + O.conv1, d, D.Kp, np, d, D.ldk, D.Kp, 1), 1, s));
         }
         to_lane();  // the lane's tail now also follows everything this stage ran on the main stream
+        if (ln1_pending >= 0) {
+            const int64_t* lo = O.layer + 12 * ln1_pending;
+            TRY(swat_layernorm_bwd_finish(w.lnws1, M, d, grads + lo[LN1W], grads + lo[LN1B],
+                                          ln1_pending > 0 ? grads + (O.layer + 12 * (ln1_pending - 1))[PRB] : nullptr, ws));
+            ln1_pending = -1;
+        }
     }
     if (g_overlap == 1) TRY(swat_vit_backward_join(stream));  // the caller's stream sees every gradient of the requested stages
     return 0;

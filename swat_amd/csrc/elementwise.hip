@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ln_bwd_reduce sums them in a fixed order (deterministic, no float atomics).
 // Each block = 4 waves; each wave walks rows  wave_global, wave_global + nwaves, ...
 // --------------------------------------------------------------------------------------------
+constexpr int LNB_MAX_BLOCKS = 1024;  // one row per wave up to 8 192 rows (ViT-L/14 at B = 32); partial sums: 1024 x 3 x d floats
 constexpr int LNB_WAVES = 8;  // one row per wave and pass: M = 1600 rows -> 200 blocks, every wave exactly one row
 template <int NSPLIT, int VPL>  // VPL float4 per lane: d <= 256 * VPL
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __restrict__ dy, int64_t dy_stride,
@@ -470,7 +471,7 @@ SWAT_API int swat_layernorm_fwd_split(const float* x_planes, int64_t x_row_strid
 
 SWAT_API int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d) {
     (void)rows;
-    return (int64_t)256 * 3 * d * sizeof(float);
+    return (int64_t)LNB_MAX_BLOCKS * 3 * d * sizeof(float);
 }
 
 #define LNB_LAUNCH(NS, V)                                                                                                    \
@@ -498,7 +499,7 @@ SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float*
     SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV, "swat_layernorm_bwd: d=%d unsupported", d);
     if (rows <= 0) return 0;
     int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
-    if (nblk > 256) nblk = 256;
+    if (nblk > LNB_MAX_BLOCKS) nblk = LNB_MAX_BLOCKS;
     const int nsplit = 1;
     const int64_t split_stride = 0;
     LNB_DISPATCH();
@@ -528,7 +529,7 @@ SWAT_API int swat_layernorm_bwd_partial(const float* dy, int64_t dy_stride, int 
     SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && nsplit >= 1 && nsplit <= 4, "swat_layernorm_bwd_partial: bad arguments");
     if (rows <= 0) return 0;
     int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
-    if (nblk > 256) nblk = 256;
+    if (nblk > LNB_MAX_BLOCKS) nblk = LNB_MAX_BLOCKS;
     LNB_DISPATCH();
     return check_launch("swat_layernorm_bwd_partial");
 }
@@ -537,7 +538,7 @@ SWAT_API int swat_layernorm_bwd_finish(const void* workspace, int rows, int d, f
                                        swat_stream_t s) {
     if (rows <= 0) return 0;
     int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
-    if (nblk > 256) nblk = 256;
+    if (nblk > LNB_MAX_BLOCKS) nblk = LNB_MAX_BLOCKS;
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 31) / 32, 3), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
     return check_launch("swat_layernorm_bwd_finish");

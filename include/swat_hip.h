@@ -86,11 +86,13 @@ int swat_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int
                    const void* actin, int ldact, int act, void* C2, int out_f32, float alpha,
                    swat_stream_t stream);
 
-/*     Measurement hooks (bench.py roofline leg): time every GEMM launch with hipEvents recorded on the
- *     launch stream.  end() synchronises and fills 6 slots indexed layout*2 + (128x128 tile ? 1 : 0)
+/*     Measurement hooks (bench.py roofline leg): time every GEMM launch with start / stop hipEvents attached to the
+ *     kernel's own dispatch packet (kernel execution time, as rocprofv3 reports it).  end() synchronises and fills
+ *     6 slots indexed layout*2 + (tile with a 128-row side ? 1 : 0)
  *     with total milliseconds, launch counts and 2*M*N*K*batch flops; returns the launches seen. */
-/*     swat_gemm_set_tile: pin one tile configuration (0 64x64x32, 1 128x128x64, 2 64x64x64, 3 128x128x32,
- *     4 128x64x64, 5 64x128x64; -1 = automatic) — tests and tuning. */
+/*     swat_gemm_set_tile: pin one tile configuration (-1 = automatic) — tests and tuning.  14-19, 25-28, 43: LDS-DMA
+ *     ring (64x64 / 128x128 / 128x64 tiles, 2-8 stages, 4 or 8 waves); 30-34: register ring on whole k-steps;
+ *     20-24: register ring with K tails and batch strides (the fallback of every other number). */
 int swat_gemm_set_tile(int cfg);
 int swat_gemm_set_exp(int bits); /* tuning only: ablate loads / MFMA / epilogue of the LDS-DMA kernel (results wrong) */
 int swat_gemm_set_trace(void* dev_buf); /* tuning only: per-workgroup timeline of the LDS-DMA kernel (exp bit 16) */

@@ -8,13 +8,14 @@
 //   layout NN: A[M,K] (k contiguous)  B[K,N] (n contiguous)      dgrad     dX = dY W
 //   layout TN: A[K,M] (m contiguous)  B[K,N] (n contiguous)      wgrad     dW = dY^T X
 //
-// 256 threads = 4 waves (2 x 2), block tile BM x BN, 64-deep k-steps.  Two kernels share ONE LDS image:
-//   * gemm_glds_kernel  (K % 64 == 0): tiles go global -> LDS by global_load_lds_dwordx4 (no VGPR staging, no
-//     ds_write), NSTAGE buffers, NSTAGE-1 stages in flight behind a counted s_waitcnt vmcnt(N) + raw s_barrier.
-//     The finetuning GEMMs are small (M = B*T = 1600, ~1 block per CU): latency has to be hidden by prefetch
-//     depth inside the wave, not by occupancy.
-//   * gemm_stage_kernel (any K): same image filled through registers with zero-filled K tails (attention's
-//     T-deep products, ViT-L/14's 588-wide patch rows).
+// 256 (or 512) threads = 4 (8) waves, block tile BM x BN, 64-deep k-steps.  Three kernels share ONE LDS image:
+//   * gemm_dma_kernel   (K % 64 == 0): tiles go global -> LDS by global_load_lds_dwordx4 (no VGPR staging, no
+//     ds_write), NSTAGE buffers, NSTAGE-1 stages in flight behind a counted s_waitcnt vmcnt(N) + raw s_barrier;
+//     every address loop-invariant.  The finetuning GEMMs are small (M = B*T = 1600, ~1-3 workgroups per CU):
+//     latency has to be hidden by prefetch depth inside the wave, not by occupancy.
+//   * gemm_ring2_kernel (K % 64 == 0): the same loop on a register ring (global_load_dwordx4 -> ds_write_b128).
+//   * gemm_ring_kernel  (any K): register ring with zero-filled K tails and batch strides (attention's T-deep
+//     products for T > 64, ViT-L/14's 588-wide patch rows, ragged shapes).
 // LDS image (LINEAR, because an LDS-DMA instruction writes wave-uniform base + lane*16; the bank-conflict swizzle
 // is applied to the per-lane SOURCE address and again on the read):
 //   k-contiguous tile [rows][64]: 16-B slot t of row r lives at slot t ^ ((r >> 1) & 7); fragments are ONE
@@ -332,104 +333,7 @@ __device__ __forceinline__ void mma_stage(const unsigned char* sa, const unsigne
 }
 
 // --------------------------------------------------------------------------------------------
-// register-staged kernel (any K; zero-filled K tail), 2 LDS buffers
-// --------------------------------------------------------------------------------------------
-template <int LAYOUT, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_stage_kernel(const GemmArgs p) {
-    constexpr bool A_KC = (LAYOUT != L_TN);
-    constexpr bool B_KC = (LAYOUT == L_NT);
-    constexpr int BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2;
-    constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int A_CH = A_BYTES / 16 / 256, B_CH = B_BYTES / 16 / 256;
-
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm0 = (wave >> 1) * WM;
-    const int wn0 = (wave & 1) * WN;
-    int bx, by;
-    tile_coords(p, bx, by);
-    const int m0 = by * BM;
-    const int n0 = bx * BN;
-    const int z = blockIdx.z;
-    const int zo = z / p.inner, zi = z % p.inner;
-    const unsigned short* __restrict__ A = p.A + zo * p.sA0 + zi * p.sA1;
-    const unsigned short* __restrict__ B = p.B + zo * p.sB0 + zi * p.sB1;
-    const int M = p.M, N = p.N, K = p.K;
-
-    s16x8_t ra[A_CH], rb[B_CH];
-    auto load_one = [&](const unsigned short* __restrict__ P, bool kcontig, int c, int row0, int R, int ld, int tile_rows,
-                        int k0) -> s16x8_t {
-        s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (kcontig) {
-            const int row = c >> 3, t = c & 7;
-            int gr = row0 + row; gr = gr < R ? gr : R - 1;
-            const int gk = k0 + 8 * t;
-            if (gk < K) {
-                v = *reinterpret_cast<const s16x8_t*>(P + (int64_t)gr * ld + gk);
-                if (gk + 8 > K) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (gk + e >= K) v[e] = 0;
-                }
-            }
-        } else {
-            const int krow = c / (tile_rows / 8), c16 = c % (tile_rows / 8);
-            const int gk = k0 + krow;
-            int gr = row0 + 8 * c16; gr = gr + 8 <= ld ? gr : 0;  // keep the 16-B load inside the row
-            if (gk < K) v = *reinterpret_cast<const s16x8_t*>(P + (int64_t)gk * ld + gr);
-        }
-        return v;
-    };
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) ra[i] = load_one(A, A_KC, tid + 256 * i, m0, M, p.lda, BM, k0);
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) rb[i] = load_one(B, B_KC, tid + 256 * i, n0, N, p.ldb, BN, k0);
-    };
-    auto store_tiles = [&](int buf) {
-        unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
-        unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int c = tid + 256 * i;
-            const int off = A_KC ? kc_off(c >> 3, c & 7) : st_off<BM>(c / (BM / 8), c % (BM / 8));
-            *reinterpret_cast<s16x8_t*>(sa + off) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            const int c = tid + 256 * i;
-            const int off = B_KC ? kc_off(c >> 3, c & 7) : st_off<BN>(c / (BN / 8), c % (BN / 8));
-            *reinterpret_cast<s16x8_t*>(sb + off) = rb[i];
-        }
-    };
-
-    f32x4_t acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nk) load_tiles((t + 1) * BK);
-        const unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
-        mma_stage<FM, FN, A_KC, B_KC, BM, BN>(sa, sa + A_BYTES, wm0, wn0, lane, acc);
-        if (t + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-    gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
-}
-
-// --------------------------------------------------------------------------------------------
-// register-ring kernel (any K): like gemm_stage_kernel, but D stages of global loads are kept in flight in a
+// register-ring kernel (any K, zero-filled K tail): D stages of global loads are kept in flight in a
 // register ring (16 VGPRs per stage for a 64x64 tile), so memory latency is covered by prefetch DEPTH while the
 // per-step issue cost stays at global_load_dwordx4 + ds_write_b128 (~25 cycles per KiB vs ~100 measured for an
 // LDS-DMA piece issued by the computing wave itself: rocprofv3 SQ_ACTIVE_INST_ANY / SQ_WAIT_ANY, profiles/).
@@ -564,107 +468,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int LAYOUT, int BM, int BN, int NSTAGE, int WGM = 2, int WGN = 2>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmArgs p) {
-    constexpr int NW = WGM * WGN;  // waves per block (4 or 8: two waves per SIMD overlap each other's DMA issue / LDS reads)
-    constexpr bool A_KC = (LAYOUT != L_TN);
-    constexpr bool B_KC = (LAYOUT == L_NT);
-    constexpr int BK = 64;
-    constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INS = A_BYTES / 1024 / NW, B_INS = B_BYTES / 1024 / NW;  // DMA instructions per wave per stage
-    constexpr int LPS = A_INS + B_INS;
-    static_assert(A_INS >= 1 && B_INS >= 1, "tile too small for this many waves");
-
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave / WGN) * WM;
-    const int wn0 = (wave % WGN) * WN;
-    int bx, by;
-    tile_coords(p, bx, by);
-    const int m0 = by * BM;
-    const int n0 = bx * BN;
-    const int z = blockIdx.z;
-    const int zo = z / p.inner, zi = z % p.inner;
-    const unsigned short* __restrict__ A = p.A + zo * p.sA0 + zi * p.sA1;
-    const unsigned short* __restrict__ B = p.B + zo * p.sB0 + zi * p.sB1;
-    const int M = p.M, N = p.N, K = p.K;
-
-    // per-lane SOURCE offsets (elements, without k0): DMA instruction `ins` fills LDS bytes [ins*1024, +1024), lane
-    // owns 16 of them; the source chunk is whatever the image says lives there (inverse of kc_off / st_off).
-    int64_t offA[A_INS], offB[B_INS];
-    auto src_off = [&](bool kcontig, int ins, int row0, int R, int ld, int tile_rows) -> int64_t {
-        const int byte = ins * 1024 + lane * 16;
-        if (kcontig) {
-            const int row = byte >> 7, ps = (byte >> 4) & 7;
-            const int t = ps ^ ((row >> 1) & 7);
-            int gr = row0 + row; gr = gr < R ? gr : R - 1;
-            return (int64_t)gr * ld + 8 * t;
-        } else {
-            const int rs = tile_rows * 2;
-            const int k = byte / rs, pc16 = (byte % rs) >> 4;
-            const int f = tile_rows == 128 ? st_f<128>(k) : st_f<64>(k);
-            const int c16 = (((pc16 >> 1) ^ f) << 1) | (pc16 & 1);
-            int gr = row0 + 8 * c16; gr = gr + 8 <= ld ? gr : 0;
-            return (int64_t)k * ld + gr;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < A_INS; ++i) offA[i] = src_off(A_KC, wave + NW * i, m0, M, p.lda, BM);
-#pragma unroll
-    for (int i = 0; i < B_INS; ++i) offB[i] = src_off(B_KC, wave + NW * i, n0, N, p.ldb, BN);
-    const int64_t kstepA = A_KC ? 64 : (int64_t)64 * p.lda;
-    const int64_t kstepB = B_KC ? 64 : (int64_t)64 * p.ldb;
-
-    auto issue = [&](int t) {
-        unsigned char* sa = smem + (t % NSTAGE) * STAGE;
-        unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_INS; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + offA[i] + t * kstepA),
-                                             (__attribute__((address_space(3))) void*)(sa + (wave + NW * i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < B_INS; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + offB[i] + t * kstepB),
-                                             (__attribute__((address_space(3))) void*)(sb + (wave + NW * i) * 1024), 16, 0, 0);
-    };
-
-    f32x4_t acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / BK;
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk) issue(s);
-
-    for (int t = 0; t < nk; ++t) {
-        // stage t has landed once at most the younger issued stages (<= NSTAGE-2 of them) are still outstanding
-        const int younger = nk - 1 - t < NSTAGE - 2 ? nk - 1 - t : NSTAGE - 2;
-        if (younger >= 2) wait_vmcnt<2 * LPS>();
-        else if (younger == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads of step t-1 are complete
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + NSTAGE - 1 < nk && !(p.exp & 1)) issue(t + NSTAGE - 1);  // into the buffer every wave finished reading at step t-1
-        const unsigned char* sa = smem + ((p.exp & 8) ? 0 : (t % NSTAGE)) * STAGE;
-        if (p.exp & 2) mma_stage<FM, FN, A_KC, B_KC, BM, BN, true>(sa, sa + A_BYTES, wm0, wn0, lane, acc);
-        else mma_stage<FM, FN, A_KC, B_KC, BM, BN, false>(sa, sa + A_BYTES, wm0, wn0, lane, acc);
-    }
-    if (!(p.exp & 4)) gemm_epilogue<FM, FN>(p, acc, m0 + wm0, n0 + wn0, lane, zo, zi);
-    else if (acc[0][0][0] == 12345.f) ((float*)p.C)[0] = 1.f;
-}
-
 // --------------------------------------------------------------------------------------------
-// LDS-DMA kernel, lean main loop (K % 64 == 0).  Same pipeline as gemm_glds_kernel, but everything that does not
+// LDS-DMA kernel, lean main loop (K % 64 == 0): everything that does not
 // change from step to step is hoisted: the per-lane source offsets are 32-bit and added to a wave-uniform base
 // pointer that advances in SGPRs (saddr + voffset addressing), the main loop is unrolled by NSTAGE so every LDS
 // stage address is an immediate, and the fragment read addresses are precomputed per lane.  rocprofv3 showed the
@@ -1084,22 +889,10 @@ static dim3 plan_grid(GemmArgs& b, int bm, int bn, int batch) {
     return dim3(tm * tn, 1, 1);
 }
 
-// tile configurations.  register-staged: 0 = 64x64, 1 = 128x128, 2 = 128x64, 3 = 64x128;
-// LDS-DMA pipelined: 6 = 128x128 x 3 stages, 7 = 64x64 x 4 stages, 8 = 128x64 x 4 stages, 9 = 64x64 x 3 stages
+// tile configurations (swat_gemm_set_tile pins one; pick_cfg chooses): 14-19 / 25-28 / 43 LDS-DMA ring, 30-34 register
+// ring (whole k-steps), 20-24 register ring with K tails
 template <int LAYOUT>
 static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-#define SWAT_STAGE(BM_, BN_)                                                                              \
-    {                                                                                                     \
-        GemmArgs b = a;                                                                                   \
-        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
-        hipExtLaunchKernelGGL((gemm_stage_kernel<LAYOUT, BM_, BN_>), grid, dim3(256), 0, s, ev0, ev1, 0, b);              \
-    }
-#define SWAT_GLDS(BM_, BN_, NS_)                                                                          \
-    {                                                                                                     \
-        GemmArgs b = a;                                                                                   \
-        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
-        hipExtLaunchKernelGGL((gemm_glds_kernel<LAYOUT, BM_, BN_, NS_>), grid, dim3(256), 0, s, ev0, ev1, 0, b);          \
-    }
 #define SWAT_RING(BM_, BN_, D_)                                                                           \
     {                                                                                                     \
         GemmArgs b = a;                                                                                   \
@@ -1124,28 +917,11 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s, hip
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
         hipExtLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, ev0, ev1, 0, b); \
     }
-#define SWAT_GLDS8(BM_, BN_, NS_, WGM_, WGN_)                                                             \
-    {                                                                                                     \
-        GemmArgs b = a;                                                                                   \
-        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
-        hipExtLaunchKernelGGL((gemm_glds_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, ev0, ev1, 0, b); \
-    }
     if (cfg == 43 && a.K % 64 != 0) cfg = 20;
     if (cfg >= 25 && cfg <= 28 && a.K % 64 != 0) cfg = 20;
     if (cfg >= 30 && (a.K % 64 != 0 || a.K < 64 * 6)) cfg = 20;  // lean ring needs whole, >= D k-steps
-    if (cfg >= 6 && cfg < 20 && a.K % 64 != 0) cfg = (cfg == 6 || (cfg >= 10 && cfg != 14 && cfg != 17 && cfg != 18 && cfg != 19)) ? 1 : (cfg == 8 ? 2 : 0);  // the LDS-DMA kernel has no K tail
+    if (cfg >= 14 && cfg < 20 && a.K % 64 != 0) cfg = 20;  // the LDS-DMA kernel has no K tail
     switch (cfg) {
-        case 1: SWAT_STAGE(128, 128) break;
-        case 2: SWAT_STAGE(128, 64) break;
-        case 3: SWAT_STAGE(64, 128) break;
-        case 6: SWAT_GLDS(128, 128, 3) break;
-        case 7: SWAT_GLDS(64, 64, 4) break;
-        case 8: SWAT_GLDS(128, 64, 4) break;
-        case 9: SWAT_GLDS(64, 64, 3) break;
-        case 10: SWAT_GLDS8(128, 128, 3, 2, 4) break;
-        case 11: SWAT_GLDS8(128, 128, 3, 4, 2) break;
-        case 12: SWAT_GLDS8(128, 64, 4, 4, 2) break;
-        case 13: SWAT_GLDS8(256, 128, 2, 4, 2) break;
         case 43: SWAT_DMA(128, 64, 2) break;
         case 14: SWAT_DMA(64, 64, 3) break;
         case 15: SWAT_DMA(128, 128, 3) break;
@@ -1167,11 +943,8 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s, hip
         case 22: SWAT_RING(128, 64, 4) break;
         case 23: SWAT_RING(64, 64, 6) break;
         case 24: SWAT_RING(64, 64, 2) break;
-        default: SWAT_STAGE(64, 64) break;
+        default: SWAT_RING(64, 64, 4) break;
     }
-#undef SWAT_STAGE
-#undef SWAT_GLDS
-#undef SWAT_GLDS8
 #undef SWAT_RING
 #undef SWAT_RING2
 #undef SWAT_DMA
@@ -1237,7 +1010,7 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     else if (layout == L_NN) rc = launch_gemm<L_NN>(a, batch, tile, s, ev0, ev1);
     else rc = launch_gemm<L_TN>(a, batch, tile, s, ev0, ev1);
     if (prof) {
-        g_prof.kind[g_prof.n] = layout * 2 + (tile == 1 || tile == 2 || tile == 6 || tile == 8 || (tile >= 10 && tile < 14) || tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43);
+        g_prof.kind[g_prof.n] = layout * 2 + (tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43);
         g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
         ++g_prof.n;
     }

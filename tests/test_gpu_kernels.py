@@ -293,7 +293,7 @@ def test_adamw_matches_torch():
     assert torch.equal(shadow, p.to(BF))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 43])
+@pytest.mark.parametrize("cfg", [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 43])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm_every_tile_configuration(cfg, layout):
     """All register-staged and LDS-DMA pipelined tile configurations give the same product (ragged M/N edges)."""

@@ -7,18 +7,19 @@ exp bits: 1 no loads after the prologue, 2 no LDS reads / MFMA, 4 no epilogue, 8
 import sys, os, glob, csv, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REPS = 12
-SHAPES = [("L14 fc fwd NT 8224x4096x1024 dual", "NT", 8224, 4096, 1024, "fc"),
-          ("L14 qkv fwd NT 8224x3072x1024", "NT", 8224, 3072, 1024, "bias"),
-          ("L14 proj fwd NT 8224x1024x4096 res", "NT", 8224, 1024, 4096, "res"),
-          ("L14 out fwd NT 8224x1024x1024 res", "NT", 8224, 1024, 1024, "res"),
-          ("L14 fc dgrad NN 8224x1024x4096 f32", "NN", 8224, 1024, 4096, "f32"),
-          ("L14 proj dgrad NN 8224x4096x1024 act'", "NN", 8224, 4096, 1024, "actin"),
-          ("L14 fc wgrad TN 4096x1024x8224", "TN", 4096, 1024, 8224, "f32"),
-          ("L14 out wgrad TN 1024x1024x8224", "TN", 1024, 1024, 8224, "f32"),
-          ("B16 fc fwd NT 6304x3072x768 dual", "NT", 6304, 3072, 768, "fc"),
-          ("B16 proj fwd NT 6304x768x3072 res", "NT", 6304, 768, 3072, "res"),
-          ("B16 fc wgrad TN 3072x768x6304", "TN", 3072, 768, 6304, "f32")]
-CFGS = {"NT": (14, 16, 43, 15, 25, 26, 33, 32), "NN": (14, 30, 43, 15, 25, 26, 33, 32), "TN": (14, 30, 16, 15, 25, 26, 33, 32)}
+SHAPES = [("fc fwd  NT 1600x3072x768 bias+gelu dual bf16", "NT", 1600, 3072, 768, "fc"),
+          ("qkv fwd NT 1600x2304x768 bias bf16", "NT", 1600, 2304, 768, "bias"),
+          ("proj fwd NT 1600x768x3072 bias+res f32", "NT", 1600, 768, 3072, "res"),
+          ("out fwd NT 1600x768x768 bias+res f32", "NT", 1600, 768, 768, "res"),
+          ("fc dgrad NN 1600x768x3072 f32", "NN", 1600, 768, 3072, "f32"),
+          ("qkv dgrad NN 1600x768x2304 f32", "NN", 1600, 768, 2304, "f32"),
+          ("proj dgrad NN 1600x3072x768 act' bf16", "NN", 1600, 3072, 768, "actin"),
+          ("out dgrad NN 1600x768x768 bf16", "NN", 1600, 768, 768, "bf16"),
+          ("fc wgrad TN 3072x768x1600 f32", "TN", 3072, 768, 1600, "f32"),
+          ("proj wgrad TN 768x3072x1600 f32", "TN", 768, 3072, 1600, "f32"),
+          ("qkv wgrad TN 2304x768x1600 f32", "TN", 2304, 768, 1600, "f32"),
+          ("out wgrad TN 768x768x1600 f32", "TN", 768, 768, 1600, "f32")]
+CFGS = {"NT": (14, 16, 43, 30), "NN": (14, 30, 43, 32), "TN": (14, 30, 33, 16)}
 EXPS = (0,)
 
 def plan():

@@ -1,0 +1,124 @@
+"""GPU: the data-parallel step end to end with TWO ranks (two processes on the one GPU of the test box, gloo carrying
+the CUDA gradient slices — RCCL refuses two ranks on one device, the step code is backend-agnostic).
+
+Rank r trains on its half of a batch; the 2-rank job must land on the weights of ONE process that sees the whole
+batch (mean-reduced cross entropy: the average of the two half-batch gradients is the full-batch gradient), in the
+trailing form bench.py runs at N > 1: per-stage all-reduce + AdamW on a side stream behind the weight-gradient lane."""
+import os
+import socket
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = (64, 16, 128, 2, 2, 64, "quick_gelu")
+STEPS, HALF, C = 3, 4, 10
+
+
+class _Lg:
+    handlers = []
+
+    def info(self, *a):
+        pass
+
+
+def _job(world, x, y):
+    """STEPS plain-CE steps (no CutMix: a permutation inside a shard is not a permutation of the whole batch)."""
+    sys.path.insert(0, ROOT)
+    from swat_amd import optimizers
+    from swat_amd.clip_model import CLIP
+    from swat_amd.models import MyLinear
+    from swat_amd.step import FusedTrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = CLIP(vision_cfg=TINY, text_cfg=(8, 64, 64, 1, 1)).to(dev)
+    head = MyLinear(weights=torch.randn(C, TINY[5])).to(dev)
+    args = types.SimpleNamespace(method="finetune", device=dev, lr_classifier=1e-2, lr_backbone=1e-3, temperature=0.07,
+                                 optim="AdamW", wd=1e-2, epochs=1, cutmix_beta=1.0, mix_prob=0.5, loss_name="CE")
+    params, ls = optimizers.set_params(args, model, head, _Lg())
+    opt, sched, _ = optimizers.set_optimizer(args, params, [None] * 50)
+    step = FusedTrainStep(model, head, ls, opt, world_size=world)
+    assert step.trail and step.reduce == (world > 1)
+    for it in range(STEPS):
+        step(x[it].to(dev), y[it].to(dev), y[it].to(dev), 1.0)
+        sched.step()
+    torch.cuda.synchronize()
+    return torch.stack([opt.arena.flat.detach().cpu(), opt.arena.grad.detach().cpu()]), step.loss.item()
+
+
+def _data():
+    g = torch.Generator().manual_seed(11)
+    return (torch.randn(STEPS, 2 * HALF, 3, 64, 64, generator=g), torch.randint(0, C, (STEPS, 2 * HALF), generator=g))
+
+
+def _worker(rank, world, port, q, out_dir):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        x, y = _data()
+        sl = slice(rank * HALF, (rank + 1) * HALF)
+        flat, loss = _job(world, x[:, sl], y[:, sl])
+        torch.save(flat, os.path.join(out_dir, f"flat{rank}.pt"))  # (tensors through an mp.Queue die with the sender)
+        dist.destroy_process_group()
+        q.put((rank, "ok", loss))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+
+
+def test_two_ranks_match_one_process_on_the_whole_batch(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, msg, loss = q.get(timeout=600)
+        assert loss is not None, msg
+    for p in procs:
+        p.join(60)
+    for rank in range(2):
+        got[rank] = torch.load(os.path.join(str(tmp_path), f"flat{rank}.pt"))
+    assert torch.equal(got[0], got[1]), "ranks diverged"
+    x, y = _data()
+    want, _ = _job(1, x, y)
+    # the last step's reduced gradient: sum over ranks of half-batch means = 2 x the whole-batch mean.  Every image's
+    # forward / backward is row-wise identical in both jobs; only the order of the sums over rows differs.
+    g2, g1 = got[0][1] / 2, want[1]
+    assert ((g2 - g1).norm() / g1.norm()).item() < 2e-3
+    got = {r: t[0] for r, t in got.items()}
+    want = want[0]
+    # weights after three warm-up AdamW steps: Adam's m / sqrt(v) turns a gradient that is zero up to rounding into a
+    # +-lr step, so single elements may differ by 2 lr; in the L2 sense the two trajectories coincide
+    init = _initial_flat()
+    moved = (want - init).norm().item()
+    assert (want - init).abs().max().item() > 1e-4
+    assert (got[0] - want).norm().item() <= 0.05 * moved, ((got[0] - want).norm().item(), moved)
+
+
+def _initial_flat():
+    sys.path.insert(0, ROOT)
+    from swat_amd import optimizers
+    from swat_amd.clip_model import CLIP
+    from swat_amd.models import MyLinear
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = CLIP(vision_cfg=TINY, text_cfg=(8, 64, 64, 1, 1)).to(dev)
+    head = MyLinear(weights=torch.randn(C, TINY[5])).to(dev)
+    args = types.SimpleNamespace(method="finetune", device=dev, lr_classifier=1e-2, lr_backbone=1e-3, temperature=0.07,
+                                 optim="AdamW", wd=1e-2, epochs=1, cutmix_beta=1.0, mix_prob=0.5, loss_name="CE")
+    params, ls = optimizers.set_params(args, model, head, _Lg())
+    opt, _, _ = optimizers.set_optimizer(args, params, [None] * 50)
+    return opt.arena.flat.detach().cpu().clone()

@@ -255,11 +255,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: swat_amd has no CPU fallback")
+    # test hooks (tests/test_gpu_ddp.py): two ranks on the single GPU of a test box over gloo — RCCL refuses that
+    backend = os.environ.get("SWAT_BENCH_TEST_BACKEND", "nccl")
+    local = int(os.environ.get("SWAT_BENCH_TEST_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     args, model, head, step, sched = build_job(dev, world, a.bsz, trail=a.overlap == 2)

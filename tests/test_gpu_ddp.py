@@ -122,3 +122,27 @@ def _initial_flat():
     params, ls = optimizers.set_params(args, model, head, _Lg())
     opt, _, _ = optimizers.set_optimizer(args, params, [None] * 50)
     return opt.arena.flat.detach().cpu().clone()
+
+
+def test_bench_two_rank_plumbing_prints_one_json_line():
+    """bench.py exactly as the driver launches it at N = 2 (torch.distributed.run, one JSON line from rank 0, roofline
+    leg on every rank, barrier + max-over-ranks timing) — on the one test GPU over gloo, so only the plumbing is
+    checked, not the number."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SWAT_BENCH_TEST_BACKEND="gloo", SWAT_BENCH_TEST_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"] + 0.1

@@ -55,6 +55,7 @@ class FusedTrainStep:
             self.trail = sl[0][0] == 0 and sl[-1][1] == self.arena.numel and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
         if self.trail:
             self._opt_stream = torch.cuda.Stream(device=dev, priority=0)
+            self._comm_stream = torch.cuda.Stream(device=dev, priority=0)  # all-reduces queue here, not behind an AdamW slice
 
     def _head_ws(self, B, dev):
         ws = self._ws.get(B)
@@ -134,17 +135,24 @@ class FusedTrainStep:
         main = torch.cuda.current_stream()
         side = self._opt_stream
         side_h = side.cuda_stream
+        comm = self._comm_stream
+        # where a slice's gradients become final: the all-reduce stream at N > 1 (so the next slice's all-reduce does not
+        # wait for this slice's AdamW), the optimizer stream itself on one GPU
+        ready_h = comm.cuda_stream if self.reduce else side_h
         opt = self.opt
         sl = self._slice_args()
 
-        def finish(args, lo, n):  # on `side`: sum over ranks (RCCL, stream-ordered), then this slice's AdamW
+        def finish(args, lo, n):  # sum over ranks (RCCL, stream-ordered on `comm`), then this slice's AdamW on `side`
             if self.reduce:
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(comm):
                     dist.all_reduce(g[lo:lo + n], op=dist.ReduceOp.SUM)
+                side.wait_stream(comm)
             _lib.check(lib.swat_adamw(*args, side_h), "swat_adamw")
 
         opt.begin_step()
         side.wait_stream(main)  # head gradients + this step's scalars
+        if self.reduce:
+            comm.wait_stream(main)
         finish(sl["head"], self.off_head, self.C * self.E)
         if self.off_ls is not None:
             finish(sl["ls"], self.off_ls, 1)
@@ -152,7 +160,7 @@ class FusedTrainStep:
         try:
             for s in range(self.visual.layers + 1, -1, -1):
                 self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
-                lib.swat_vit_lane_order(side_h)  # the lane's tail follows everything stage s ran on either stream
+                lib.swat_vit_lane_order(ready_h)  # the lane's tail follows everything stage s ran on either stream
                 lo, hi = self._stage_slices[s]
                 finish(sl["stages"][s], lo, hi - lo)
         finally:

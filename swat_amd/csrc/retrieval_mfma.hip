@@ -90,6 +90,80 @@ __global__ __launch_bounds__(256) void sim_topk_candidates_kernel(const float* _
     }
 }
 
+// Wide form for the query-against-database scan: a workgroup takes 128 DB rows against a whole group of up to 224
+// queries (7 tiles of 32), so the database is streamed from HBM ONCE per group instead of once per 64 queries and every
+// DB operand fetched from LDS feeds 7 MFMAs.  Wave w owns DB rows 32w..32w+31 of the tile and all 7 query tiles (7
+// accumulators = 112 VGPRs); 32-float k-chunks (46 KB of LDS, three workgroups per CU hide each other's staging).
+// Same k-ascending accumulation per output element as tile_product: bit-identical results.
+constexpr int WQ = 7;            // query tiles of 32 per group
+constexpr int WK = 32;           // floats per k-chunk
+constexpr int WLD = WK + 1;
+__global__ __launch_bounds__(256) void sim_topk_candidates_wide_kernel(const float* __restrict__ queries, int n_q,
+                                                                       const float* __restrict__ db, int64_t n_db, int d,
+                                                                       const float* __restrict__ thr, int64_t row_base,
+                                                                       unsigned long long* __restrict__ cand, int cap,
+                                                                       unsigned* __restrict__ cnt, float* __restrict__ S_out,
+                                                                       int64_t ld_s) {
+    __shared__ float sQ[WQ * 32 * WLD];
+    __shared__ float sD[128 * WLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * 128;
+    const int q0 = blockIdx.y * (WQ * 32);
+    f32x16_t acc[WQ];
+#pragma unroll
+    for (int t = 0; t < WQ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int k0 = 0; k0 < d; k0 += WK) {
+        // stage: queries 224 rows x 32 floats = 1792 float4 (7 per thread), database 128 x 32 floats = 1024 float4 (4 per thread)
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int c = tid + 256 * it;
+            const int row = c >> 3, c4 = c & 7;
+            int rq = q0 + row; rq = rq < n_q ? rq : n_q - 1;
+            const float4 v = *reinterpret_cast<const float4*>(queries + (int64_t)rq * d + k0 + 4 * c4);
+            float* pq = sQ + row * WLD + 4 * c4;
+            pq[0] = v.x; pq[1] = v.y; pq[2] = v.z; pq[3] = v.w;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = tid + 256 * it;
+            const int row = c >> 3, c4 = c & 7;
+            int64_t rb = j0 + row; rb = rb < n_db ? rb : n_db - 1;
+            const float4 v = *reinterpret_cast<const float4*>(db + rb * d + k0 + 4 * c4);
+            float* pd = sD + row * WLD + 4 * c4;
+            pd[0] = v.x; pd[1] = v.y; pd[2] = v.z; pd[3] = v.w;
+        }
+        __syncthreads();
+        const float* lq = sQ + (lane & 31) * WLD + (lane >> 5);
+        const float* ld = sD + (wave * 32 + (lane & 31)) * WLD + (lane >> 5);
+#pragma unroll 4
+        for (int kk = 0; kk < WK; kk += 2) {  // k ascending: lanes 0-31 add k = kk, lanes 32-63 k = kk + 1
+            const float b = ld[kk];
+#pragma unroll
+            for (int t = 0; t < WQ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(lq[t * 32 * WLD + kk], b, acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int64_t col = j0 + wave * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < WQ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = q0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < n_q && col < n_db) {
+                const float s = acc[t][r];
+                if (S_out) S_out[(int64_t)row * ld_s + col] = s;
+                if (cand && s >= thr[row]) {
+                    const unsigned pos = atomicAdd(&cnt[row], 1u);
+                    if (pos < (unsigned)cap)
+                        cand[row * (int64_t)cap + pos] = ((unsigned long long)ordered_bits_m(s) << 32) |
+                                                         (unsigned long long)(0xFFFFFFFFu - (uint32_t)(row_base + col));
+                }
+            }
+        }
+}
+
 // marks[j] = 1 iff exists i < j with <f_i, f_j> > thr.  grid over the upper-triangular tiles (x = j tile >= y = i tile).
 __global__ __launch_bounds__(256) void near_dup_kernel(const float* __restrict__ F, int64_t n, int d, float thr,
                                                        uint8_t* __restrict__ marks) {
@@ -162,9 +236,15 @@ SWAT_API int swat_sim_topk_candidates(const float* queries, int n_q, const float
     SWAT_REQUIRE(n_q > 0 && n_db > 0, "swat_sim_topk_candidates: empty operand");
     SWAT_REQUIRE(row_base + n_db < (1ll << 32), "swat_sim_topk_candidates: global rows must fit 32 bits");
     SWAT_REQUIRE((cand_keys && cand_cnt && thr_dev) || S_out, "swat_sim_topk_candidates: nothing to produce");
-    dim3 grid((unsigned)((n_db + 63) / 64), (unsigned)((n_q + 63) / 64));
-    hipLaunchKernelGGL(sim_topk_candidates_kernel, grid, dim3(256), 0, (hipStream_t)s, queries, n_q, db, n_db, d, thr_dev,
-                       row_base, (unsigned long long*)cand_keys, cap, (unsigned*)cand_cnt, S_out, ld_s);
+    if (n_q > 64) {  // many queries: stream the database once per 224 of them
+        dim3 grid((unsigned)((n_db + 127) / 128), (unsigned)((n_q + WQ * 32 - 1) / (WQ * 32)));
+        hipLaunchKernelGGL(sim_topk_candidates_wide_kernel, grid, dim3(256), 0, (hipStream_t)s, queries, n_q, db, n_db, d,
+                           thr_dev, row_base, (unsigned long long*)cand_keys, cap, (unsigned*)cand_cnt, S_out, ld_s);
+    } else {
+        dim3 grid((unsigned)((n_db + 63) / 64), (unsigned)((n_q + 63) / 64));
+        hipLaunchKernelGGL(sim_topk_candidates_kernel, grid, dim3(256), 0, (hipStream_t)s, queries, n_q, db, n_db, d, thr_dev,
+                           row_base, (unsigned long long*)cand_keys, cap, (unsigned*)cand_cnt, S_out, ld_s);
+    }
     return check_launch("swat_sim_topk_candidates");
 }
 

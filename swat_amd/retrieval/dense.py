@@ -24,7 +24,9 @@ def sim_matrix(queries, db):
 
 
 def _thresholds(queries, db, k, sample, boost):
-    """Per-query pruning threshold from a strided row sample: the value at the rank that should leave ~boost*k rows."""
+    """Per-query pruning threshold from a strided row sample: the value at the rank that should leave ~boost*k rows.
+    (16 384 sample rows put the rank near 30 for k = 500 of 1.25 M: the kept count scatters by ~20 % around boost*k,
+    well inside [k, CAP]; the caller re-brackets when it does not.)"""
     n = db.shape[0]
     nq = queries.shape[0]
     if n <= CAP // 2:
@@ -39,7 +41,7 @@ def _thresholds(queries, db, k, sample, boost):
     return val[:, rank - 1].contiguous()
 
 
-def topk_dense(db, queries, k, row_base=0, sample=65536):
+def topk_dense(db, queries, k, row_base=0, sample=16384):
     """-> (idx [n_q, k] int64 global rows (-1 padded), val [n_q, k] fp32, cnt [n_q]) in (value desc, row asc) order."""
     assert db.dtype == torch.float32 and queries.dtype == torch.float32 and k <= CAP
     n, d = db.shape

@@ -234,7 +234,7 @@ def retrieval_dense_secondary(dev, steps=3):
     return {"metric": "retrieval top-k queries/s (dense N_query x N_db, exact fp32)", "value": round(nq / dt, 1), "unit": "queries/s",
             "config": {"workload": f"{nq} queries x {n} x {d} fp32 rows, k={k}, threshold-pruned exact top-k"},
             "ms_per_pass": round(dt * 1e3, 3),
-            "roofline": {"bound": "mfma", "kernel": "sim_topk_candidates_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(tf, 1),
+            "roofline": {"bound": "mfma", "kernel": "sim_topk_candidates_wide_kernel (v_mfma_f32_32x32x2_f32; 128 DB rows x 224 queries per workgroup)", "achieved": round(tf, 1),
                          "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None}}
 
 

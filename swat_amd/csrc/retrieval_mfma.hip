@@ -93,57 +93,72 @@ __global__ __launch_bounds__(256) void sim_topk_candidates_kernel(const float* _
 // Wide form for the query-against-database scan: a workgroup takes 128 DB rows against a whole group of up to 224
 // queries (7 tiles of 32), so the database is streamed from HBM ONCE per group instead of once per 64 queries and every
 // DB operand fetched from LDS feeds 7 MFMAs.  Wave w owns DB rows 32w..32w+31 of the tile and all 7 query tiles (7
-// accumulators = 112 VGPRs); 32-float k-chunks (46 KB of LDS, three workgroups per CU hide each other's staging).
+// accumulators = 112 AGPRs).  16-float k-chunks go global -> LDS by global_load_lds_dwordx4 into two stage buffers
+// (the next chunk lands while this one is multiplied; one barrier per chunk; 45 KB of LDS: three workgroups per CU).
+// LDS rows are 64 B with the 16-B slot index XORed with (row >> 2) & 3 — applied to the per-lane SOURCE address, the
+// DMA destination being lane-linear — which leaves the lane-per-row ds_read_b32 operand fetches 2-way conflicted.
 // Same k-ascending accumulation per output element as tile_product: bit-identical results.
-constexpr int WQ = 7;            // query tiles of 32 per group
-constexpr int WK = 32;           // floats per k-chunk
-constexpr int WLD = WK + 1;
+constexpr int WQ = 7;                       // query tiles of 32 per group
+constexpr int WK = 16;                      // floats per k-chunk
+constexpr int WROWS = WQ * 32 + 128;        // rows per stage: queries then database
+constexpr int WSTAGE = WROWS * WK * 4;      // bytes
+constexpr int WPIECES = WROWS / 16;         // 1 KB DMA pieces per stage (16 rows each): 22, dealt 6 / 6 / 5 / 5 to the waves
+constexpr int WPW = (WPIECES + 3) / 4;
 __global__ __launch_bounds__(256) void sim_topk_candidates_wide_kernel(const float* __restrict__ queries, int n_q,
                                                                        const float* __restrict__ db, int64_t n_db, int d,
                                                                        const float* __restrict__ thr, int64_t row_base,
                                                                        unsigned long long* __restrict__ cand, int cap,
                                                                        unsigned* __restrict__ cnt, float* __restrict__ S_out,
                                                                        int64_t ld_s) {
-    __shared__ float sQ[WQ * 32 * WLD];
-    __shared__ float sD[128 * WLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t j0 = (int64_t)blockIdx.x * 128;
     const int q0 = blockIdx.y * (WQ * 32);
+    // per-lane source pointers of this wave's pieces (piece p covers stage rows 16p..16p+15; lane -> row 16p + lane/4,
+    // LDS slot lane%4 which must hold the 16-B chunk (slot ^ f(row)) of that row)
+    const float* src[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        int row = 16 * (wave + 4 * i) + (lane >> 2);
+        row = row < WROWS ? row : WROWS - 1;
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        if (row < WQ * 32) {
+            int rq = q0 + row; rq = rq < n_q ? rq : n_q - 1;
+            src[i] = queries + (int64_t)rq * d + 4 * chunk;
+        } else {
+            int64_t rb = j0 + (row - WQ * 32); rb = rb < n_db ? rb : n_db - 1;
+            src[i] = db + rb * d + 4 * chunk;
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i)
+            if (wave + 4 * i < WPIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + stage * WSTAGE + (wave + 4 * i) * 1024),
+                                                 16, 0, 0);
+    };
     f32x16_t acc[WQ];
 #pragma unroll
     for (int t = 0; t < WQ; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (int k0 = 0; k0 < d; k0 += WK) {
-        // stage: queries 224 rows x 32 floats = 1792 float4 (7 per thread), database 128 x 32 floats = 1024 float4 (4 per thread)
+    const int r32 = lane & 31, h = lane >> 5, fr = (r32 >> 2) & 3;
+    const int nchunk = d / WK;
+    issue(0, 0);
+    for (int c = 0; c < nchunk; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c has landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();                       // ... everyone's; and everyone is done reading chunk c-1
+        if (c + 1 < nchunk) issue((c + 1) & 1, (c + 1) * WK);
+        const float* sq = reinterpret_cast<const float*>(smem + (c & 1) * WSTAGE) + r32 * WK;
+        const float* sd = reinterpret_cast<const float*>(smem + (c & 1) * WSTAGE) + (WQ * 32 + wave * 32 + r32) * WK;
 #pragma unroll
-        for (int it = 0; it < 7; ++it) {
-            const int c = tid + 256 * it;
-            const int row = c >> 3, c4 = c & 7;
-            int rq = q0 + row; rq = rq < n_q ? rq : n_q - 1;
-            const float4 v = *reinterpret_cast<const float4*>(queries + (int64_t)rq * d + k0 + 4 * c4);
-            float* pq = sQ + row * WLD + 4 * c4;
-            pq[0] = v.x; pq[1] = v.y; pq[2] = v.z; pq[3] = v.w;
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = tid + 256 * it;
-            const int row = c >> 3, c4 = c & 7;
-            int64_t rb = j0 + row; rb = rb < n_db ? rb : n_db - 1;
-            const float4 v = *reinterpret_cast<const float4*>(db + rb * d + k0 + 4 * c4);
-            float* pd = sD + row * WLD + 4 * c4;
-            pd[0] = v.x; pd[1] = v.y; pd[2] = v.z; pd[3] = v.w;
-        }
-        __syncthreads();
-        const float* lq = sQ + (lane & 31) * WLD + (lane >> 5);
-        const float* ld = sD + (wave * 32 + (lane & 31)) * WLD + (lane >> 5);
-#pragma unroll 4
         for (int kk = 0; kk < WK; kk += 2) {  // k ascending: lanes 0-31 add k = kk, lanes 32-63 k = kk + 1
-            const float b = ld[kk];
+            const int off = (((kk >> 2) ^ fr) << 2) + (kk & 3) + h;
+            const float b = sd[off];
 #pragma unroll
-            for (int t = 0; t < WQ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(lq[t * 32 * WLD + kk], b, acc[t], 0, 0, 0);
+            for (int t = 0; t < WQ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sq[t * 32 * WK + off], b, acc[t], 0, 0, 0);
         }
-        __syncthreads();
     }
     const int64_t col = j0 + wave * 32 + (lane & 31);
 #pragma unroll

@@ -191,7 +191,7 @@ def retrieval_secondary(dev, steps=5):
                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(ms_sim, 4)}}
 
 
-def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=8, warmup=3):
+def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=10, warmup=4):
     """The same fused step on another BASELINE config (configs[2] ViT-B/16, configs[4] ViT-L/14), one GPU, B = 32."""
     args, model, head, step, sched = build_job(dev, 1, bsz, arch=arch)
     g = torch.Generator(device=dev).manual_seed(4321)

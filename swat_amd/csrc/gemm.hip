@@ -979,7 +979,8 @@ static int pick_cfg(int layout, const GemmArgs& a, int batch) {
     // weight gradients run on the backward's second stream beside the data-gradient chain: alone the LDS-DMA 64x64
     // kernel is the fastest for the large ones (21 vs 22 us), but in the step the 128x128 register ring disturbs the
     // main chain least (3.65 vs 3.79 ms/step; 15 / 16 / 30 / 32 in between) — half the operand traffic through L2
-    if ((int64_t)a.M * a.N >= (1 << 21)) return many_rows ? 16 : (a.K >= 384 ? 33 : 14);
+    // (the same holds at 6 304 / 8 224 rows: ViT-L/14 40.1 ms/step with 33 vs 43.3 with the 128x64 LDS-DMA tile)
+    if ((int64_t)a.M * a.N >= (1 << 21)) return a.K >= 384 ? 33 : 14;
     return a.K >= 384 ? 30 : 14;
     return a.K >= 384 ? 30 : 14;
 }

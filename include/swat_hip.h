@@ -206,6 +206,15 @@ int swat_ce_mixed(const float* z, const float* logit_scale_dev, const int64_t* y
 int swat_attn_fwd_small(const void* qkv_bf16, void* out_bf16, int B, int T, int d, int H, swat_stream_t stream);
 int swat_attn_bwd_small(const void* qkv_bf16, const void* dout_bf16, void* dqkv_bf16, int B, int T, int d, int H,
                         swat_stream_t stream);
+/*     64 < T <= 320: one workgroup per (image, head, 64-query tile) walks the key tiles with the running-maximum
+ *     softmax; lse [B*H, T] (optional) receives the row log-sum-exp the backward needs; causal = 1 masks keys > query
+ *     (text tower). */
+int swat_attn_fwd_tiled(const void* qkv_bf16, void* out_bf16, float* lse, int B, int T, int d, int H, int causal,
+                        swat_stream_t stream);
+/*     its backward: one workgroup per (image, head) walks every (query tile, key tile) pair, recomputing P from Q, K
+ *     and lse; out = the forward's output (for delta = rowsum(dO * O)). */
+int swat_attn_bwd_tiled(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16, const float* lse,
+                        void* dqkv_bf16, int B, int T, int d, int H, swat_stream_t stream);
 
 /* A2 (whole)  model.encode_image(images) as one call: CutMix-aware patch embed, cls/pos, ln_pre, L
  *     pre-LN blocks, ln_post(cls), proj -> feats [B,E] fp32 (un-normalised).

@@ -16,51 +16,10 @@
 //  * P and dS feed the next product from the accumulator registers: a lane's 8 values of k-step ks are keys
 //    32ks + 4g + {0..3} and 32ks + 16 + 4g + {0..3}; the LDS operand uses the same key order, so no shuffle is needed.
 // ref: nn.MultiheadAttention inside open_clip's ResidualAttentionBlock, call sites utils/training.py:332,1474
-#include "common.hpp"
+#include "attention.hpp"
 #include "../../include/swat_hip.h"
 
 namespace swat {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float af32x4_t;
-typedef __attribute__((ext_vector_type(4))) short as16x4_t;
-typedef __attribute__((ext_vector_type(8))) short as16x8_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int au32x4_t;
-typedef __attribute__((ext_vector_type(2))) unsigned int au32x2_t;
-
-constexpr int ATP = 72;  // LDS tile pitch in elements (144 B: 16-B aligned rows that step 4 banks)
-
-__device__ __forceinline__ abf16x8_t ld_frag(const unsigned short* p) {
-    return __builtin_bit_cast(abf16x8_t, *reinterpret_cast<const au32x4_t*>(p));
-}
-
-// lane (r16, g) <- tile[krow0 + 0..3][n0 + r16], tile[krow1 + 0..3][n0 + r16]
-__device__ __forceinline__ abf16x8_t tr_frag(const unsigned short* tile, int krow0, int krow1, int n0, int r16) {
-    const unsigned short* a0 = tile + (krow0 + (r16 >> 2)) * ATP + n0 + 4 * (r16 & 3);
-    const unsigned short* a1 = tile + (krow1 + (r16 >> 2)) * ATP + n0 + 4 * (r16 & 3);
-    const as16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) as16x4_t*)a0);
-    const as16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) as16x4_t*)a1);
-    const as16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(abf16x8_t, v);
-}
-
-// stage rows 0..63 (clamped to T-1) x 64 head columns of one operand into an LDS tile
-__device__ __forceinline__ void stage_tile(unsigned short* tile, const unsigned short* src, int64_t ld, int T) {
-    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
-        const int row = i >> 3, ch = i & 7;
-        const int rr = row < T ? row : T - 1;
-        *reinterpret_cast<au32x4_t*>(tile + row * ATP + ch * 8) = *reinterpret_cast<const au32x4_t*>(src + (int64_t)rr * ld + ch * 8);
-    }
-}
-
-__device__ __forceinline__ float xor_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    return fmaxf(v, __shfl_xor(v, 32));
-}
-__device__ __forceinline__ float xor_sum(float v) {
-    v += __shfl_xor(v, 16);
-    return v + __shfl_xor(v, 32);
-}
 
 // S = Q K^T for the wave's 16 query rows, then the row softmax; returns P (fp32, already rounded through bf16) in s[][]
 __device__ __forceinline__ void scores_softmax(const unsigned short* base, int64_t ld, int d, int T, int wave, int r16, int g,
@@ -101,21 +60,6 @@ __device__ __forceinline__ void scores_softmax(const unsigned short* base, int64
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[j][e] = bf2f(f2bf(s[j][e] * inv));
-}
-
-// the wave's 16 x 64 block of P or dS as the k-contiguous operand of the next product (key order: see the header)
-__device__ __forceinline__ abf16x8_t acc_frag(const af32x4_t (&s)[4], int ks) {
-    au32x4_t v;
-    v[0] = pack_bf16x2(s[2 * ks][0], s[2 * ks][1]);
-    v[1] = pack_bf16x2(s[2 * ks][2], s[2 * ks][3]);
-    v[2] = pack_bf16x2(s[2 * ks + 1][0], s[2 * ks + 1][1]);
-    v[3] = pack_bf16x2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
-    return __builtin_bit_cast(abf16x8_t, v);
-}
-
-__device__ __forceinline__ void store4(unsigned short* p, const af32x4_t& v) {
-    au32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    *reinterpret_cast<au32x2_t*>(p) = o;
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
@@ -221,6 +165,86 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const unsigned shor
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Longer sequences (64 < T <= 64 * NT, NT <= 5: ViT-B/16 T = 197, ViT-L/14 T = 257, the text tower's causal T = 77):
+// one workgroup per (image, head, 64-query tile) walks the key tiles with the running-maximum softmax; the row
+// log-sum-exp is saved for the backward.  Same operand layouts as above.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+                                                             float* __restrict__ lse, int T, int d, int H, float scale, int causal) {
+    __shared__ __attribute__((aligned(16))) unsigned short vt[64 * ATP];
+    const int b = blockIdx.x / H, h = blockIdx.x % H, q0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const int64_t ld = 3 * (int64_t)d;
+    const unsigned short* base = qkv + (int64_t)b * T * ld + h * 64;
+    const int q = q0 + wave * 16 + r16, qq = q < T ? q : T - 1;
+    abf16x8_t qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(base + (int64_t)qq * ld + 32 * ks + 8 * g);
+    af32x4_t o[4];
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc) o[jc] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    const int nkt = causal ? (q0 + 63 < T ? q0 / 64 + 1 : (T + 63) / 64) : (T + 63) / 64;  // key tiles this query tile can see
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 64;
+        __syncthreads();  // every wave is done with the previous V tile
+        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+            const int row = i >> 3, ch = i & 7;
+            const int rr = k0 + row < T ? k0 + row : T - 1;
+            *reinterpret_cast<au32x4_t*>(vt + row * ATP + ch * 8) = *reinterpret_cast<const au32x4_t*>(base + 2 * d + (int64_t)rr * ld + ch * 8);
+        }
+        af32x4_t s[4];
+        float mx = m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = k0 + 16 * j + r16, kk = key < T ? key : T - 1;
+            s[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(base + d + (int64_t)kk * ld + 32 * ks + 8 * g), qf[ks], s[j], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kcol = k0 + 16 * j + 4 * g + e;
+                s[j][e] = (kcol < T && !(causal && kcol > q)) ? s[j][e] * scale : -INFINITY;
+                mx = fmaxf(mx, s[j][e]);
+            }
+        }
+        mx = xor_max(mx);
+        const float alpha = mx == -INFINITY ? 1.0f : __expf(m - mx);  // (m = -inf, mx finite: exp(-inf) = 0)
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[j][e] = s[j][e] == -INFINITY ? 0.f : bf2f(f2bf(__expf(s[j][e] - mx)));
+                sum += s[j][e];
+            }
+        l = l * alpha + xor_sum(sum);
+        m = mx;
+        const abf16x8_t pf[2] = {acc_frag(s, 0), acc_frag(s, 1)};
+        __syncthreads();  // V tile staged
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[jc][e] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                o[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(vt, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), pf[ks], o[jc], 0, 0, 0);
+        }
+    }
+    if (q < T) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[jc][e] *= inv;
+            store4(out + ((int64_t)b * T + q) * d + h * 64 + 16 * jc + 4 * g, o[jc]);
+        }
+        if (lse && g == 0) lse[(int64_t)blockIdx.x * T + q] = m + __logf(l);
+    }
+}
+
 }  // namespace swat
 
 SWAT_API int swat_attn_fwd_small(const void* qkv_bf16, void* out_bf16, int B, int T, int d, int H, swat_stream_t stream) {
@@ -238,4 +262,13 @@ SWAT_API int swat_attn_bwd_small(const void* qkv_bf16, const void* dout_bf16, vo
     hipLaunchKernelGGL(swat::attn_bwd_small_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)qkv_bf16,
                        (const unsigned short*)dout_bf16, (unsigned short*)dqkv_bf16, T, d, H, 0.125f);
     return swat::check_launch("swat_attn_bwd_small");
+}
+
+SWAT_API int swat_attn_fwd_tiled(const void* qkv_bf16, void* out_bf16, float* lse, int B, int T, int d, int H, int causal,
+                                 swat_stream_t stream) {
+    SWAT_REQUIRE(qkv_bf16 && out_bf16 && B > 0 && T > 0 && T <= 320 && H > 0 && d == 64 * H,
+                 "swat_attn_fwd_tiled: needs T <= 320 and head width 64 (T=%d d=%d H=%d)", T, d, H);
+    hipLaunchKernelGGL(swat::attn_fwd_tiled_kernel, dim3(B * H, (T + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)qkv_bf16, (unsigned short*)out_bf16, lse, T, d, H, 0.125f, causal);
+    return swat::check_launch("swat_attn_fwd_tiled");
 }

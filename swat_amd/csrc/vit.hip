@@ -64,6 +64,7 @@ struct VitWs {
     unsigned short* P;        // L x [B*H,T,ldp]
     unsigned short *f, *gact; // L x [M,mlp]
     float *mean1, *rstd1, *mean2, *rstd2;  // L x [M]
+    float* lse;               // L x [B*H, T] attention row log-sum-exp (tiled attention, 64 < T <= 320)
     // scratch
     float* S;                 // [B*H,T,ldp] scores / dP
     float* xsplit;            // 4 x [M,d] forward split-K planes
@@ -111,6 +112,7 @@ static VitWs carve(const VitDims& D, void* base) {
     w.gact = (unsigned short*)take(Ls * Mp * D.mlp * 2);
     w.mean1 = (float*)take(Ls * M * 4); w.rstd1 = (float*)take(Ls * M * 4);
     w.mean2 = (float*)take(Ls * M * 4); w.rstd2 = (float*)take(Ls * M * 4);
+    w.lse = (float*)take(Ls * (int64_t)D.B * D.H * D.T * 4);
     w.S = (float*)take(pbytes * 4);
     w.xsplit = (float*)take(4 * M * d * 4);  // split-K partial planes of a forward N = d GEMM (summed by the next LayerNorm)
     if (D.save) {
@@ -148,9 +150,10 @@ static GemmArgs G(const void* A, const void* B, void* C, int M, int N, int K, in
 
 // multi-head attention forward on the packed qkv buffer of one layer
 static int attn_forward(const VitDims& D, const unsigned short* qkv, float* S, unsigned short* P, unsigned short* out,
-                        hipStream_t s, int causal = 0) {
+                        hipStream_t s, int causal = 0, float* lse = nullptr) {
     const int T = D.T, d = D.d, dh = D.dh, H = D.H, ldp = D.ldp;
     if (T <= 64 && dh == 64 && !causal) return swat_attn_fwd_small(qkv, out, D.B, T, d, H, s);  // one workgroup per head
+    if (T <= 320 && dh == 64) return swat_attn_fwd_tiled(qkv, out, lse, D.B, T, d, H, causal, s);  // ... per 64-query tile
     GemmArgs a = G(qkv, qkv + d, S, T, T, dh, 3 * d, 3 * d, ldp, 1);
     a.inner = H; a.sA0 = (int64_t)T * 3 * d; a.sA1 = dh; a.sB0 = a.sA0; a.sB1 = dh; a.sC0 = (int64_t)H * T * ldp; a.sC1 = (int64_t)T * ldp;
     TRY(gemm_dispatch(L_NT, a, D.B * H, s));
@@ -161,9 +164,11 @@ static int attn_forward(const VitDims& D, const unsigned short* qkv, float* S, u
 }
 
 static int attn_backward(const VitDims& D, const unsigned short* qkv, const unsigned short* P, const unsigned short* dout,
-                         float* dP, unsigned short* dS, unsigned short* dqkv, hipStream_t s) {
+                         float* dP, unsigned short* dS, unsigned short* dqkv, hipStream_t s, const unsigned short* out = nullptr,
+                         const float* lse = nullptr) {
     const int T = D.T, d = D.d, dh = D.dh, H = D.H, ldp = D.ldp, BH = D.B * D.H;
     if (T <= 64 && dh == 64) return swat_attn_bwd_small(qkv, dout, dqkv, D.B, T, d, H, s);  // recomputes P from Q, K
+    if (T <= 320 && dh == 64 && out && lse) return swat_attn_bwd_tiled(qkv, out, dout, lse, dqkv, D.B, T, d, H, s);
     const int64_t sP0 = (int64_t)H * T * ldp, sP1 = (int64_t)T * ldp, sQ0 = (int64_t)T * 3 * d, sO0 = (int64_t)T * d;
     {   // dV = P^T dO
         GemmArgs a = G(P, dout, dqkv + 2 * d, T, dh, T, ldp, d, 3 * d, 0);
@@ -302,7 +307,7 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
             TRY(gemm_dispatch(L_NT, a, 1, s));
         }
         // A2d: attention
-        TRY(attn_forward(D, qkv, w.S, P, at, s));
+        TRY(attn_forward(D, qkv, w.S, P, at, s, 0, w.lse + li * (int64_t)D.B * D.H * T));
         // A2e: out_proj + residual
         {
             GemmArgs a = G(at, sh + lo[OUTW], x1, M, d, d, d, d, d, 1);
@@ -485,7 +490,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             // out_proj: da = dx1 W (its weight gradient joins in_proj's on the lane below; bias gradient: from the ln_2 backward)
             TRY(gemm_dispatch(L_NN, G(w.dxb2, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
             // attention backward -> dqkv
-            TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s));
+            TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s, at, w.lse + (int64_t)l * D.B * D.H * T));
             // lane: out_proj dW = dx1^T a and in_proj dW = dqkv^T h1, db = colsum(dqkv)
             to_lane();
             TRY(swat_layernorm_bwd_finish(w.lnws2, M, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], ws));

@@ -156,6 +156,36 @@ def test_attention_one_workgroup_per_head(B, H, T):
     assert (dqkv.float() - dqkv2.float()).abs().max().item() <= 0.02 * ref.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("B,H,T,causal", [(2, 3, 65, 0), (2, 12, 197, 0), (1, 16, 257, 0), (3, 8, 77, 1), (2, 2, 320, 0), (1, 2, 128, 1),
+                                              (2, 4, 50, 0), (1, 1, 64, 1)])
+def test_attention_tiled(B, H, T, causal):
+    """64 < T <= 320 (ViT-B/16, ViT-L/14, the causal text tower): query-tile workgroups with the running-maximum
+    softmax forward (+ row log-sum-exp), one workgroup per head walking all tile pairs backward; vs torch autograd."""
+    from swat_amd import _lib
+    lib = _lib.lib()
+    d = 64 * H
+    qkv = rnd(B * T, 3 * d, seed=31, dtype=BF)
+    do = rnd(B * T, d, seed=32, dtype=BF)
+    out = torch.full((B * T, d), float("nan"), device=qkv.device, dtype=BF)
+    dqkv = torch.full((B * T, 3 * d), float("nan"), device=qkv.device, dtype=BF)
+    lse = torch.full((B * H, T), float("nan"), device=qkv.device)
+    _lib.check(lib.swat_attn_fwd_tiled(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(lse), B, T, d, H, causal, _lib.stream()), "swat_attn_fwd_tiled")
+    q, k, v = [t.reshape(B, T, H, 64).permute(0, 2, 1, 3).float().requires_grad_(True) for t in qkv.float().split(d, dim=1)]
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    if causal:
+        s = s.masked_fill(torch.ones(T, T, device=qkv.device).triu(1).bool(), float("-inf"))
+    o = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+    assert (out.float() - o).abs().max().item() <= 2.0 ** -7 * o.abs().max().item() + 1e-3
+    assert (lse - torch.logsumexp(s, -1).reshape(B * H, T)).abs().max().item() < 5e-3
+    if causal:
+        return  # the text tower is frozen: no backward
+    _lib.check(lib.swat_attn_bwd_tiled(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(do), _lib.ptr(lse), _lib.ptr(dqkv), B, T, d, H,
+                                       _lib.stream()), "swat_attn_bwd_tiled")
+    o.backward(do.float())
+    ref = torch.cat([g.grad.permute(0, 2, 1, 3).reshape(B * T, d) for g in (q, k, v)], dim=1)
+    assert (dqkv.float() - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 1e-3
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_softmax_kernels(causal):
     from swat_amd import ops

@@ -211,8 +211,8 @@ int swat_attn_bwd_small(const void* qkv_bf16, const void* dout_bf16, void* dqkv_
  *     (text tower). */
 int swat_attn_fwd_tiled(const void* qkv_bf16, void* out_bf16, float* lse, int B, int T, int d, int H, int causal,
                         swat_stream_t stream);
-/*     its backward: one workgroup per (image, head) walks every (query tile, key tile) pair, recomputing P from Q, K
- *     and lse; out = the forward's output (for delta = rowsum(dO * O)). */
+/*     its backward in two launches (dQ per query tile; dK, dV per key tile), each recomputing P from Q, K and lse;
+ *     out = the forward's output (for delta = rowsum(dO * O)). */
 int swat_attn_bwd_tiled(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16, const float* lse,
                         void* dqkv_bf16, int B, int T, int d, int H, swat_stream_t stream);
 

@@ -78,8 +78,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Each block = 4 waves; each wave walks rows  wave_global, wave_global + nwaves, ...
 // --------------------------------------------------------------------------------------------
 constexpr int LNB_MAX_BLOCKS = 1024;  // one row per wave up to 8 192 rows (ViT-L/14 at B = 32); partial sums: 1024 x 3 x d floats
-constexpr int LNB_WAVES = 8;  // one row per wave and pass: M = 1600 rows -> 200 blocks, every wave exactly one row
-template <int NSPLIT, int VPL>  // VPL float4 per lane: d <= 256 * VPL
+// waves per workgroup: 8 up to d = 768 (M = 1600 rows -> 200 workgroups, every wave exactly one row, ~126 VGPRs: two
+// workgroups per CU); 4 for wider rows (~150 VGPRs: three 4-wave workgroups per CU instead of one 8-wave workgroup)
+static inline int lnb_waves(int d) { return d <= 768 ? 8 : 4; }
+static inline int lnb_blocks(int rows, int d) {
+    const int w = lnb_waves(d);
+    const int n = (rows + w - 1) / w;
+    return n > LNB_MAX_BLOCKS ? LNB_MAX_BLOCKS : n;
+}
+template <int NSPLIT, int VPL, int LNB_WAVES = (VPL <= 3 ? 8 : 4)>  // VPL float4 per lane: d <= 256 * VPL
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __restrict__ dy, int64_t dy_stride,
                                                      const float* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -90,15 +97,13 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
     __shared__ float sh[LNB_WAVES][64 * 4 * VPL];  // [wave][d], reused for dgamma / dbeta / colsum(dx_bf16)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
-    float4 dg[VPL], db[VPL], dcs[VPL], gm[VPL];
+    float4 dg[VPL], db[VPL], dcs[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[i] = dg[i];
         dcs[i] = dg[i];
         const int c = lane + 64 * i;
-        gm[i] = dg[i];
-        if (c < nv) gm[i] = reinterpret_cast<const float4*>(gamma)[c];
     }
     for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
         const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * dy_stride);
@@ -130,12 +135,14 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
                 }
                 const float4 xv = xh[i];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                const float a0 = dyv[i].x * gm[i].x, a1 = dyv[i].y * gm[i].y, a2 = dyv[i].z * gm[i].z, a3 = dyv[i].w * gm[i].w;
+                const float4 gmv = reinterpret_cast<const float4*>(gamma)[c];  // (L1-resident; not kept across rows)
+                const float a0 = dyv[i].x * gmv.x, a1 = dyv[i].y * gmv.y, a2 = dyv[i].z * gmv.z, a3 = dyv[i].w * gmv.w;
                 s1 += a0 + a1 + a2 + a3;
                 s2 += a0 * xh[i].x + a1 * xh[i].y + a2 * xh[i].z + a3 * xh[i].w;
                 dg[i].x += dyv[i].x * xh[i].x; dg[i].y += dyv[i].y * xh[i].y;
                 dg[i].z += dyv[i].z * xh[i].z; dg[i].w += dyv[i].w * xh[i].w;
                 db[i].x += dyv[i].x; db[i].y += dyv[i].y; db[i].z += dyv[i].z; db[i].w += dyv[i].w;
+                dyv[i] = make_float4(a0, a1, a2, a3);  // from here on only dy * gamma is needed
             }
         }
         const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
@@ -144,10 +151,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
             const int c = lane + 64 * i;
             if (c < nv) {
                 float4 o;
-                o.x = rs * (dyv[i].x * gm[i].x - m1 - xh[i].x * m2);
-                o.y = rs * (dyv[i].y * gm[i].y - m1 - xh[i].y * m2);
-                o.z = rs * (dyv[i].z * gm[i].z - m1 - xh[i].z * m2);
-                o.w = rs * (dyv[i].w * gm[i].w - m1 - xh[i].w * m2);
+                o.x = rs * (dyv[i].x - m1 - xh[i].x * m2);
+                o.y = rs * (dyv[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (dyv[i].z - m1 - xh[i].z * m2);
+                o.w = rs * (dyv[i].w - m1 - xh[i].w * m2);
                 if (dx_add) {
                     const float4 a = add[i];
                     o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
@@ -475,7 +482,7 @@ SWAT_API int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d) {
 }
 
 #define LNB_LAUNCH(NS, V)                                                                                                    \
-    hipLaunchKernelGGL((ln_bwd_kernel<NS, V>), dim3(nblk), dim3(64 * LNB_WAVES), 0, (hipStream_t)s, dy, dy_stride, x, x_stride,  \
+    hipLaunchKernelGGL((ln_bwd_kernel<NS, V>), dim3(nblk), dim3(64 * lnb_waves(d)), 0, (hipStream_t)s, dy, dy_stride, x, x_stride,  \
                        gamma, mean, rstd, dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride,      \
                        (float*)workspace, rows, d, split_stride)
 #define LNB_SPLITS(V)                       \
@@ -498,8 +505,7 @@ SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float*
                                 float* dbeta, float* dcolsum, void* workspace, int rows, int d, swat_stream_t s) {
     SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV, "swat_layernorm_bwd: d=%d unsupported", d);
     if (rows <= 0) return 0;
-    int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
-    if (nblk > LNB_MAX_BLOCKS) nblk = LNB_MAX_BLOCKS;
+    const int nblk = lnb_blocks(rows, d);
     const int nsplit = 1;
     const int64_t split_stride = 0;
     LNB_DISPATCH();
@@ -528,8 +534,7 @@ SWAT_API int swat_layernorm_bwd_partial(const float* dy, int64_t dy_stride, int 
                                         void* dx_bf16, int64_t dxb_stride, void* workspace, int rows, int d, swat_stream_t s) {
     SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && nsplit >= 1 && nsplit <= 4, "swat_layernorm_bwd_partial: bad arguments");
     if (rows <= 0) return 0;
-    int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
-    if (nblk > LNB_MAX_BLOCKS) nblk = LNB_MAX_BLOCKS;
+    const int nblk = lnb_blocks(rows, d);
     LNB_DISPATCH();
     return check_launch("swat_layernorm_bwd_partial");
 }
@@ -537,8 +542,7 @@ SWAT_API int swat_layernorm_bwd_partial(const float* dy, int64_t dy_stride, int 
 SWAT_API int swat_layernorm_bwd_finish(const void* workspace, int rows, int d, float* dgamma, float* dbeta, float* dcolsum,
                                        swat_stream_t s) {
     if (rows <= 0) return 0;
-    int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
-    if (nblk > LNB_MAX_BLOCKS) nblk = LNB_MAX_BLOCKS;
+    const int nblk = lnb_blocks(rows, d);
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 31) / 32, 3), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
     return check_launch("swat_layernorm_bwd_finish");

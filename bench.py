@@ -204,8 +204,7 @@ def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=10, warmup=4):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     assert math.isfinite(step.loss.item()), "training diverged"
-    del step, model, head
-    torch.cuda.empty_cache()
+    del step, model, head  # (no empty_cache(): memory handed back to the driver and mapped again can come back 2-3x slower)
     return {"metric": f"finetune img/s ({arch} bsz={bsz})", "value": round(bsz / dt, 1), "unit": "img/s",
             "ms_per_step": round(dt * 1e3, 3), "steps": steps,
             "config": {"workload": f"{arch} (random init) --method cutmix finetune step, 200 classes, one GPU"},
@@ -316,11 +315,10 @@ def main():
     if world == 1:
         if not a.no_cpu_baseline:
             del step, model
-            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(a.bsz)
         if not a.no_secondary:
-            # (the finetune records first: after the retrieval passes have cycled ~10 GB through the caching allocator the
-            #  same ViT-B/16 step measures 20-30 % slower — buffer placement, not the kernels)
+            # (nothing here returns memory to the driver: a step whose buffers were hipFree'd and mapped again measured up to
+            #  2.9x slower at identical virtual addresses — tools/micro/sec_order32.py)
             ft = [finetune_secondary(dev, "ViT-B-16", vit_gflop_per_img(768, 12, 197, 3 * 16 * 16, 512)),
                   finetune_secondary(dev, "ViT-L-14", vit_gflop_per_img(1024, 24, 257, 3 * 14 * 14, 768))]
             out["secondary"] = [retrieval_secondary(dev), retrieval_dense_secondary(dev)] + ft

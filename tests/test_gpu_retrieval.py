@@ -150,7 +150,8 @@ def test_full_size_properties():
     assert np.array_equal(idx[:2].cpu().numpy(), o_idx)
 
 
-@pytest.mark.parametrize("n,nq,k", [(3000, 5, 17), (70000, 33, 500), (200001, 200, 500)])
+@pytest.mark.parametrize("n,nq,k", [(3000, 5, 17), (70000, 33, 500), (200001, 200, 500), (50000, 65, 100), (30001, 225, 64),
+                                    (20000, 449, 32)])
 def test_dense_mfma_topk_bit_exact_vs_oracle(n, nq, k):
     """(N_query x N_db) scan on the fp32 matrix cores: same bits as the lane-per-row kernel and the C oracle."""
     from swat_amd.retrieval import dense, ops

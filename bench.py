@@ -212,6 +212,22 @@ def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=10, warmup=4):
             "algorithmic_gflop_per_img": gflop_per_img}
 
 
+_ARCH_GFLOP = {"ViT-B-16": (768, 12, 197, 3 * 16 * 16, 512), "ViT-L-14": (1024, 24, 257, 3 * 14 * 14, 768)}
+
+
+def finetune_secondary_subprocess(arch):
+    """finetune_secondary in a child process of its own: buffers carved out of blocks the caching allocator recycled
+    from an earlier, differently sized job measured 20-30 % slower than the same step in a fresh process, so every
+    configuration gets the allocation pattern a real training run has."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--finetune-only", arch], capture_output=True, text=True,
+                       timeout=1200)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"metric": f"finetune img/s ({arch} bsz=32)", "value": None, "error": (r.stderr or r.stdout)[-400:]}
+    return json.loads(lines[-1])
+
+
 def retrieval_dense_secondary(dev, steps=3):
     """BASELINE config 4 on one shard: N_query = 200 random unit queries against 1.25 M x 512 fp32 rows (the per-GPU share
     of 10 M), k = 500, exact (value desc, row asc) top-k on the fp32 matrix cores (157.3 TF peak)."""
@@ -247,7 +263,13 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--overlap", type=int, default=2, help="0: one stream; 1: weight-gradient lane in the backward; "
                     "2 (default, what swat_amd.training runs): lane + per-stage all-reduce / AdamW trailing the backward")
+    ap.add_argument("--finetune-only", default=None, help="internal: print one finetune_secondary record for this arch and exit")
     a = ap.parse_args()
+    if a.finetune_only:
+        torch.cuda.set_device(0)
+        print(json.dumps(finetune_secondary(torch.device("cuda", 0), a.finetune_only, vit_gflop_per_img(*_ARCH_GFLOP[a.finetune_only]))),
+              flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -319,8 +341,7 @@ def main():
         if not a.no_secondary:
             # (nothing here returns memory to the driver: a step whose buffers were hipFree'd and mapped again measured up to
             #  2.9x slower at identical virtual addresses — tools/micro/sec_order32.py)
-            ft = [finetune_secondary(dev, "ViT-B-16", vit_gflop_per_img(768, 12, 197, 3 * 16 * 16, 512)),
-                  finetune_secondary(dev, "ViT-L-14", vit_gflop_per_img(1024, 24, 257, 3 * 14 * 14, 768))]
+            ft = [finetune_secondary_subprocess(arch) for arch in ("ViT-B-16", "ViT-L-14")]
             out["secondary"] = [retrieval_secondary(dev), retrieval_dense_secondary(dev)] + ft
     if rank == 0:
         print(json.dumps(out), flush=True)

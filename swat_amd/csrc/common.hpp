@@ -38,6 +38,16 @@ __device__ __forceinline__ unsigned short f2bf(float f) { return (unsigned short
 
 }  // namespace swat
 
+// a HIP runtime call inside a function that returns the ABI's int status
+#define SWAT_HIP(call)                                                       \
+    do {                                                                     \
+        const hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) {                                             \
+            swat::set_error("%s: %s", #call, hipGetErrorString(e__));        \
+            return -1;                                                       \
+        }                                                                    \
+    } while (0)
+
 #define SWAT_REQUIRE(cond, ...)                       \
     do {                                              \
         if (!(cond)) {                                \

@@ -103,7 +103,6 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[i] = dg[i];
         dcs[i] = dg[i];
-        const int c = lane + 64 * i;
     }
     for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
         const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * dy_stride);

@@ -1044,14 +1044,14 @@ SWAT_API int swat_gemm_set_tile(int cfg) {
 SWAT_API int swat_gemm_prof_begin(int max_launches) {
     using swat::g_prof;
     if (g_prof.ev) {
-        for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+        for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
         delete[] g_prof.ev; delete[] g_prof.kind; delete[] g_prof.flops;
     }
     g_prof.cap = max_launches; g_prof.n = 0;
     g_prof.ev = new hipEvent_t[2 * max_launches];
     g_prof.kind = new int[max_launches];
     g_prof.flops = new double[max_launches];
-    for (int i = 0; i < 2 * max_launches; ++i) hipEventCreate(&g_prof.ev[i]);
+    for (int i = 0; i < 2 * max_launches; ++i) SWAT_HIP(hipEventCreate(&g_prof.ev[i]));
     g_prof.on = true;
     return 0;
 }
@@ -1062,9 +1062,9 @@ SWAT_API int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, doub
     g_prof.on = false;
     for (int k = 0; k < 6; ++k) { ms_by_kind[k] = 0; count_by_kind[k] = 0; flops_by_kind[k] = 0; }
     for (int i = 0; i < g_prof.n; ++i) {
-        hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        SWAT_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
         float ms = 0.f;
-        hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        SWAT_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
         ms_by_kind[g_prof.kind[i]] += ms;
         count_by_kind[g_prof.kind[i]] += 1;
         flops_by_kind[g_prof.kind[i]] += g_prof.flops[i];

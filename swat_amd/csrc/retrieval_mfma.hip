@@ -274,7 +274,7 @@ SWAT_API int swat_candidates_topk(const void* cand_keys, int cap, const void* ca
 SWAT_API int swat_near_dup_marks(const float* feats, int64_t n, int d, float thr, uint8_t* marks, swat_stream_t s) {
     SWAT_REQUIRE(d > 0 && d % MK == 0, "swat_near_dup_marks: d=%d must be a multiple of %d", d, MK);
     if (n <= 0) return 0;
-    hipMemsetAsync(marks, 0, (size_t)n, (hipStream_t)s);
+    SWAT_HIP(hipMemsetAsync(marks, 0, (size_t)n, (hipStream_t)s));
     const unsigned t = (unsigned)((n + 63) / 64);
     hipLaunchKernelGGL(near_dup_kernel, dim3(t, t), dim3(256), 0, (hipStream_t)s, feats, n, d, thr, marks);
     return check_launch("swat_near_dup_marks");

@@ -357,7 +357,7 @@ struct SideLane {
     hipEvent_t next() {
         if (ev.size() < 1024) {
             hipEvent_t e;
-            hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
             ev.push_back(e);
             return e;
         }
@@ -366,7 +366,7 @@ struct SideLane {
     int ensure() {
         if (st) return 0;
         int least = 0, greatest = 0;
-        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 1;
         return hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) == hipSuccess ? 0 : 1;
     }
 };
@@ -388,16 +388,18 @@ SWAT_API swat_stream_t swat_vit_lane_stream(void) {
 SWAT_API int swat_vit_lane_order(swat_stream_t stream) {
     SWAT_REQUIRE(g_side.ensure() == 0, "swat_vit_lane_order: cannot create the weight-gradient stream");
     hipEvent_t e = g_side.next();
-    hipEventRecord(e, g_side.st);
-    hipStreamWaitEvent((hipStream_t)stream, e, 0);
+    SWAT_REQUIRE(e, "cannot create an event");
+    SWAT_HIP(hipEventRecord(e, g_side.st));
+    SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
     return 0;
 }
 
 SWAT_API int swat_vit_backward_join(swat_stream_t stream) {
     if (!g_side.open) return 0;
     hipEvent_t e = g_side.next();
-    hipEventRecord(e, g_side.st);
-    hipStreamWaitEvent((hipStream_t)stream, e, 0);
+    SWAT_REQUIRE(e, "cannot create an event");
+    SWAT_HIP(hipEventRecord(e, g_side.st));
+    SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
     g_side.open = false;
     g_side.doneA = g_side.doneB = nullptr;
     return 0;
@@ -424,20 +426,20 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
     hipStream_t ws = fork ? g_side.st : s;  // weight-gradient lane
     hipEvent_t &doneA = g_side.doneA, &doneB = g_side.doneB;
     if (fork) g_side.open = true;
+    bool lane_ok = true;  // an event call failed: reported once the stages are enqueued
     auto to_lane = [&]() {  // everything issued so far on the main stream precedes what the lane runs next
         if (!fork) return;
         hipEvent_t e = g_side.next();
-        hipEventRecord(e, s);
-        hipStreamWaitEvent(ws, e, 0);
+        if (!e || hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(ws, e, 0) != hipSuccess) lane_ok = false;
     };
     auto lane_done = [&](hipEvent_t& slot) {
         if (!fork) return;
         slot = g_side.next();
-        hipEventRecord(slot, ws);
+        if (!slot || hipEventRecord(slot, ws) != hipSuccess) lane_ok = false;
     };
     auto wait_lane = [&](hipEvent_t& slot) {
         if (!slot) return;
-        hipStreamWaitEvent(s, slot, 0);
+        if (hipStreamWaitEvent(s, slot, 0) != hipSuccess) lane_ok = false;
         slot = nullptr;
     };
 
@@ -449,8 +451,8 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(swat_sgemm_small(w.u, dfeats, grads + O.proj, d, D.E, D.B, 1, d, D.E, 1, D.E, 1.0f, 0, s));
             TRY(swat_sgemm_small(dfeats, params + O.proj, w.du, D.B, d, D.E, D.E, 1, 1, D.E, d, 1.0f, 0, s));
             wait_lane(doneA);
-            hipMemsetAsync(w.dx, 0, (size_t)M * d * 4, s);
-            hipMemsetAsync(w.dxb, 0, (size_t)M * d * 2, s);
+            SWAT_HIP(hipMemsetAsync(w.dx, 0, (size_t)M * d * 4, s));
+            SWAT_HIP(hipMemsetAsync(w.dxb, 0, (size_t)M * d * 2, s));
             const float* xl = w.xs + (int64_t)D.L * M * d;
             TRY(swat_layernorm_bwd(w.du, d, xl, (int64_t)T * d, params + O.lnpost_w, w.mean_post, w.rstd_post, nullptr, 0, w.dx,
                                    (int64_t)T * d, w.dxb, (int64_t)T * d, grads + O.lnpost_w, grads + O.lnpost_b,
@@ -523,6 +525,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             ln1_pending = -1;
         }
     }
+    SWAT_REQUIRE(lane_ok, "swat_vit_backward: a stream-ordering call (hipEventRecord / hipStreamWaitEvent) failed");
     if (g_overlap == 1) TRY(swat_vit_backward_join(stream));  // the caller's stream sees every gradient of the requested stages
     return 0;
 }

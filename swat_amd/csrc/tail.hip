@@ -209,6 +209,10 @@ SWAT_API int swat_sgemm_small(const float* A, const float* B, float* C, int M, i
     if (sbn == 1 && K >= 64) {
         hipLaunchKernelGGL(sgemm_small_ncontig_kernel, dim3((N + 63) / 64, (M + 3) / 4), dim3(1024), 0, (hipStream_t)s, A, B, C, M,
                            N, K, sam, sak, sbk, ldc, alpha, accumulate);
+    } else if (sak == 1 && sbk == 1 && sam == K && sbn == K && alpha == 1.0f && !accumulate && K % 64 == 0 && M <= 64) {
+        // both operands k-contiguous, a handful of rows: the fp32 matrix-core tile product of the retrieval path
+        // (v_mfma_f32_32x32x2_f32, k-ordered fp32 chain) — head logits z = fn W^T and du = df proj^T
+        return swat_sim_topk_candidates(A, M, B, N, K, nullptr, 0, nullptr, 0, nullptr, C, ldc, s);
     } else if (sak == 1 && sbk == 1 && K <= 1024 && M <= 256) {
         hipLaunchKernelGGL(sgemm_small_kcontig_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)s, A, B, C, M, N, K, sam, sbn,
                            ldc, alpha, accumulate);

@@ -897,25 +897,29 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s, hip
     {                                                                                                     \
         GemmArgs b = a;                                                                                   \
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
-        hipExtLaunchKernelGGL((gemm_ring_kernel<LAYOUT, BM_, BN_, D_>), grid, dim3(256), 0, s, ev0, ev1, 0, b);           \
+        if (ev0) hipExtLaunchKernelGGL((gemm_ring_kernel<LAYOUT, BM_, BN_, D_>), grid, dim3(256), 0, s, ev0, ev1, 0, b); \
+        else hipLaunchKernelGGL((gemm_ring_kernel<LAYOUT, BM_, BN_, D_>), grid, dim3(256), 0, s, b);           \
     }
 #define SWAT_DMA(BM_, BN_, NS_)                                                                           \
     {                                                                                                     \
         GemmArgs b = a;                                                                                   \
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
-        hipExtLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_>), grid, dim3(256), 0, s, ev0, ev1, 0, b);           \
+        if (ev0) hipExtLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_>), grid, dim3(256), 0, s, ev0, ev1, 0, b); \
+        else hipLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_>), grid, dim3(256), 0, s, b);           \
     }
 #define SWAT_RING2(BM_, BN_, D_)                                                                          \
     {                                                                                                     \
         GemmArgs b = a;                                                                                   \
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
-        hipExtLaunchKernelGGL((gemm_ring2_kernel<LAYOUT, BM_, BN_, D_>), grid, dim3(256), 0, s, ev0, ev1, 0, b);          \
+        if (ev0) hipExtLaunchKernelGGL((gemm_ring2_kernel<LAYOUT, BM_, BN_, D_>), grid, dim3(256), 0, s, ev0, ev1, 0, b); \
+        else hipLaunchKernelGGL((gemm_ring2_kernel<LAYOUT, BM_, BN_, D_>), grid, dim3(256), 0, s, b);          \
     }
 #define SWAT_DMA8(BM_, BN_, NS_, WGM_, WGN_)                                                              \
     {                                                                                                     \
         GemmArgs b = a;                                                                                   \
         dim3 grid = plan_grid(b, BM_, BN_, batch);                                                        \
-        hipExtLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, ev0, ev1, 0, b); \
+        if (ev0) hipExtLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, ev0, ev1, 0, b); \
+        else hipLaunchKernelGGL((gemm_dma_kernel<LAYOUT, BM_, BN_, NS_, WGM_, WGN_>), grid, dim3(512), 0, s, b); \
     }
     if (cfg == 43 && a.K % 64 != 0) cfg = 20;
     if (cfg >= 25 && cfg <= 28 && a.K % 64 != 0) cfg = 20;

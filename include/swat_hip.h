@@ -246,7 +246,10 @@ int swat_vit_backward(const int32_t* dims, const int64_t* offs, const float* par
  *     Same kernels and buffers in every mode: the gradients are bit-identical. */
 int swat_vit_set_overlap(int mode);
 swat_stream_t swat_vit_lane_stream(void);
+swat_stream_t swat_vit_aux_stream(int i); /* i = 0, 1: two more process-wide streams created together with the lane (the
+                                            * data-parallel step's all-reduce and optimizer streams) */
 int swat_vit_lane_order(swat_stream_t stream); /* `stream` waits for what the lane holds now; the lane is not joined */
+int swat_vit_lane_follow(swat_stream_t stream); /* the lane waits for what `stream` holds now (then work may be queued on swat_vit_lane_stream()) */
 int swat_vit_backward_join(swat_stream_t stream);
 /* A3+A4+A6 fused with their backward (ref utils/training.py:1475-1481): loss, d/dfeats, d/dW_head,
  *     d/dlogit_scale.  want_grad = 0: forward only (validate, testing.py:430-447); z_out / feat_norm_out

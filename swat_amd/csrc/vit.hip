@@ -363,11 +363,18 @@ struct SideLane {
         }
         return ev[used++ % ev.size()];
     }
+    hipStream_t aux[2] = {nullptr, nullptr};  // the data-parallel step's all-reduce / optimizer streams
     int ensure() {
         if (st) return 0;
+        // all side streams of the process are created here, once and back to back: streams share a small number of
+        // hardware queues, and a later-created stream that lands on the queue of the main stream or of the lane was
+        // measured to triple the step time (tools/micro/sec_order32.py)
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 1;
-        return hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) == hipSuccess ? 0 : 1;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) return 1;
+        for (int i = 0; i < 2; ++i)
+            if (hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking) != hipSuccess) return 1;
+        return 0;
     }
 };
 static SideLane g_side;
@@ -385,12 +392,27 @@ SWAT_API swat_stream_t swat_vit_lane_stream(void) {
     return (swat_stream_t)g_side.st;
 }
 
+SWAT_API swat_stream_t swat_vit_aux_stream(int i) {
+    if (i < 0 || i > 1 || g_side.ensure()) return nullptr;
+    return (swat_stream_t)g_side.aux[i];
+}
+
 SWAT_API int swat_vit_lane_order(swat_stream_t stream) {
     SWAT_REQUIRE(g_side.ensure() == 0, "swat_vit_lane_order: cannot create the weight-gradient stream");
     hipEvent_t e = g_side.next();
     SWAT_REQUIRE(e, "cannot create an event");
     SWAT_HIP(hipEventRecord(e, g_side.st));
     SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+    return 0;
+}
+
+SWAT_API int swat_vit_lane_follow(swat_stream_t stream) {
+    SWAT_REQUIRE(g_side.ensure() == 0, "swat_vit_lane_follow: cannot create the weight-gradient stream");
+    hipEvent_t e = g_side.next();
+    SWAT_REQUIRE(e, "cannot create an event");
+    SWAT_HIP(hipEventRecord(e, (hipStream_t)stream));
+    SWAT_HIP(hipStreamWaitEvent(g_side.st, e, 0));
+    g_side.open = true;  // the caller joins (swat_vit_backward_join) before it reads what it queued on the lane
     return 0;
 }
 

@@ -54,8 +54,9 @@ class FusedTrainStep:
                         + ([(self.off_ls, self.off_ls + 64)] if self.off_ls is not None else []))
             self.trail = sl[0][0] == 0 and sl[-1][1] == self.arena.numel and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
         if self.trail:
-            self._opt_stream = torch.cuda.Stream(device=dev, priority=0)
-            self._comm_stream = torch.cuda.Stream(device=dev, priority=0)  # all-reduces queue here, not behind an AdamW slice
+            # process-wide streams owned by the library (created once, together with the weight-gradient lane)
+            self._comm_stream = torch.cuda.ExternalStream(_lib.lib().swat_vit_aux_stream(0), device=dev)  # all-reduces
+            self._opt_stream = torch.cuda.ExternalStream(_lib.lib().swat_vit_aux_stream(1), device=dev)   # AdamW slices at N > 1
 
     def _head_ws(self, B, dev):
         ws = self._ws.get(B)
@@ -134,15 +135,18 @@ class FusedTrainStep:
         lib = _lib.lib()
         main = torch.cuda.current_stream()
         side = self._opt_stream
-        side_h = side.cuda_stream
         comm = self._comm_stream
-        # where a slice's gradients become final: the all-reduce stream at N > 1 (so the next slice's all-reduce does not
-        # wait for this slice's AdamW), the optimizer stream itself on one GPU
-        ready_h = comm.cuda_stream if self.reduce else side_h
+        lane_h = lib.swat_vit_lane_stream()
+        # One GPU: the AdamW slices go straight onto the weight-gradient lane (main + lane are the only streams: every
+        # extra stream is another chance of sharing a hardware queue with one of them, which was measured to triple the
+        # step time — tools/micro/sec_order32.py).  N > 1: all-reduces on `comm` (so the next slice's all-reduce does not
+        # queue behind this slice's AdamW), AdamW on `side` behind them.
+        side_h = side.cuda_stream if self.reduce else lane_h
+        ready_h = comm.cuda_stream
         opt = self.opt
         sl = self._slice_args()
 
-        def finish(args, lo, n):  # sum over ranks (RCCL, stream-ordered on `comm`), then this slice's AdamW on `side`
+        def finish(args, lo, n):  # sum over ranks (RCCL, stream-ordered on `comm`), then this slice's AdamW
             if self.reduce:
                 with torch.cuda.stream(comm):
                     dist.all_reduce(g[lo:lo + n], op=dist.ReduceOp.SUM)
@@ -150,23 +154,27 @@ class FusedTrainStep:
             _lib.check(lib.swat_adamw(*args, side_h), "swat_adamw")
 
         opt.begin_step()
-        side.wait_stream(main)  # head gradients + this step's scalars
-        if self.reduce:
-            comm.wait_stream(main)
-        finish(sl["head"], self.off_head, self.C * self.E)
-        if self.off_ls is not None:
-            finish(sl["ls"], self.off_ls, 1)
         _lib.check(lib.swat_vit_set_overlap(2), "swat_vit_set_overlap")
         try:
+            if self.reduce:
+                side.wait_stream(main)  # head gradients + this step's scalars
+                comm.wait_stream(main)
+            else:
+                _lib.check(lib.swat_vit_lane_follow(main.cuda_stream), "swat_vit_lane_follow")
+            finish(sl["head"], self.off_head, self.C * self.E)
+            if self.off_ls is not None:
+                finish(sl["ls"], self.off_ls, 1)
             for s in range(self.visual.layers + 1, -1, -1):
                 self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
-                lib.swat_vit_lane_order(ready_h)  # the lane's tail follows everything stage s ran on either stream
+                if self.reduce:
+                    lib.swat_vit_lane_order(ready_h)  # `comm` follows everything stage s ran on either stream
                 lo, hi = self._stage_slices[s]
                 finish(sl["stages"][s], lo, hi - lo)
         finally:
             lib.swat_vit_backward_join(main.cuda_stream)
             lib.swat_vit_set_overlap(1)
-        main.wait_stream(side)
+        if self.reduce:
+            main.wait_stream(side)
         opt.end_step()
         return self.loss
 

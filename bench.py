@@ -204,7 +204,7 @@ def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=10, warmup=4):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     assert math.isfinite(step.loss.item()), "training diverged"
-    del step, model, head  # (no empty_cache(): memory handed back to the driver and mapped again can come back 2-3x slower)
+    del step, model, head
     return {"metric": f"finetune img/s ({arch} bsz={bsz})", "value": round(bsz / dt, 1), "unit": "img/s",
             "ms_per_step": round(dt * 1e3, 3), "steps": steps,
             "config": {"workload": f"{arch} (random init) --method cutmix finetune step, 200 classes, one GPU"},
@@ -216,9 +216,8 @@ _ARCH_GFLOP = {"ViT-B-16": (768, 12, 197, 3 * 16 * 16, 512), "ViT-L-14": (1024, 
 
 
 def finetune_secondary_subprocess(arch):
-    """finetune_secondary in a child process of its own: buffers carved out of blocks the caching allocator recycled
-    from an earlier, differently sized job measured 20-30 % slower than the same step in a fresh process, so every
-    configuration gets the allocation pattern a real training run has."""
+    """finetune_secondary in a child process of its own, so every configuration is measured the way a training run of
+    that configuration would start (fresh allocator, fresh streams)."""
     import subprocess
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--finetune-only", arch], capture_output=True, text=True,
                        timeout=1200)
@@ -339,8 +338,6 @@ def main():
             del step, model
             out["cpu_baseline"] = cpu_baseline(a.bsz)
         if not a.no_secondary:
-            # (nothing here returns memory to the driver: a step whose buffers were hipFree'd and mapped again measured up to
-            #  2.9x slower at identical virtual addresses — tools/micro/sec_order32.py)
             ft = [finetune_secondary_subprocess(arch) for arch in ("ViT-B-16", "ViT-L-14")]
             out["secondary"] = [retrieval_secondary(dev), retrieval_dense_secondary(dev)] + ft
     if rank == 0:

@@ -45,9 +45,9 @@ class FusedTrainStep:
                 lo = self.arena.offset_of(ps[0])
                 hi = self.arena.offset_of(ps[-1]) + (ps[-1].numel() + 63) // 64 * 64
                 self._stage_slices.append((lo, hi))
-        # trailing mode: per backward stage, the slice's all-reduce and AdamW run on a third stream behind the
-        # weight-gradient lane (swat_hip.h: swat_vit_set_overlap mode 2), so the HBM-bound optimizer overlaps the
-        # GEMM-bound backward of the stages below.  Needs the slices to tile the whole arena.
+        # trailing mode: per backward stage, the slice's (all-reduce and) AdamW trail the weight-gradient lane
+        # (swat_hip.h: swat_vit_set_overlap mode 2), so the HBM-bound optimizer overlaps the GEMM-bound backward of the
+        # stages below.  Needs the slices to tile the whole arena.
         self.trail = False
         if trail and self.train_visual:
             sl = sorted(self._stage_slices + [(self.off_head, self.off_head + (self.C * self.E + 63) // 64 * 64)]

@@ -410,10 +410,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e = i << 2;
-        float4 pv = reinterpret_cast<float4*>(p)[i];
-        const float4 gv = reinterpret_cast<const float4*>(g)[i];
-        float4 mv = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
+        // every byte is touched once per step: nontemporal accesses keep the stream out of the way of the GEMMs' L2 lines
+        typedef float nt4 __attribute__((ext_vector_type(4)));
+        const nt4 pn = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p) + i);
+        const nt4 gn = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(g) + i);
+        const nt4 mn = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(m) + i);
+        const nt4 vn = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(v) + i);
+        float4 pv = make_float4(pn[0], pn[1], pn[2], pn[3]);
+        const float4 gv = make_float4(gn[0], gn[1], gn[2], gn[3]);
+        float4 mv = make_float4(mn[0], mn[1], mn[2], mn[3]);
+        float4 vv = make_float4(vn[0], vn[1], vn[2], vn[3]);
         float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
         float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
@@ -429,9 +435,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             const float denom = sqrtf(va[k]) / sbc2 + eps;
             pa[k] -= (lr / bc1) * (ma[k] / denom);
         }
-        reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
-        reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
-        reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
+        __builtin_nontemporal_store((nt4){pa[0], pa[1], pa[2], pa[3]}, reinterpret_cast<nt4*>(p) + i);
+        __builtin_nontemporal_store((nt4){ma[0], ma[1], ma[2], ma[3]}, reinterpret_cast<nt4*>(m) + i);
+        __builtin_nontemporal_store((nt4){va[0], va[1], va[2], va[3]}, reinterpret_cast<nt4*>(v) + i);
         if (shadow) reinterpret_cast<ushort4*>(shadow)[i] = make_ushort4(f2bf(pa[0]), f2bf(pa[1]), f2bf(pa[2]), f2bf(pa[3]));
     }
 }

@@ -119,7 +119,11 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
 #pragma unroll
                 for (int sp = 1; sp < NSPLIT; ++sp)
                     pl[sp - 1][i] = reinterpret_cast<const float4*>(dy + sp * split_stride + (int64_t)row * dy_stride)[c];
-                xh[i] = xr[c];
+                {   // the saved activation is read here for the last time this step: keep it out of L2's way
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    const nt4 t = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(xr) + c);
+                    xh[i] = make_float4(t[0], t[1], t[2], t[3]);
+                }
                 if (dx_add) add[i] = reinterpret_cast<const float4*>(dx_add + (int64_t)row * dxa_stride)[c];
             }
         }

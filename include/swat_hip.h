@@ -270,6 +270,26 @@ int64_t swat_transformer_workspace_bytes(const int32_t* dims);
 int swat_transformer_forward(const int32_t* dims, const int64_t* offs, const float* params,
                              const void* shadow_bf16, float* x, void* workspace, swat_stream_t stream);
 
+/* §8(f).2  Image side of the input pipeline (ref: utils/extras.py:66-85 `transform` = RandomResizedCrop(224, bicubic)
+ *     + RandomHorizontalFlip + ToTensor + Normalize for training, Resize(224, bicubic) + CenterCrop + ToTensor +
+ *     Normalize for validation; applied per sample at utils/datasets/dataset_utils.py:165-180).  Decoded RGB images go
+ *     in as bytes, the normalised fp32 batch [n_images, 3, n_px, n_px] comes out; the resampling is Pillow's 8-bit
+ *     antialiased bicubic (two passes, 22-bit fixed-point weights), bit for bit.  The random draws stay on the host.
+ *     pixels_u8 : all images back to back, HWC uint8, image i at byte offsets[i]; the allocation must extend 4 bytes
+ *                 past the last image (rows are fetched as aligned 32-bit words).
+ *     desc      : DEVICE int32 [n_images][12] = { width, height (stored image), x0, y0, in_w, in_h (region that is
+ *                 resampled), out_w, out_h (size it is resampled to), off_x, off_y (corner of the n_px window kept from
+ *                 that result), flip (mirror the window left-right), 0 }.
+ *                 training: region = the random crop, out = n_px x n_px, off = 0; validation: region = whole image,
+ *                 out = (nw, nh) with the short side n_px, off = the centre-crop corner.
+ *     row_start : DEVICE int64 [n_images + 1], prefix sums of in_h.       lut: DEVICE float [3][256], the value of
+ *                 (v / 255 - mean_c) / std_c for every byte v (computed once by the host in float32).
+ *     max_in_w / max_in_h / max_ksize: maxima over the batch; ksize = 2 * ceil(2 * max(in / out, 1)) + 1 per axis. */
+int64_t swat_preprocess_workspace_bytes(int n_images, int n_px, int max_ksize, int64_t total_rows);
+int swat_preprocess_batch(const void* pixels_u8, const int64_t* offsets, const int32_t* desc, const int64_t* row_start,
+                          const float* lut, float* out, int n_images, int n_px, int max_in_w, int max_in_h,
+                          int max_ksize, void* workspace, int64_t workspace_bytes, swat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,3 +60,86 @@ def build_transform(n_px, mode='train'):
         return _to_tensor_normalize(img.crop((left, top, left + n_px, top + n_px)))
 
     return train if mode == 'train' else val
+
+
+def _axis_ksize(in_size, out_size):
+    return int(math.ceil(2.0 * max(float(in_size) / out_size, 1.0))) * 2 + 1
+
+
+class DeviceBatchTransform:
+    """The same two transforms for a whole batch of decoded images on the GPU (include/swat_hip.h
+    `swat_preprocess_batch`): crop + antialiased bicubic resize + flip + ToTensor + Normalize in three launches, bit for
+    bit what `build_transform` computes per image with Pillow.  The host keeps what is inherently serial: JPEG decoding
+    and the random draws (same generator, same order per image: crop box, then the flip coin).
+
+        tf = DeviceBatchTransform(224, 'train'); batch = tf(list_of_PIL_images)   # float32 [B, 3, 224, 224] on the GPU
+    ref: utils/extras.py:66-85, utils/datasets/dataset_utils.py:165-180
+    """
+
+    def __init__(self, n_px, mode='train', device='cuda'):
+        from . import _lib
+        self.n_px, self.mode, self.device = n_px, mode, torch.device(device)
+        self._lib = _lib
+        v = torch.arange(256, dtype=torch.float32) / 255.0
+        lut = (v.view(1, 256) - torch.tensor(MEAN).view(3, 1)) / torch.tensor(STD).view(3, 1)
+        self._lut = lut.contiguous().to(self.device)
+        self._ws = None
+
+    def geometry(self, w, h):
+        """-> (x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip) for one image; draws from torch's CPU generator"""
+        n = self.n_px
+        if self.mode == 'train':
+            i, j, ch, cw = _rrc_params(w, h, (0.9, 1.0), (0.75, 1.3333))
+            flip = int(torch.rand(1).item() < 0.5)
+            return j, i, cw, ch, n, n, 0, 0, flip
+        s = n / min(w, h)
+        nw, nh = (n, max(n, int(round(h * s)))) if w <= h else (max(n, int(round(w * s))), n)
+        return 0, 0, w, h, nw, nh, int(round((nw - n) / 2.0)), int(round((nh - n) / 2.0)), 0
+
+    def __call__(self, images, geometry=None, stream=None):
+        """images: PIL images or uint8 [H, W, 3] arrays.  geometry: optional per-image tuples as `geometry()` returns."""
+        arrs = [np.ascontiguousarray(np.asarray(im.convert('RGB') if hasattr(im, 'convert') else im, dtype=np.uint8)) for im in images]
+        B, n = len(arrs), self.n_px
+        if B == 0:
+            return torch.empty(0, 3, n, n, device=self.device)
+        desc = np.zeros((B, 12), np.int32)
+        offsets = np.zeros(B, np.int64)
+        row_start = np.zeros(B + 1, np.int64)
+        total, ks = 0, 5
+        for b, a in enumerate(arrs):
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError(f"image {b}: expected [H, W, 3] uint8, got {a.shape}")
+            h, w = a.shape[:2]
+            g = geometry[b] if geometry is not None else self.geometry(w, h)
+            x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip = g
+            if not (0 <= x0 and 0 <= y0 and 0 < in_w and 0 < in_h and x0 + in_w <= w and y0 + in_h <= h
+                    and 0 <= off_x and 0 <= off_y and off_x + n <= out_w and off_y + n <= out_h):
+                raise ValueError(f"image {b}: geometry {g} does not fit a {w} x {h} image / a {n}-pixel window")
+            desc[b] = (w, h, x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip, 0)
+            offsets[b] = total
+            total += a.size
+            row_start[b + 1] = row_start[b] + in_h
+            ks = max(ks, _axis_ksize(in_w, out_w), _axis_ksize(in_h, out_h))
+        host = torch.empty(total + 4, dtype=torch.uint8).pin_memory()
+        hv = host.numpy()
+        for b, a in enumerate(arrs):
+            hv[offsets[b]:offsets[b] + a.size] = a.reshape(-1)
+        hv[total:] = 0
+        meta = torch.from_numpy(np.concatenate([offsets, row_start, desc.reshape(-1).view(np.int64)])).pin_memory()
+        dev = self.device
+        lib, ptr = self._lib.lib(), self._lib.ptr
+        with torch.cuda.device(dev):
+            s = stream if stream is not None else torch.cuda.current_stream(dev)
+            with torch.cuda.stream(s):
+                pix = host.to(dev, non_blocking=True)
+                m = meta.to(dev, non_blocking=True)
+                need = lib.swat_preprocess_workspace_bytes(B, n, ks, int(row_start[-1]))
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                out = torch.empty(B, 3, n, n, dtype=torch.float32, device=dev)
+                self._lib.check(lib.swat_preprocess_batch(ptr(pix), m.data_ptr(), m.data_ptr() + 8 * (2 * B + 1), m.data_ptr() + 8 * B,
+                                                          ptr(self._lut), ptr(out), B, n, int(desc[:, 4].max()), int(desc[:, 5].max()),
+                                                          ks, ptr(self._ws), self._ws.numel(), s.cuda_stream), "swat_preprocess_batch")
+                pix.record_stream(s)
+                m.record_stream(s)
+        return out

@@ -1,0 +1,75 @@
+"""GPU: swat_preprocess_batch (through the C ABI, via swat_amd.transforms.DeviceBatchTransform) against Pillow — the
+library behind the reference's torchvision transforms (utils/extras.py:66-85) — and against oracle/image_oracle.py.
+Byte / index work: the bar is bit-exact."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import image_oracle as io
+from swat_amd import transforms as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _image(rng, h, w, smooth=True):
+    if not smooth:
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    y, x = np.mgrid[0:h, 0:w]
+    a = np.stack([127 + 120 * np.sin(x / 17.0 + c) * np.cos(y / 23.0 - c) for c in range(3)], -1)
+    return np.clip(a + rng.normal(0, 6, a.shape), 0, 255).astype(np.uint8)
+
+
+SIZES = [(375, 500), (500, 333), (224, 224), (180, 260), (640, 480), (97, 131), (1200, 1600), (333, 500), (224, 301),
+         (301, 224), (50, 40), (768, 1024)]
+
+
+@pytest.mark.parametrize("mode", ["train", "val"])
+def test_batch_matches_host_transform(mode):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    rng = np.random.default_rng(11)
+    imgs = [_image(rng, h, w, smooth=(i % 2 == 0)) for i, (h, w) in enumerate(SIZES)]
+    tf = T.build_transform(224, mode)
+    torch.manual_seed(5)
+    ref = torch.stack([tf(Image.fromarray(a)) for a in imgs])
+    torch.manual_seed(5)
+    got = T.DeviceBatchTransform(224, mode)([Image.fromarray(a) for a in imgs])
+    assert got.shape == (len(imgs), 3, 224, 224) and got.dtype == torch.float32
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_edge_geometries_match_oracle():
+    """one-pixel regions, up-scaling, identity axes, odd byte offsets, forced flips, a 4000-pixel-wide panorama"""
+    rng = np.random.default_rng(12)
+    cases = [((1, 1), (0, 0, 1, 1)), ((3, 5), (1, 2, 1, 3)), ((224, 224), (0, 0, 224, 224)), ((224, 500), (0, 100, 224, 333)),
+             ((500, 224), (13, 0, 401, 224)), ((31, 17), (0, 0, 31, 17)), ((600, 4000), (7, 3, 590, 3990)), ((2000, 90), (100, 1, 1800, 88))]
+    imgs, geo = [], []
+    for i, ((h, w), (y0, x0, ch, cw)) in enumerate(cases):
+        imgs.append(_image(rng, h, w, smooth=False))
+        geo.append((x0, y0, cw, ch, 224, 224, 0, 0, i % 2))
+    got = T.DeviceBatchTransform(224, "train")(imgs, geometry=geo).cpu().numpy()
+    for i, (a, g) in enumerate(zip(imgs, geo)):
+        x0, y0, cw, ch = g[:4]
+        want = io.apply(a, 224, box=(y0, x0, ch, cw), flip=bool(g[8]), mode="train")
+        assert np.array_equal(got[i], want), f"case {i}: {cases[i]}"
+        pil = np.asarray(Image.fromarray(a).crop((x0, y0, x0 + cw, y0 + ch)).resize((224, 224), Image.BICUBIC))
+        if g[8]:
+            pil = pil[:, ::-1]
+        assert np.array_equal(got[i], np.stack([io.normalize_lut()[c][pil[:, :, c]] for c in range(3)]))
+
+
+def test_other_resolution_and_single_image():
+    rng = np.random.default_rng(13)
+    a = _image(rng, 300, 420)
+    tf = T.build_transform(336, "val")
+    got = T.DeviceBatchTransform(336, "val")([a])
+    assert torch.equal(got.cpu()[0], tf(Image.fromarray(a)))
+    assert T.DeviceBatchTransform(224, "val")([]).shape == (0, 3, 224, 224)
+
+
+def test_bad_geometry_is_refused():
+    a = np.zeros((10, 10, 3), np.uint8)
+    with pytest.raises(ValueError):
+        T.DeviceBatchTransform(224, "train")([a], geometry=[(5, 5, 10, 10, 224, 224, 0, 0, 0)])
+    with pytest.raises(ValueError):
+        T.DeviceBatchTransform(224, "train")([np.zeros((10, 10), np.uint8)])

@@ -84,6 +84,7 @@ class DeviceBatchTransform:
         lut = (v.view(1, 256) - torch.tensor(MEAN).view(3, 1)) / torch.tensor(STD).view(3, 1)
         self._lut = lut.contiguous().to(self.device)
         self._ws = None
+        self._pin, self._pin_free, self._turn = [None, None], [None, None], 0  # two pinned staging buffers, reused
 
     def geometry(self, w, h):
         """-> (x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip) for one image; draws from torch's CPU generator"""
@@ -120,26 +121,33 @@ class DeviceBatchTransform:
             total += a.size
             row_start[b + 1] = row_start[b] + in_h
             ks = max(ks, _axis_ksize(in_w, out_w), _axis_ksize(in_h, out_h))
-        host = torch.empty(total + 4, dtype=torch.uint8).pin_memory()
-        hv = host.numpy()
+        meta_bytes = 8 * (2 * B + 1) + 48 * B
+        slot = self._turn = self._turn ^ 1
+        if self._pin[slot] is None or self._pin[slot].numel() < total + 8 + meta_bytes:
+            self._pin[slot] = torch.empty(int((total + 8 + meta_bytes) * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        elif self._pin_free[slot] is not None:
+            self._pin_free[slot].synchronize()  # the copy that last read this buffer has finished
+        hv = self._pin[slot].numpy()
         for b, a in enumerate(arrs):
             hv[offsets[b]:offsets[b] + a.size] = a.reshape(-1)
-        hv[total:] = 0
-        meta = torch.from_numpy(np.concatenate([offsets, row_start, desc.reshape(-1).view(np.int64)])).pin_memory()
+        m0 = (total + 4 + 7) // 8 * 8  # pixels, 4 bytes of padding, then offsets / row_start / desc (8-byte aligned)
+        hv[total:m0] = 0
+        hv[m0:m0 + meta_bytes] = np.concatenate([offsets, row_start, desc.reshape(-1).view(np.int64)]).view(np.uint8)
         dev = self.device
         lib, ptr = self._lib.lib(), self._lib.ptr
         with torch.cuda.device(dev):
             s = stream if stream is not None else torch.cuda.current_stream(dev)
             with torch.cuda.stream(s):
-                pix = host.to(dev, non_blocking=True)
-                m = meta.to(dev, non_blocking=True)
+                pix = self._pin[slot][:m0 + meta_bytes].to(dev, non_blocking=True)
+                self._pin_free[slot] = torch.cuda.Event()
+                self._pin_free[slot].record(s)
                 need = lib.swat_preprocess_workspace_bytes(B, n, ks, int(row_start[-1]))
                 if self._ws is None or self._ws.numel() < need:
-                    self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                    self._ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
                 out = torch.empty(B, 3, n, n, dtype=torch.float32, device=dev)
-                self._lib.check(lib.swat_preprocess_batch(ptr(pix), m.data_ptr(), m.data_ptr() + 8 * (2 * B + 1), m.data_ptr() + 8 * B,
-                                                          ptr(self._lut), ptr(out), B, n, int(desc[:, 4].max()), int(desc[:, 5].max()),
-                                                          ks, ptr(self._ws), self._ws.numel(), s.cuda_stream), "swat_preprocess_batch")
+                m = pix.data_ptr() + m0
+                self._lib.check(lib.swat_preprocess_batch(ptr(pix), m, m + 8 * (2 * B + 1), m + 8 * B, ptr(self._lut), ptr(out), B, n,
+                                                          int(desc[:, 4].max()), int(desc[:, 5].max()), ks, ptr(self._ws),
+                                                          self._ws.numel(), s.cuda_stream), "swat_preprocess_batch")
                 pix.record_stream(s)
-                m.record_stream(s)
         return out

@@ -20,15 +20,18 @@ def _image(rng, h, w, smooth=True):
     return np.clip(a + rng.normal(0, 6, a.shape), 0, 255).astype(np.uint8)
 
 
-SIZES = [(375, 500), (500, 333), (224, 224), (180, 260), (640, 480), (97, 131), (1200, 1600), (333, 500), (224, 301),
-         (301, 224), (50, 40), (768, 1024)]
+# one group per kernel instantiation: the tap count of a batch (its largest reduction) selects the unrolled form
+GROUPS = {"taps5": [(100, 80), (224, 224), (50, 40), (180, 260)], "taps9": [(300, 400), (97, 131), (224, 301), (301, 224)],
+          "taps13": [(375, 500), (500, 333), (333, 500), (640, 480)], "taps17": [(800, 600), (375, 500)],
+          "taps25": [(768, 1024), (1100, 900), (224, 224)], "generic": [(1200, 1600), (375, 500), (2000, 1500)]}
 
 
+@pytest.mark.parametrize("group", list(GROUPS))
 @pytest.mark.parametrize("mode", ["train", "val"])
-def test_batch_matches_host_transform(mode):
+def test_batch_matches_host_transform(mode, group):
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
     rng = np.random.default_rng(11)
-    imgs = [_image(rng, h, w, smooth=(i % 2 == 0)) for i, (h, w) in enumerate(SIZES)]
+    imgs = [_image(rng, h, w, smooth=(i % 2 == 0)) for i, (h, w) in enumerate(GROUPS[group])]
     tf = T.build_transform(224, mode)
     torch.manual_seed(5)
     ref = torch.stack([tf(Image.fromarray(a)) for a in imgs])
@@ -38,11 +41,27 @@ def test_batch_matches_host_transform(mode):
     assert torch.equal(got.cpu(), ref)
 
 
+def test_full_batch_of_mixed_sizes():
+    rng = np.random.default_rng(14)
+    sizes = [(int(rng.integers(200, 700)), int(rng.integers(200, 700))) for _ in range(32)]
+    imgs = [_image(rng, h, w, smooth=False) for h, w in sizes]
+    tf = T.build_transform(224, "train")
+    torch.manual_seed(6)
+    ref = torch.stack([tf(Image.fromarray(a)) for a in imgs])
+    torch.manual_seed(6)
+    assert torch.equal(T.DeviceBatchTransform(224, "train")(imgs).cpu(), ref)
+
+
 def test_edge_geometries_match_oracle():
     """one-pixel regions, up-scaling, identity axes, odd byte offsets, forced flips, a 4000-pixel-wide panorama"""
     rng = np.random.default_rng(12)
-    cases = [((1, 1), (0, 0, 1, 1)), ((3, 5), (1, 2, 1, 3)), ((224, 224), (0, 0, 224, 224)), ((224, 500), (0, 100, 224, 333)),
-             ((500, 224), (13, 0, 401, 224)), ((31, 17), (0, 0, 31, 17)), ((600, 4000), (7, 3, 590, 3990)), ((2000, 90), (100, 1, 1800, 88))]
+    small = [((1, 1), (0, 0, 1, 1)), ((3, 5), (1, 2, 1, 3)), ((224, 224), (0, 0, 224, 224)), ((224, 500), (0, 100, 224, 333)),
+             ((500, 224), (13, 0, 401, 224)), ((31, 17), (0, 0, 31, 17)), ((227, 229), (1, 1, 225, 227))]
+    _check_cases(rng, small)  # unrolled kernels
+    _check_cases(rng, small + [((600, 4000), (7, 3, 590, 3990)), ((2000, 90), (100, 1, 1800, 88))])  # run-time tap loops
+
+
+def _check_cases(rng, cases):
     imgs, geo = [], []
     for i, ((h, w), (y0, x0, ch, cw)) in enumerate(cases):
         imgs.append(_image(rng, h, w, smooth=False))
@@ -65,6 +84,12 @@ def test_other_resolution_and_single_image():
     got = T.DeviceBatchTransform(336, "val")([a])
     assert torch.equal(got.cpu()[0], tf(Image.fromarray(a)))
     assert T.DeviceBatchTransform(224, "val")([]).shape == (0, 3, 224, 224)
+    for n in (30, 32):  # 30: not a multiple of 4 -> the run-time tap loops
+        assert torch.equal(T.DeviceBatchTransform(n, "val")([a]).cpu()[0], T.build_transform(n, "val")(Image.fromarray(a)))
+        torch.manual_seed(1)
+        ref = T.build_transform(n, "train")(Image.fromarray(a[:40, :50]))
+        torch.manual_seed(1)
+        assert torch.equal(T.DeviceBatchTransform(n, "train")([a[:40, :50]]).cpu()[0], ref)
 
 
 def test_bad_geometry_is_refused():

@@ -10,7 +10,7 @@ import torch
 from torch.utils.data import DataLoader, Dataset
 
 from .features import extract_test_feats
-from .transforms import build_transform
+from .transforms import DecodeOnly, DeviceBatchTransform, build_transform
 
 
 def _pil_loader(path):
@@ -80,6 +80,32 @@ class SyntheticImages(Dataset):
         return img, y, torch.zeros(1, 1, dtype=torch.long), 1
 
 
+def _raw_collate(samples):
+    """images stay a list of uint8 [H, W, 3] arrays of different sizes; everything else collates as usual"""
+    from torch.utils.data import default_collate
+    imgs = [s[0][0].numpy() for s in samples]
+    geo = [tuple(int(v) for v in s[0][1]) for s in samples]
+    return (imgs, geo), *default_collate([tuple(s[1:]) for s in samples])
+
+
+class DeviceTransformLoader:
+    """A DataLoader whose workers only decode (transform = DecodeOnly) and whose batches get crop / resize / flip /
+    normalise on the GPU (`swat_preprocess_batch`) as they leave the iterator: yields the tuples the reference's loaders
+    yield (utils/datasets/dataset_utils.py:165-180), with the image batch already on the device."""
+
+    def __init__(self, dataset, n_px, mode, device, **loader_kw):
+        self.loader = DataLoader(dataset, collate_fn=_raw_collate, **loader_kw)
+        self.dataset, self.batch_size = dataset, self.loader.batch_size
+        self.tf = DeviceBatchTransform(n_px, mode, device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for (imgs, geo), *rest in self.loader:
+            yield (self.tf(imgs, geometry=geo), *rest)
+
+
 def load_dataset(dataset_root, split, preprocess, tokenized_text_prompts):
     return MyDataset(dataset_root, split, preprocess, tokenized_text_prompts)
 
@@ -93,6 +119,14 @@ def get_dataloader(args, train_split, val_split, test_split, tokenized_text_prom
         tr = load_dataset(args.dataset_root, train_split, build_transform(224, 'train'), tokenized_text_prompts)
         va = load_dataset(args.dataset_root, val_split, preprocess, tokenized_text_prompts)
         te = load_dataset(args.dataset_root, test_split, preprocess, tokenized_text_prompts)
+    if getattr(args, 'gpu_transform', False) and not getattr(args, 'synthetic', 0):
+        dev = getattr(args, 'device', 'cuda')
+        for ds, mode in ((tr, 'train'), (va, 'val'), (te, 'val')):
+            ds.transform = DecodeOnly(224, mode)
+        train_loader = DeviceTransformLoader(tr, 224, 'train', dev, batch_size=args.bsz, shuffle=True, drop_last=True, num_workers=args.num_workers)
+        val_loader = DeviceTransformLoader(va, 224, 'val', dev, batch_size=128, drop_last=False, shuffle=False, num_workers=args.num_workers)
+        test_loader = DeviceTransformLoader(te, 224, 'val', dev, batch_size=256, drop_last=False, shuffle=False, num_workers=args.num_workers)
+        return train_loader, val_loader, test_loader
     train_loader = DataLoader(tr, batch_size=args.bsz, pin_memory=True, shuffle=True, drop_last=True, num_workers=args.num_workers)
     val_loader = DataLoader(va, batch_size=128, drop_last=False, pin_memory=True, shuffle=False, num_workers=args.num_workers)
     test_loader = DataLoader(te, batch_size=256, drop_last=False, pin_memory=True, shuffle=False, num_workers=args.num_workers)

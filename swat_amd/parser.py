@@ -70,6 +70,8 @@ def build_parser():
     p.add_argument('--epochs', type=int, default=0)
     p.add_argument('--stop_epochs', type=int, default=200)
     p.add_argument('--num_workers', type=int, default=8)
+    p.add_argument('--gpu_transform', action='store_true',
+                   help='loader workers only decode; crop / bicubic resize / flip / normalise run on the GPU per batch (bit-exact)')
     p.add_argument('--start_validation', type=int, default=0)
     p.add_argument('--lr_classifier', type=float, default=1e-4)
     p.add_argument('--lr_backbone', type=float, default=1e-6)

@@ -66,6 +66,31 @@ def _axis_ksize(in_size, out_size):
     return int(math.ceil(2.0 * max(float(in_size) / out_size, 1.0))) * 2 + 1
 
 
+def sample_geometry(n, mode, w, h):
+    """What the host transform would do to a w x h image, as the nine integers `swat_preprocess_batch` takes; the
+    training form draws the crop box and then the flip coin from torch's CPU generator, exactly as `build_transform`."""
+    if mode == 'train':
+        i, j, ch, cw = _rrc_params(w, h, (0.9, 1.0), (0.75, 1.3333))
+        flip = int(torch.rand(1).item() < 0.5)
+        return j, i, cw, ch, n, n, 0, 0, flip
+    s = n / min(w, h)
+    nw, nh = (n, max(n, int(round(h * s)))) if w <= h else (max(n, int(round(w * s))), n)
+    return 0, 0, w, h, nw, nh, int(round((nw - n) / 2.0)), int(round((nh - n) / 2.0)), 0
+
+
+class DecodeOnly:
+    """Worker-side half of the GPU transform: hands back the decoded bytes and this sample's geometry (the random draws
+    happen here, in the worker, in the order the host transform makes them); `DeviceBatchTransform` does the rest for
+    the collated batch in the main process."""
+
+    def __init__(self, n_px, mode='train'):
+        self.n_px, self.mode = n_px, mode
+
+    def __call__(self, img):
+        a = np.array(img.convert('RGB'), dtype=np.uint8)
+        return torch.from_numpy(a), torch.tensor(sample_geometry(self.n_px, self.mode, a.shape[1], a.shape[0]), dtype=torch.int32)
+
+
 class DeviceBatchTransform:
     """The same two transforms for a whole batch of decoded images on the GPU (include/swat_hip.h
     `swat_preprocess_batch`): crop + antialiased bicubic resize + flip + ToTensor + Normalize in three launches, bit for
@@ -88,14 +113,7 @@ class DeviceBatchTransform:
 
     def geometry(self, w, h):
         """-> (x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip) for one image; draws from torch's CPU generator"""
-        n = self.n_px
-        if self.mode == 'train':
-            i, j, ch, cw = _rrc_params(w, h, (0.9, 1.0), (0.75, 1.3333))
-            flip = int(torch.rand(1).item() < 0.5)
-            return j, i, cw, ch, n, n, 0, 0, flip
-        s = n / min(w, h)
-        nw, nh = (n, max(n, int(round(h * s)))) if w <= h else (max(n, int(round(w * s))), n)
-        return 0, 0, w, h, nw, nh, int(round((nw - n) / 2.0)), int(round((nh - n) / 2.0)), 0
+        return sample_geometry(self.n_px, self.mode, w, h)
 
     def __call__(self, images, geometry=None, stream=None):
         """images: PIL images or uint8 [H, W, 3] arrays.  geometry: optional per-image tuples as `geometry()` returns."""

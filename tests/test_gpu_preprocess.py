@@ -98,3 +98,37 @@ def test_bad_geometry_is_refused():
         T.DeviceBatchTransform(224, "train")([a], geometry=[(5, 5, 10, 10, 224, 224, 0, 0, 0)])
     with pytest.raises(ValueError):
         T.DeviceBatchTransform(224, "train")([np.zeros((10, 10), np.uint8)])
+
+
+def test_loader_with_gpu_transform_matches_host_loader(tmp_path):
+    """real files, worker processes that only decode, the batch transformed by the HIP kernels: the same batches as
+    the reference-shaped loader (utils/dataloader.py:107-135) whose workers run Pillow"""
+    import os
+    from types import SimpleNamespace
+    from swat_amd import dataloader as dl
+    rng = np.random.default_rng(21)
+    os.makedirs(tmp_path / "img")
+    lines = []
+    for i in range(12):
+        h, w = int(rng.integers(120, 500)), int(rng.integers(120, 500))
+        Image.fromarray(_image(rng, h, w)).save(tmp_path / "img" / f"{i}.png")
+        lines.append(f"img/{i}.png {i % 3} {i % 2}\n")
+    (tmp_path / "split.txt").write_text("".join(lines))
+    split = [["split.txt"], [str(tmp_path)]]
+    args = SimpleNamespace(dataset_root=str(tmp_path), bsz=4, num_workers=0, device="cuda:0", gpu_transform=False)
+    val_tf = T.build_transform(224, "val")
+    torch.manual_seed(3)
+    want = [list(l) for l in dl.get_dataloader(args, split, split, split, None, val_tf)]
+    args.gpu_transform = True
+    torch.manual_seed(3)
+    loaders = dl.get_dataloader(args, split, split, split, None, val_tf)
+    assert all(isinstance(l, dl.DeviceTransformLoader) for l in loaders)
+    got = [list(l) for l in loaders]
+    for lw, lg in zip(want, got):
+        assert len(lw) == len(lg) > 0
+        for bw, bg in zip(lw, lg):
+            assert bg[0].is_cuda and torch.equal(bg[0].cpu(), bw[0])
+            assert all(torch.equal(a, b) for a, b in zip(bg[1:], bw[1:]))
+    # worker processes: same batches for the un-shuffled validation loader
+    args.num_workers = 2
+    assert all(torch.equal(a[0].cpu(), b[0]) for a, b in zip(dl.get_dataloader(args, split, split, split, None, val_tf)[1], want[1]))

@@ -58,3 +58,50 @@ def test_whole_transform_matches_host_path(mode):
             assert (out_w, out_h, off_x, off_y) == io.val_geometry(w, h, 224)
             got = io.apply(a, 224, mode="val")
         assert got.dtype == np.float32 and np.array_equal(got, ref)
+
+
+def _write_split(tmp_path, rng, n=10):
+    import os
+    os.makedirs(tmp_path / "img", exist_ok=True)
+    lines = []
+    for i in range(n):
+        h, w = int(rng.integers(120, 400)), int(rng.integers(120, 400))
+        Image.fromarray(_image(rng, h, w, smooth=True)).save(tmp_path / "img" / f"{i}.png")
+        lines.append(f"img/{i}.png {i % 3} {i % 2}\n")
+    (tmp_path / "split.txt").write_text("".join(lines))
+    return [["split.txt"], [str(tmp_path)]]
+
+
+class _HostStandIn:
+    """what DeviceBatchTransform computes, through the oracle (no GPU in this test)"""
+
+    def __init__(self, n_px, mode, device):
+        self.n_px, self.mode = n_px, mode
+
+    def __call__(self, imgs, geometry):
+        out = []
+        for a, g in zip(imgs, geometry):
+            x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip = g
+            if self.mode == "train":
+                out.append(io.apply(a, self.n_px, box=(y0, x0, in_h, in_w), flip=bool(flip), mode="train"))
+            else:
+                out.append(io.apply(a, self.n_px, mode="val"))
+        return torch.from_numpy(np.stack(out))
+
+
+@pytest.mark.parametrize("mode", ["train", "val"])
+def test_decode_only_loader_yields_the_host_loaders_batches(tmp_path, monkeypatch, mode):
+    from torch.utils.data import DataLoader
+    from swat_amd import dataloader as dl
+    monkeypatch.setattr(dl, "DeviceBatchTransform", _HostStandIn)
+    split = _write_split(tmp_path, np.random.default_rng(5))
+    toks = {str(c): {"all": torch.arange(12).view(4, 1, 3) + 100 * c} for c in range(3)}
+    host = dl.MyDataset(str(tmp_path), split, T.build_transform(224, mode), toks)
+    raw = dl.MyDataset(str(tmp_path), split, T.DecodeOnly(224, mode), toks)
+    torch.manual_seed(9)
+    want = list(DataLoader(host, batch_size=4, shuffle=(mode == "train"), num_workers=0))
+    torch.manual_seed(9)
+    got = list(dl.DeviceTransformLoader(raw, 224, mode, "cpu", batch_size=4, shuffle=(mode == "train"), num_workers=0))
+    assert len(got) == len(want) == 3
+    for g, w in zip(got, want):
+        assert len(g) == 4 and all(torch.equal(a, b) for a, b in zip(g, w))

@@ -146,7 +146,7 @@ constexpr int PP_ROWS = 4;  // source rows per wave (at most)
 
 // grid (ceil(max_in_h / (4 * R)), image); wave w of block x owns rows (4x + w) * R .. + R - 1.  row_words: LDS words per
 // staged row = the row's aligned words rounded up to a multiple of 64 (one LDS-DMA instruction moves 64 words) plus slack
-// for the zero-weight taps that reach past the row's end.
+// for the zero-weight taps that reach past the row's end (24 words: 25 taps x 3 bytes, read as whole words).
 template <int KS>
 __global__ __launch_bounds__(256) void resample_rows_fixed_kernel(const unsigned char* __restrict__ pixels, const int64_t* __restrict__ offsets,
                                                                   const int* __restrict__ desc, const int64_t* __restrict__ row_start,
@@ -191,18 +191,27 @@ __global__ __launch_bounds__(256) void resample_rows_fixed_kernel(const unsigned
 #pragma unroll
         for (int r = 0; r < PP_ROWS; ++r) {
             if (r < R && row0 + r < in_h) {
-                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(mine + r * row_words) + mis[r];
+                const unsigned int* roww = mine + r * row_words;
                 unsigned char* dst = tmp + (row_start[b] + row0 + r) * (int64_t)(3 * n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int t = t0 + lane + 64 * j;
-                    const unsigned char* p = rowb + xm3[j];
+                    // the 3 * KS bytes under this column's taps, as whole LDS words shifted into place (a third of the
+                    // LDS instructions of byte reads, and bank conflicts per word instead of per byte)
+                    constexpr int NU = (3 * KS + 3) / 4;
+                    const int off = xm3[j] + mis[r];
+                    const unsigned int* wp = roww + (off >> 2);
+                    unsigned int w[NU + 1], u[NU];
+#pragma unroll
+                    for (int i = 0; i <= NU; ++i) w[i] = wp[i];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) u[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], (unsigned)(off & 3));
                     int s0 = 1 << (PP_BITS - 1), s1 = s0, s2 = s0;
 #pragma unroll
                     for (int x = 0; x < KS; ++x) {
-                        s0 += p[3 * x] * kreg[j][x];
-                        s1 += p[3 * x + 1] * kreg[j][x];
-                        s2 += p[3 * x + 2] * kreg[j][x];
+                        s0 += (int)((u[(3 * x) >> 2] >> (8 * ((3 * x) & 3))) & 255u) * kreg[j][x];
+                        s1 += (int)((u[(3 * x + 1) >> 2] >> (8 * ((3 * x + 1) & 3))) & 255u) * kreg[j][x];
+                        s2 += (int)((u[(3 * x + 2) >> 2] >> (8 * ((3 * x + 2) & 3))) & 255u) * kreg[j][x];
                     }
                     if (t < n) {
                         dst[3 * t] = (unsigned char)clip8(s0);
@@ -286,7 +295,7 @@ SWAT_API int swat_preprocess_batch(const void* pixels_u8, const int64_t* offsets
     const bool fixed = max_ksize <= 25 && n_px % 4 == 0;
     if (fixed) {
         // words of the widest staged row, in whole LDS-DMA instructions, + the reach of 25 zero-weight taps
-        const int row_words = ((max_in_w * 3 + 3 + 3) / 4 + 63) / 64 * 64 + 20;
+        const int row_words = ((max_in_w * 3 + 3 + 3) / 4 + 63) / 64 * 64 + 24;
         SWAT_REQUIRE(16 * row_words <= 64 * 1024, "swat_preprocess_batch: regions wider than 5300 pixels are not supported (%d)", max_in_w);
         const int R = 64 * row_words <= 48 * 1024 ? 4 : (32 * row_words <= 48 * 1024 ? 2 : 1);
         const dim3 grid_r((max_in_h + 4 * R - 1) / (4 * R), n_images), grid_c(n_px, n_images);

@@ -105,3 +105,15 @@ def test_decode_only_loader_yields_the_host_loaders_batches(tmp_path, monkeypatc
     assert len(got) == len(want) == 3
     for g, w in zip(got, want):
         assert len(g) == 4 and all(torch.equal(a, b) for a, b in zip(g, w))
+
+
+def test_weight_range_over_a_size_sweep():
+    """normalised fixed-point weights stay within 23 bits + sign for every region / output size tried (the largest
+    occur where an edge cuts the kernel of an up-scaled axis: about 1.125 x 2^22)"""
+    worst = 0
+    for out in (224, 336, 32, 30):
+        for ins in list(range(1, 48)) + [63, 100, 223, 224, 225, 300, 448, 500, 1000, 2000, 4000]:
+            b, k = io.axis_table(ins, out)
+            assert (b[:, 1] <= io.ksize_of(ins, out)).all() and (b[:, 1] >= 1).all()
+            worst = max(worst, int(np.abs(k).max()))
+    assert worst < (1 << 23)

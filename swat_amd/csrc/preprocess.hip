@@ -11,8 +11,9 @@
 //                            words by LDS-DMA (all rows in flight at once), lanes = output columns whose taps stay in
 //                            registers across the rows; result bytes [rows of the region][n][3];
 //   resample_cols_*_kernel — vertical pass + mirror + (v / 255 - mean) / std through a 3 x 256 table: one output row
-//                            per block, every tap's word of the intermediate loaded before the first is used, the
-//                            row transposed through LDS and written as coalesced fp32 planes.
+//                            per wave, every tap's word of the intermediate loaded before the first is used, the
+//                            row transposed through LDS and written as coalesced fp32 planes.  Neither pass has a
+//                            block-wide barrier: every wave is its own latency chain.
 // The *_fixed<KS> forms unroll over a compile-time tap count (taps beyond an image's own count carry weight 0); the
 // generic forms loop over the run-time count and serve very large reductions (more than 25 taps: > 6x) and widths
 // that are not a multiple of 4.  A variable-length tap loop costs one dependent memory latency per tap: 49 us + 28 us
@@ -174,9 +175,7 @@ __global__ __launch_bounds__(256) void resample_rows_fixed_kernel(const unsigned
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (row0 >= in_h) return;
+    if (row0 >= in_h) return;  // no block-wide barrier below: a wave reads only the LDS rows its own DMA wrote
     const int* ctab = coef + (int64_t)(b * 2) * ks * n;
     const int* btab = bounds + (int64_t)(b * 2) * n * 2;
     for (int t0 = 0; t0 < n; t0 += 256) {
@@ -188,6 +187,8 @@ __global__ __launch_bounds__(256) void resample_rows_fixed_kernel(const unsigned
 #pragma unroll
             for (int x = 0; x < KS; ++x) kreg[j][x] = x < ks ? ctab[x * n + tt] : 0;
         }
+        // the taps' loads above travel together with the rows' DMA; everything has landed after this wait
+        if (t0 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int r = 0; r < PP_ROWS; ++r) {
             if (r < R && row0 + r < in_h) {
@@ -224,14 +225,17 @@ __global__ __launch_bounds__(256) void resample_rows_fixed_kernel(const unsigned
     }
 }
 
-// grid (n output rows, image); n % 4 == 0.  Dynamic LDS: 3n bytes (the output row as bytes, pixel-interleaved).
+// grid (ceil(n / 4), image), one output row per wave (four independent latency chains per block); n % 4 == 0.
+// Dynamic LDS: 4 x 3n bytes (each wave's output row as bytes, pixel-interleaved).
 template <int KS>
 __global__ __launch_bounds__(256) void resample_cols_fixed_kernel(const int* __restrict__ desc, const int64_t* __restrict__ row_start,
                                                                   const int* __restrict__ coef, const int* __restrict__ bounds,
                                                                   const unsigned char* __restrict__ tmp, const float* __restrict__ lut,
                                                                   float* __restrict__ out, int n, int ks) {
     extern __shared__ unsigned int pp_lds_[];
-    const int yy = blockIdx.x, b = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // scalar: taps via s_load
+    const int yy = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (yy >= n) return;  // waves are independent: no block-wide barrier in this kernel
     const int flip = desc[b * PP_DESC + 10];
     const int* ctab = coef + (int64_t)(b * 2 + 1) * ks * n + yy;
     const int* btab = bounds + (int64_t)(b * 2 + 1) * n * 2 + 2 * yy;
@@ -240,8 +244,9 @@ __global__ __launch_bounds__(256) void resample_cols_fixed_kernel(const int* __r
 #pragma unroll
     for (int y = 0; y < KS; ++y) k[y] = y < ks ? ctab[y * n] : 0;
     const int nd = (3 * n) >> 2;
+    unsigned int* mine = pp_lds_ + wave * nd;
     const unsigned int* src4 = reinterpret_cast<const unsigned int*>(tmp + (row_start[b] + ymin) * (int64_t)(3 * n));
-    for (int i = threadIdx.x; i < nd; i += 256) {
+    for (int i = lane; i < nd; i += 64) {
         unsigned int v[KS];
 #pragma unroll
         for (int y = 0; y < KS; ++y) v[y] = src4[(int64_t)(y < cnt ? y : cnt - 1) * nd + i];
@@ -254,14 +259,16 @@ __global__ __launch_bounds__(256) void resample_cols_fixed_kernel(const int* __r
         // opaque to the optimiser: hipcc 7.2 otherwise folds shift + clamp + pack of c0, c1 into v_ashr_pk_u8_i32 and ORs
         // c2, c3 onto its result as if the instruction cleared the upper half of the register — on gfx950 it keeps it
         asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-        pp_lds_[i] = (unsigned)c0 | ((unsigned)c1 << 8) | ((unsigned)c2 << 16) | ((unsigned)c3 << 24);
+        mine[i] = (unsigned)c0 | ((unsigned)c1 << 8) | ((unsigned)c2 << 16) | ((unsigned)c3 << 24);
     }
-    __syncthreads();
-    const unsigned char* rowb = reinterpret_cast<const unsigned char*>(pp_lds_);
-    for (int e = threadIdx.x; e < 3 * n; e += 256) {
-        const int c = e / n, xx = e - c * n;
-        const int xo = flip ? n - 1 - xx : xx;
-        __builtin_nontemporal_store(lut[c * 256 + rowb[3 * xx + c]], out + ((int64_t)(b * 3 + c) * n + yy) * n + xo);
+    // one wave's LDS instructions execute in order: its reads below see its writes above once the compiler keeps them apart
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned char* rowb = reinterpret_cast<const unsigned char*>(mine);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float* plane = out + ((int64_t)(b * 3 + c) * n + yy) * n;
+        for (int xx = lane; xx < n; xx += 64)
+            __builtin_nontemporal_store(lut[c * 256 + rowb[3 * xx + c]], plane + (flip ? n - 1 - xx : xx));
     }
 }
 
@@ -298,8 +305,8 @@ SWAT_API int swat_preprocess_batch(const void* pixels_u8, const int64_t* offsets
         const int row_words = ((max_in_w * 3 + 3 + 3) / 4 + 63) / 64 * 64 + 24;
         SWAT_REQUIRE(16 * row_words <= 64 * 1024, "swat_preprocess_batch: regions wider than 5300 pixels are not supported (%d)", max_in_w);
         const int R = 64 * row_words <= 48 * 1024 ? 4 : (32 * row_words <= 48 * 1024 ? 2 : 1);
-        const dim3 grid_r((max_in_h + 4 * R - 1) / (4 * R), n_images), grid_c(n_px, n_images);
-        const size_t lds_r = (size_t)16 * R * row_words, lds_c = (size_t)3 * n_px;
+        const dim3 grid_r((max_in_h + 4 * R - 1) / (4 * R), n_images), grid_c((n_px + 3) / 4, n_images);
+        const size_t lds_r = (size_t)16 * R * row_words, lds_c = (size_t)4 * 3 * n_px;
 #define SWAT_PP_LAUNCH(KS)                                                                                                             \
     do {                                                                                                                               \
         hipLaunchKernelGGL(swat::resample_rows_fixed_kernel<KS>, grid_r, dim3(256), lds_r, s, pix, offsets, desc, row_start, coef,     \

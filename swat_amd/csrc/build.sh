@@ -8,7 +8,10 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -Wall -Wno
 pids=()
 for f in *.hip; do
   o=_obj/${f%.hip}.o
-  if [ ! -f $o ] || [ $f -nt $o ] || [ common.hpp -nt $o ] || [ ../../include/swat_hip.h -nt $o ]; then
+  stale=0
+  [ -f $o ] || stale=1
+  for dep in $f *.hpp ../../include/*.h build.sh; do [ $dep -nt $o ] && stale=1; done
+  if [ $stale = 1 ]; then
     echo "hipcc $f"
     /opt/rocm/bin/hipcc $FLAGS -c $f -o $o &
     pids+=($!)

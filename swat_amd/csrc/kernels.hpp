@@ -30,9 +30,14 @@ struct GemmArgs {
     float* colsum;  // TN only, lean kernels: colsum[m] = sum_k A[k, m] (the bias gradient that goes with a weight gradient
                     // dW = dY^T X), produced by the n-tile-0 workgroups with one extra MFMA against a ones fragment per k-step
     int epi0;  // split-K: apply bias / residual / rowbias on batch slice 0 only (the other slices are raw partial planes)
+    unsigned long long* trace;  // tuning only (exp bit 16): per-workgroup time stamps of the producer / consumer kernel
     int exp;  // tuning experiments (bit 0: no loads after the prologue, bit 1: no MFMA, bit 2: no epilogue); 0 in production
 };
 
 int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s);
+// grid + XCD-aware tile order for bm x bn tiles (fills swz / tiles_m / tiles_n / exp of b); gemm.hip
+dim3 plan_grid(GemmArgs& b, int bm, int bn, int batch);
+// producer / consumer kernel, tile configurations >= 50 (gemm_pc.hip); batch == 1, K % 64 == 0, K >= 256
+int launch_gemm_pc(int layout, const GemmArgs& a, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 }  // namespace swat

@@ -323,7 +323,12 @@ def test_adamw_matches_torch():
     assert torch.equal(shadow, p.to(BF))
 
 
-@pytest.mark.parametrize("cfg", [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 43])
+PC_LAYOUTS = {50: ("nt", "nn", "tn"), 51: ("nt", "nn"), 53: ("nt", "nn", "tn"), 54: ("tn",), 55: ("nt", "nn", "tn"),
+              56: ("nt", "nn", "tn"), 58: ("nt", "nn")}
+
+
+@pytest.mark.parametrize("cfg", [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 43,
+                                 50, 51, 53, 54, 55, 56, 58])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm_every_tile_configuration(cfg, layout):
     """All register-staged and LDS-DMA pipelined tile configurations give the same product (ragged M/N edges)."""
@@ -331,6 +336,8 @@ def test_gemm_every_tile_configuration(cfg, layout):
     M, N, K = 1600, 840, 768  # 1600 = 12.5 x 128 rows, 840 = 6.56 x 128 cols: edge tiles on both sides
     a, b = rnd(M, K, seed=31, dtype=BF), rnd(N, K, seed=32, scale=0.05, dtype=BF)
     ref = a.float() @ b.float().t()
+    if cfg >= 50 and layout not in PC_LAYOUTS[cfg]:
+        pytest.skip("producer / consumer tile not built for this layout")
     _lib.lib().swat_gemm_set_tile(cfg)
     try:
         C = torch.empty(M, N, device=dev(), dtype=F32)

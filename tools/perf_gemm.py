@@ -12,7 +12,10 @@ shapes = [  # (name, layout, M, N, K)  in the kernel's own (rows, cols, reductio
     ("wgrad proj", ops.TN, d, 4 * d, M), ("wgrad fc", ops.TN, 4 * d, d, M), ("wgrad out", ops.TN, d, d, M), ("wgrad qkv", ops.TN, 3 * d, d, M),
     ("patch", ops.NT, 1568, d, 3072), ("wgrad conv", ops.TN, d, 3072, 1568),
 ]
-cfgs = {14: "d64x64s3", 16: "d128x64s3", 25: "D128sq8w s3", 26: "D128sq8w s4", 27: "D128x64 8w", 28: "D256x128 8w", 30: "R64x64d4"}
+cfgs = {14: "d64x64s3", 30: "R64x64d4", 50: "P128x128", 51: "P160x128", 52: "P160x96", 53: "P96x64", 54: "P96x96", 55: "P128x64", 56: "P64x64", 57: "P192x128",
+        58: "P128sq8c", 59: "P128sqL2", 60: "P128sqL8", 61: "P128sqS5", 62: "P80x64", 63: "P48x48"}
+if len(sys.argv) > 1:
+    cfgs = {int(c): str(c) for c in sys.argv[1].split(",")}
 print(f"{'shape':18s} " + " ".join(f"{v:>11s}" for v in cfgs.values()) + "   (TFLOP/s)")
 for name, layout, m, n, k in shapes:
     if layout == ops.NT:

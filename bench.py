@@ -88,24 +88,24 @@ def gemm_roofline(args, step, sched, images, labels, n_steps, bsz, overlap=1):
     torch.cuda.synchronize()
     lib.swat_vit_set_overlap(min(overlap, 1))
     step.trail = trail
-    ms = (ctypes.c_double * 6)()
-    cnt = (ctypes.c_int64 * 6)()
-    fl = (ctypes.c_double * 6)()
+    ms = (ctypes.c_double * 9)()
+    cnt = (ctypes.c_int64 * 9)()
+    fl = (ctypes.c_double * 9)()
     n = lib.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
-    names = ["NT_64", "NT_128", "NN_64", "NN_128", "TN_64", "TN_128"]
+    names = ["NT_64", "NT_128", "NT_pc", "NN_64", "NN_128", "NN_pc", "TN_64", "TN_128", "TN_pc"]
     total_ms = sum(ms) / n_steps
     # the T = 50 attention products run in the one-workgroup-per-head kernels, not in gemm_*: take their share out
     attn_flops = 3 * 2 * (2.0 * 50 * 50 * 64) * bsz * 12 * 12
     algo_flops = GFLOP_PER_IMG_STEP * 1e9 * bsz - attn_flops
     achieved = algo_flops / (total_ms * 1e-3) / 1e12
     per_kind = {names[i]: {"launches_per_step": cnt[i] / n_steps, "avg_us": (1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0,
-                           "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0} for i in range(6)}
+                           "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0} for i in range(9) if cnt[i]}
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
     if os.path.exists(tpath):  # PMC passes cannot run inside this process: the committed rocprofv3 --pmc result of this command
         traffic = round(json.load(open(tpath))["hbm_bytes_per_gemm_launch"])
         traffic_src = "profiles/r01_gemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per GEMM launch)"
-    return {"bound": "mfma", "kernel": "gemm_dma_kernel / gemm_ring2_kernel / gemm_ring_kernel (all GEMM instantiations)",
+    return {"bound": "mfma", "kernel": "gemm_pc_kernel / gemm_dma_kernel / gemm_ring2_kernel / gemm_ring_kernel (all GEMM instantiations)",
             "achieved": round(achieved, 2),
             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(algo_flops / (n / n_steps)),

@@ -689,6 +689,22 @@ static int pick_cfg(int layout, const GemmArgs& a, int batch) {
     // register ring (30) for the deep-K dgrad / small wgrad products; everything ragged goes to the staged ring (20).
     const bool whole = a.K % 64 == 0;
     if (!whole || batch > 1) return a.K % 64 == 0 && batch > 1 ? 14 : 20;
+    // One-round grids go to the producer / consumer kernel (gemm_pc.hip: one large tile per CU, loader waves + consumer
+    // waves, LDS-staged epilogue).  Measured per launch with the step's own epilogues (tools/perf_gemm.py, M = 1600):
+    // c_fc forward 17.1 vs 18.8 us, c_proj dgrad 17.0 vs 19.0 (160 x 128: 240 tiles); the N = 768 products 9.4 / 19.9 /
+    // 17.9 / 7.3 / 14.5 vs 12.6 / 24.7 / 23.8 / 8.4 / 19.3 us (96 x 64: 204 tiles); c_fc / c_proj weight gradients 15.8 /
+    // 16.6 vs 21.3 us (96 x 96: 256 tiles); out_proj / in_proj weight gradients 9.7 / 14.0 vs 10.6 / 17.2 us (64 x 64).
+    if (!(g_exp & 512) && a.K >= 256) {
+        auto tiles = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+        if (layout != L_TN) {
+            if (a.N >= 2048 && a.K <= 1024) {
+                if (tiles(160, 128) > 192 && tiles(160, 128) <= 256) return 51;
+            } else if (tiles(96, 64) > 128 && tiles(96, 64) <= 256) return 53;
+        } else {
+            if (tiles(96, 96) > 192 && tiles(96, 96) <= 256) return 54;
+            if (tiles(64, 64) >= 128 && tiles(64, 64) <= 512) return 56;
+        }
+    }
     // thousands of rows (ViT-B/16: 6 304, ViT-L/14: 8 224 at B = 32) fill several rounds with any tile: there the
     // 128-wide tiles' lower operand traffic wins the deep-K products (register ring 128x128 / 128x64) and the wgrads
     const bool many_rows = (layout == L_TN ? a.K : a.M) >= 4096;
@@ -715,7 +731,7 @@ struct GemmProf {
     bool on = false;
     int cap = 0, n = 0;
     hipEvent_t* ev = nullptr;  // 2 per launch
-    int* kind = nullptr;       // layout * 2 + (128-row tile)
+    int* kind = nullptr;       // layout * 3 + (0: 64-row tile, 1: 128-row tile, 2: producer / consumer kernel)
     double* flops = nullptr;
 };
 static GemmProf g_prof;
@@ -738,7 +754,7 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     else if (layout == L_NN) rc = launch_gemm<L_NN>(a, batch, tile, s, ev0, ev1);
     else rc = launch_gemm<L_TN>(a, batch, tile, s, ev0, ev1);
     if (prof) {
-        g_prof.kind[g_prof.n] = layout * 2 + (tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43);
+        g_prof.kind[g_prof.n] = layout * 3 + (tile >= 50 ? 2 : 0) + (tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43);
         g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
         ++g_prof.n;
     }
@@ -784,11 +800,12 @@ SWAT_API int swat_gemm_prof_begin(int max_launches) {
     return 0;
 }
 
-// Stop, synchronise the events and report per kind (layout*2 + 128-row tile; 6 kinds): total ms, launches, flops.
+// Stop, synchronise the events and report per kind (layout * 3 + {64-row tile, 128-row tile, producer / consumer}; 9 kinds):
+// total ms, launches, flops.
 SWAT_API int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind) {
     using swat::g_prof;
     g_prof.on = false;
-    for (int k = 0; k < 6; ++k) { ms_by_kind[k] = 0; count_by_kind[k] = 0; flops_by_kind[k] = 0; }
+    for (int k = 0; k < 9; ++k) { ms_by_kind[k] = 0; count_by_kind[k] = 0; flops_by_kind[k] = 0; }
     for (int i = 0; i < g_prof.n; ++i) {
         SWAT_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
         float ms = 0.f;

@@ -83,6 +83,58 @@ def test_linear_wgrad_bias(M, N, K):
     assert (db - ref).abs().max().item() <= 1e-5 * math.sqrt(M) * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [50, 51, 53, 55, 56, 58])
+def test_gemm_producer_consumer_epilogues(cfg):
+    """The producer / consumer kernel's LDS-staged epilogue: bias, activation + second output, in-place fp32 residual,
+    dgrad through the activation, fp32 and bf16 outputs, ragged M edge (M = 200 is not a multiple of any tile height)."""
+    from swat_amd import ops, _lib
+    M, N, K = 200, 3072, 768
+    x, w, b = rnd(M, K, seed=1, dtype=BF), rnd(N, K, seed=2, scale=0.05, dtype=BF), rnd(N, seed=3)
+    _lib.lib().swat_gemm_set_tile(cfg)
+    try:
+        pre, post = ops.linear_fwd(x, w, bias=b, act="quick_gelu", want_act=True)
+        ref_pre = x.float() @ w.float().t() + b
+        close(pre, ref_pre, True, K)
+        f = pre.float()
+        close(post, f * torch.sigmoid(1.702 * f), True, 1)
+        res = rnd(M, K, seed=9)
+        w2 = rnd(K, N, seed=10, scale=0.02, dtype=BF)
+        expect = res + post.float() @ w2.float().t() + b[:K]
+        out = res.clone()
+        ops.gemm(ops.NT, post, w2, M, K, N, N, N, out, K, bias=b[:K].contiguous(), residual=out)
+        close(out, expect, False, N)
+        dg = rnd(M, K, seed=11, dtype=BF)
+        df = ops.linear_dgrad(dg, w2, actin=pre, act="quick_gelu")
+        fr = pre.float().requires_grad_(True)
+        (fr * torch.sigmoid(1.702 * fr)).backward(dg.float() @ w2.float())
+        close(df, fr.grad, True, K)
+        y32 = ops.linear_fwd(x, w, out_dtype=F32)
+        close(y32, x.float() @ w.float().t(), False, K)
+    finally:
+        _lib.lib().swat_gemm_set_tile(-1)
+
+
+@pytest.mark.parametrize("cfg", [50, 53, 54, 55, 56])
+def test_gemm_producer_consumer_wgrad_bias(cfg):
+    """Weight gradient + fused bias gradient (one extra MFMA against a ones fragment) on the producer / consumer kernel."""
+    from swat_amd import _lib
+    lib = _lib.lib()
+    M, N, K = 1600, 2304, 768
+    dy, x = rnd(M, N, seed=8, dtype=BF), rnd(M, K, seed=9, dtype=BF)
+    dw = torch.empty(N, K, device=dy.device)
+    db = torch.full((N,), float("nan"), device=dy.device)
+    ws = torch.empty(lib.swat_colsum_bf16_workspace_bytes(N), dtype=torch.uint8, device=dy.device)
+    lib.swat_gemm_set_tile(cfg)
+    try:
+        _lib.check(lib.swat_linear_wgrad_bias(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), M, N, K, N, K, _lib.ptr(ws),
+                                              _lib.stream()), "swat_linear_wgrad_bias")
+    finally:
+        lib.swat_gemm_set_tile(-1)
+    close(dw, dy.float().t() @ x.float(), False, M)
+    ref = dy.float().sum(0)
+    assert (db - ref).abs().max().item() <= 1e-5 * math.sqrt(M) * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
 def test_gemm_epilogues(act):
     from swat_amd import ops

@@ -171,6 +171,12 @@ int swat_colsum_bf16(const void* X_bf16, int64_t rows, int n, int ld, float* out
  *     else GEMM + the two-stage column sum; workspace: swat_colsum_bf16_workspace_bytes(n_out). */
 int swat_linear_wgrad_bias(const void* dY_bf16, const void* X_bf16, float* dW, float* dbias, int rows, int n_out,
                            int n_in, int ld_dy, int ld_x, void* workspace, swat_stream_t stream);
+/*     the same for n <= 4 layers in ONE persistent launch over the joint tile list (the four weight gradients of a
+ *     transformer block are independent; the reference's autograd runs them as separate cuBLAS calls).  Arrays are HOST
+ *     arrays of length n; dbias[i] may be null; rows[i] % 64 != 0 falls back to one launch per layer. */
+int swat_linear_wgrad_bias_group(int n, const void* const* dY_bf16, const void* const* X_bf16, float* const* dW,
+                                 float* const* dbias, const int* rows, const int* n_out, const int* n_in,
+                                 const int* ld_dy, const int* ld_x, void* workspace, swat_stream_t stream);
 int swat_gather_cast_bf16(const float* in, void* out_bf16, int64_t rows, int d, int64_t group_rows,
                           int64_t group_stride_rows, int64_t row_off, swat_stream_t stream);
 int swat_cast_bf16(const float* in, void* out_bf16, int64_t n, swat_stream_t stream);
@@ -245,6 +251,10 @@ int swat_vit_backward(const int32_t* dims, const int64_t* offs, const float* par
  *     optimizer slice can trail the backward without stalling it.  mode 0: everything on `stream`.
  *     Same kernels and buffers in every mode: the gradients are bit-identical. */
 int swat_vit_set_overlap(int mode);
+/* Split-K planes of the deep, narrow products (c_proj forward, c_fc / in_proj dgrads: K = 4d / 3d onto N = d): the
+ *     reduction runs as `planes` slices into fp32 planes that the next LayerNorm kernel sums in a fixed order (default 3;
+ *     0 or 1 = one launch, no planes).  Deterministic either way; the per-element summation order differs. */
+int swat_vit_set_split_k(int planes);
 swat_stream_t swat_vit_lane_stream(void);
 swat_stream_t swat_vit_aux_stream(int i); /* i = 0, 1: two more process-wide streams created together with the lane (the
                                             * data-parallel step's all-reduce and optimizer streams) */

@@ -688,6 +688,12 @@ static int pick_cfg(int layout, const GemmArgs& a, int batch) {
     // workgroups in flight) win: LDS-DMA (14) for the k-contiguous NT products and the large wgrads, the lean
     // register ring (30) for the deep-K dgrad / small wgrad products; everything ragged goes to the staged ring (20).
     const bool whole = a.K % 64 == 0;
+    // split-K planes of a deep product with a narrow output (c_proj forward, the c_fc / in_proj dgrads: N = 768, K = 2304 /
+    // 3072): 128 x 128 tiles over <= 4 planes fill the chip with half the operand bytes per flop of the 96 x 64 tiling
+    if (whole && batch >= 2 && batch <= 4 && layout != L_TN && !(g_exp & 512) && a.K >= 256) {
+        const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
+        if (t128 > 160 && t128 <= 256) return 50;
+    }
     if (!whole || batch > 1) return a.K % 64 == 0 && batch > 1 ? 14 : 20;
     // One-round grids go to the producer / consumer kernel (gemm_pc.hip: one large tile per CU, loader waves + consumer
     // waves, LDS-staged epilogue).  Measured per launch with the step's own epilogues (tools/perf_gemm.py, M = 1600):
@@ -738,7 +744,7 @@ static GemmProf g_prof;
 
 int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     int tile = pick_cfg(layout, a, batch);
-    if (tile >= 50 && (batch != 1 || a.K % 64 != 0)) tile = (a.K % 64 == 0) ? 14 : 20;  // the producer / consumer kernel: whole k-steps, one product
+    if (tile >= 50 && (batch > 4 || a.K % 64 != 0)) tile = (a.K % 64 == 0) ? 14 : 20;  // the producer / consumer kernel: whole k-steps, <= 4 planes
     if (a.colsum) {
         const bool lean = tile >= 50 || tile == 14 || (tile >= 15 && tile <= 19) || (tile >= 25 && tile <= 28) || (tile >= 30 && tile <= 34) || tile == 43;
         SWAT_REQUIRE(layout == L_TN && batch == 1 && lean && a.K % 64 == 0 && a.K >= 384,
@@ -749,13 +755,40 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     // kernel's execution time as rocprofv3 reports it, without the ~2-3 us each separately recorded event adds
     hipEvent_t ev0 = prof ? g_prof.ev[2 * g_prof.n] : nullptr, ev1 = prof ? g_prof.ev[2 * g_prof.n + 1] : nullptr;
     int rc;
-    if (tile >= 50) rc = launch_gemm_pc(layout, a, tile, s, ev0, ev1);
+    if (tile >= 50) rc = launch_gemm_pc(layout, a, batch, tile, s, ev0, ev1);
     else if (layout == L_NT) rc = launch_gemm<L_NT>(a, batch, tile, s, ev0, ev1);
     else if (layout == L_NN) rc = launch_gemm<L_NN>(a, batch, tile, s, ev0, ev1);
     else rc = launch_gemm<L_TN>(a, batch, tile, s, ev0, ev1);
     if (prof) {
         g_prof.kind[g_prof.n] = layout * 3 + (tile >= 50 ? 2 : 0) + (tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43);
         g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
+        ++g_prof.n;
+    }
+    return rc;
+}
+
+// n products of one layout (the weight gradients of a transformer block): ONE persistent launch over the joint tile list
+// when every product qualifies for the producer / consumer kernel's grouped form, else one launch each.
+int gemm_group_dispatch(int layout, const GemmArgs* probs, int n, hipStream_t s) {
+    bool ok = layout == L_TN && n >= 2 && n <= 4 && !(g_exp & 512) && g_force_cfg < 0;
+    for (int i = 0; ok && i < n; ++i) {
+        const GemmArgs& a = probs[i];
+        ok = a.K % 64 == 0 && a.K >= 256 && a.out_f32 && a.N % 4 == 0 && a.ldc % 4 == 0 && !a.actin && !a.C2 && a.inner == 1 &&
+             (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0;
+    }
+    if (!ok) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = gemm_dispatch(layout, probs[i], 1, s)) return rc;
+        return 0;
+    }
+    const bool prof = g_prof.on && g_prof.n < g_prof.cap;
+    hipEvent_t ev0 = prof ? g_prof.ev[2 * g_prof.n] : nullptr, ev1 = prof ? g_prof.ev[2 * g_prof.n + 1] : nullptr;
+    const int rc = launch_gemm_pc_group(layout, probs, n, s, ev0, ev1);
+    if (prof) {
+        g_prof.kind[g_prof.n] = layout * 3 + 2;
+        double fl = 0;
+        for (int i = 0; i < n; ++i) fl += 2.0 * probs[i].M * probs[i].N * probs[i].K;
+        g_prof.flops[g_prof.n] = fl;
         ++g_prof.n;
     }
     return rc;

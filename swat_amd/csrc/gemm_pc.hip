@@ -529,13 +529,331 @@ __global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pc_kernel(const Gemm
     }
 }
 
+// ---- persistent, grouped form: up to 4 products of one layout in ONE launch, 256 workgroups walking the joint tile list
+// (the weight gradients of a transformer block: four launches of 64-256 tiles each pay four times for dispatch, set-up
+// and the first operand bytes).  The stage stream is continuous across tiles: the loaders run NS-1 stages ahead straight
+// into the next tile's operands while the consumers finish a tile, park its accumulators in an LDS tile of its own
+// (behind the ring) and store it with the fused epilogue; one extra barrier per tile.  Tiles of a workgroup are
+// b, b + G, b + 2G, ... of the joint list after the XCD-contiguous remap, so an XCD's L2 keeps serving the same panels.
+struct GemmGroup {
+    int n, total;
+    int tile_end[4];
+    GemmArgs p[4];
+};
+
+template <int LAYOUT, int BM, int BN, int CM, int CN, int NL, int NS>
+__global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pcg_kernel(const GemmGroup g) {
+    constexpr bool A_KC = (LAYOUT != L_TN);
+    constexpr bool B_KC = (LAYOUT == L_NT);
+    constexpr int NC = CM * CN;
+    constexpr int WM = BM / CM, WN = BN / CN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    static_assert(BM % (16 * CM) == 0 && BN % (16 * CN) == 0, "wave tiles are whole 16 x 16 fragments");
+    constexpr int PA = BM / 8, PB = BN / 8, P = PA + PB;
+    constexpr int A_BYTES = PA * 1024;
+    constexpr int STAGE = P * 1024;
+    constexpr int LPS = (P + NL - 1) / NL;
+    constexpr int CT_BYTES = BM * (BN + 4) * 4;
+    static_assert(NS >= 4, "consumers read stages t and t+1 while t+2, t+3 fly");
+    static_assert(NS * STAGE + CT_BYTES <= 160 * 1024, "LDS ring + output tile");
+    static_assert(P > NL, "more pieces than loader waves");
+    constexpr int NA = A_KC ? 1 : 2, NB = B_KC ? 1 : 2;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE + CT_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x, total = g.total;
+    const int ntiles = (total - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup (>= 1: G <= total)
+
+    // joint tile list -> (problem, tile row, tile column), after the XCD-contiguous remap of the virtual tile number
+    auto decode = [&](int vt, int& pi, int& by, int& bx) {
+        const int xcd = vt & 7, q = total >> 3, r = total & 7;
+        int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vt >> 3);
+        pi = 0;
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k + 1 < g.n && id >= g.tile_end[k]) { pi = k + 1; base = g.tile_end[k]; }
+        id -= base;
+        const int tm = g.p[pi].tiles_m, tn = g.p[pi].tiles_n;
+        if (g.p[pi].swz == 2) { bx = id % tn; by = id / tn; }
+        else { by = id % tm; bx = id / tm; }
+    };
+
+    if (wave >= NC) {
+        // ================================ loader waves ================================
+        const int lw = wave - NC;
+        unsigned voff[LPS];
+        unsigned amask = 0, dmask = 0;
+        const char *curA = nullptr, *curB = nullptr;
+        int64_t stepA = 0, stepB = 0;
+        int nk = 0, kk = 0;  // k-steps of the tile being issued, next k-step to issue
+        auto open_tile = [&](int ti) {  // per-lane source offsets and wave-uniform bases of tile number ti of this workgroup
+            int pi, by, bx;
+            decode((int)blockIdx.x + ti * G, pi, by, bx);
+            const GemmArgs& p = g.p[pi];
+            const int m0 = by * BM, n0 = bx * BN, M = p.M, N = p.N;
+            amask = 0; dmask = 0;
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) {
+                int q = lw + NL * i;
+                if (q >= P) { q -= NL; dmask |= 1u << i; }
+                const bool isA = q < PA;
+                if (isA) amask |= 1u << i;
+                const int byte = (isA ? q : q - PA) * 1024 + lane * 16;
+                unsigned off;
+                if (isA) {
+                    if constexpr (A_KC) {
+                        const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
+                        int gr = m0 + row; gr = gr < M ? gr : M - 1;
+                        off = (unsigned)((gr - m0) * p.lda + 8 * t) * 2u;
+                    } else {
+                        int k, col;
+                        stp_inv<BM>(byte, k, col);
+                        int gc = m0 + col; gc = gc + 8 <= p.lda ? gc : 0;
+                        off = (unsigned)(k * p.lda + gc) * 2u;
+                    }
+                } else {
+                    if constexpr (B_KC) {
+                        const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
+                        int gr = n0 + row; gr = gr < N ? gr : N - 1;
+                        off = (unsigned)((gr - n0) * p.ldb + 8 * t) * 2u;
+                    } else {
+                        int k, col;
+                        stp_inv<BN>(byte, k, col);
+                        int gc = n0 + col; gc = gc + 8 <= p.ldb ? gc : 0;
+                        off = (unsigned)(k * p.ldb + gc) * 2u;
+                    }
+                }
+                voff[i] = off;
+            }
+            curA = reinterpret_cast<const char*>(p.A + (A_KC ? (int64_t)m0 * p.lda : 0));
+            curB = reinterpret_cast<const char*>(p.B + (B_KC ? (int64_t)n0 * p.ldb : 0));
+            stepA = A_KC ? 128 : (int64_t)128 * p.lda;
+            stepB = B_KC ? 128 : (int64_t)128 * p.ldb;
+            nk = p.K >> 6;
+            kk = 0;
+        };
+        int ti_issue = 0;  // tile the next issue belongs to
+        open_tile(0);
+        int64_t stages_total = 0;  // all k-steps of all tiles of this workgroup
+        for (int ti = 0; ti < ntiles; ++ti) {
+            int pi, by, bx;
+            decode((int)blockIdx.x + ti * G, pi, by, bx);
+            stages_total += g.p[pi].K >> 6;
+        }
+        const int S = (int)stages_total;
+        int issued = 0, buf = 0;
+        auto issue = [&]() {  // next stage of the stream into ring buffer `buf`
+            unsigned char* st = smem + buf * STAGE + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) {
+                const char* src = ((amask >> i) & 1) ? curA : curB;
+                unsigned char* dst = st + (NL * i - (((dmask >> i) & 1) ? NL : 0)) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + voff[i]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+            curA += stepA; curB += stepB;
+            ++issued;
+            buf = buf + 1 == NS ? 0 : buf + 1;
+            if (++kk == nk && ti_issue + 1 < ntiles) open_tile(++ti_issue);
+        };
+#pragma unroll 1
+        for (int s0 = 0; s0 < NS - 1 && s0 < S; ++s0) issue();
+        // consumer side bookkeeping mirrored here: the extra barrier at the end of every tile
+        int ct = 0, ck = 0, cnk;  // tile / k-step the consumers are at
+        {
+            int pi, by, bx;
+            decode((int)blockIdx.x, pi, by, bx);
+            cnk = g.p[pi].K >> 6;
+        }
+        for (int s = 0; s < S; ++s) {
+            // stages issued: `issued`; stage min(s + 1, S - 1) must have landed
+            const int need = s + 1 < S - 1 ? s + 1 : S - 1;
+            switch (issued - 1 - need) {
+                case 1: pc_wait_vmcnt<LPS>(); break;
+                case 2: pc_wait_vmcnt<(NS >= 5 ? 2 : 0) * LPS>(); break;
+                case 3: pc_wait_vmcnt<(NS >= 6 ? 3 : 0) * LPS>(); break;
+                default: pc_wait_vmcnt<0>(); break;
+            }
+            pc_barrier();
+            if (issued < S) issue();
+            if (++ck == cnk) {  // the consumers finish a tile behind this stage: their accumulators go through LDS
+                pc_barrier();
+                ck = 0;
+                if (++ct < ntiles) {
+                    int pi, by, bx;
+                    decode((int)blockIdx.x + ct * G, pi, by, bx);
+                    cnk = g.p[pi].K >> 6;
+                }
+            }
+        }
+        return;
+    }
+
+    // ================================ consumer waves ================================
+    const int wm0 = (wave / CN) * WM;
+    const int wn0 = (wave % CN) * WN;
+    const int r16 = lane & 15, gq = lane >> 4;
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
+    float* cl = reinterpret_cast<float*>(smem + NS * STAGE);
+    unsigned ra[2][A_KC ? 1 : FM][NA], rb[2][B_KC ? 1 : FN][NB];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (A_KC) ra[ks][0][0] = lds0 + kc_off(wm0 + r16, 4 * ks + gq);
+        else {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int k = 32 * ks + 8 * gq + (r16 >> 2);
+                ra[ks][i][0] = lds0 + stp_off<BM>(k, wm0 + 16 * i) + 8 * (r16 & 3);
+                ra[ks][i][NA - 1] = lds0 + stp_off<BM>(k + 4, wm0 + 16 * i) + 8 * (r16 & 3);
+            }
+        }
+        if constexpr (B_KC) rb[ks][0][0] = lds0 + A_BYTES + kc_off(wn0 + r16, 4 * ks + gq);
+        else {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int k = 32 * ks + 8 * gq + (r16 >> 2);
+                rb[ks][j][0] = lds0 + A_BYTES + stp_off<BN>(k, wn0 + 16 * j) + 8 * (r16 & 3);
+                rb[ks][j][NB - 1] = lds0 + A_BYTES + stp_off<BN>(k + 4, wn0 + 16 * j) + 8 * (r16 & 3);
+            }
+        }
+    }
+    bf16x8_t fa[FM], fb[2][FN];
+    constexpr int RB = FM >= 2 ? FM / 2 : 1;
+    auto read_a = [&](auto I, unsigned so, int ks) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (A_KC) fa[i] = pc_lds_b128<2048 * i>(ra[ks][0][0] + so);
+        else fa[i] = pc_lds_tr(ra[ks][i][0] + so, ra[ks][i][NA - 1] + so);
+    };
+    auto read_b = [&](auto J, unsigned so, int ks, bf16x8_t (&bfr)[FN]) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (B_KC) bfr[j] = pc_lds_b128<2048 * j>(rb[ks][0][0] + so);
+        else bfr[j] = pc_lds_tr(rb[ks][j][0] + so, rb[ks][j][NB - 1] + so);
+    };
+    const s16x8_t ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
+    f32x4_t acc[FM][FN], accs[FM];
+    bool do_cs = false;
+    constexpr int NRI = FM * NA + FN * NB;
+    auto half = [&](auto WITH_READS, bf16x8_t (&bcur)[FN], bf16x8_t (&bnext)[FN], unsigned sn, int nks) {
+        pc_static_for<FM>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i == 0) {
+                pc_wait_lgkm<(FM - RB) * NA>();
+#pragma unroll
+                for (int j = 0; j < FN; ++j) pc_pin(bcur[j]);
+            } else if constexpr (decltype(WITH_READS)::value) {
+                pc_wait_lgkm<NRI - NA>();
+            } else {
+                constexpr int later_b = i + 1 < RB ? FN - (i + 1) * FN / RB : 0;
+                pc_wait_lgkm<(FM - 1 - i) * NA + later_b * NB>();
+            }
+            pc_pin(fa[i]);
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], fa[i], acc[i][j], 0, 0, 0);
+            if constexpr (LAYOUT == L_TN) {
+                if (do_cs) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], accs[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (decltype(WITH_READS)::value) {
+                read_a(I, sn, nks);
+                if constexpr (i < RB) {
+                    constexpr int j0 = i * FN / RB, j1 = (i + 1) * FN / RB;
+                    pc_static_for<j1 - j0>([&](auto Jd) {
+                        read_b(std::integral_constant<int, j0 + decltype(Jd)::value>{}, sn, nks, bnext);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+
+    pc_barrier();  // barrier 0: stages 0 and 1 have landed
+    pc_static_for<FM>([&](auto I) { read_a(I, 0u, 0); });
+    pc_static_for<FN>([&](auto J) { read_b(J, 0u, 0, fb[0]); });
+    pc_wait_lgkm<0>();
+    unsigned so = 0;  // byte offset in the ring of the stage being computed
+    for (int ti = 0; ti < ntiles; ++ti) {
+        int pi, by, bx;
+        decode((int)blockIdx.x + ti * G, pi, by, bx);
+        const GemmArgs& p = g.p[pi];
+        const int m0 = by * BM, n0 = bx * BN;
+        const int nk = p.K >> 6;
+        do_cs = LAYOUT == L_TN && p.colsum && n0 == 0 && wn0 == 0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) accs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t + 1 < nk; ++t) {
+            const unsigned sn = so + STAGE == NS * STAGE ? 0u : so + STAGE;
+            half(T1{}, fb[0], fb[1], so, 1);
+            half(T1{}, fb[1], fb[0], sn, 0);
+            pc_barrier();
+            so = sn;
+        }
+        const unsigned sn = so + STAGE == NS * STAGE ? 0u : so + STAGE;
+        half(T1{}, fb[0], fb[1], so, 1);
+        if (ti + 1 < ntiles) half(T1{}, fb[1], fb[0], sn, 0);  // the next tile's first fragments (its stage 0 is visible)
+        else half(T0{}, fb[1], fb[0], 0u, 0);
+        // epilogue: accumulators -> LDS tile -> fused epilogue + 16-B stores by the consumer waves
+        if (do_cs && (lane >> 4) == 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm0 + 16 * i + (lane & 15);
+                if (m < p.M) p.colsum[m] = accs[i][0];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<f32x4_t*>(cl + (wm0 + 16 * i + r16) * (BN + 4) + wn0 + 16 * j + 4 * gq) = acc[i][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pc_barrier();  // the tile's extra barrier: every consumer has parked its accumulators
+        pc_store_tile<BM, BN, 64 * NC>(p, cl, m0, n0, tid, 0, 0);
+        if (ti + 1 < ntiles) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS tile has been read before the next tile's stage barrier
+            pc_barrier();  // barrier of the next tile's first stage
+            so = sn;
+        }
+    }
+}
+
+int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    SWAT_REQUIRE(n >= 1 && n <= 4, "gemm group: 1-4 products");
+    GemmGroup g{};
+    g.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        g.p[i] = probs[i];
+        (void)plan_grid(g.p[i], 96, 96, 1);
+        if (g.p[i].swz == 0) g.p[i].swz = 1;  // small grids: any walk
+        total += g.p[i].tiles_m * g.p[i].tiles_n;
+        g.tile_end[i] = total;
+    }
+    g.total = total;
+    int G = total < 256 ? total : 256;
+    SWAT_REQUIRE(layout == L_TN, "gemm group: built for the weight-gradient layout only");
+    auto kern = gemm_pcg_kernel<L_TN, 96, 96, 2, 2, 4, 4>;
+    if (ev0) hipExtLaunchKernelGGL(kern, dim3(G), dim3(512), 0, s, ev0, ev1, 0, g);
+    else hipLaunchKernelGGL(kern, dim3(G), dim3(512), 0, s, g);
+    return check_launch("swat_gemm group (pc)");
+}
+
 // ---- launcher: configurations 50.. (swat_gemm_set_tile pins one; pick_cfg in gemm.hip chooses) ----
 template <int LAYOUT>
-static int launch_pc_layout(const GemmArgs& a, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+static int launch_pc_layout(const GemmArgs& a, int batch, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
 #define SWAT_PC(LMASK_, BM_, BN_, CM_, CN_, NL_, NS_)                                                                \
     if constexpr (((LMASK_) >> LAYOUT) & 1) {                                                                         \
         GemmArgs b = a;                                                                                               \
-        dim3 grid = plan_grid(b, BM_, BN_, 1);                                                                        \
+        dim3 grid = plan_grid(b, BM_, BN_, batch);                                                                    \
         auto kern = gemm_pc_kernel<LAYOUT, BM_, BN_, CM_, CN_, NL_, NS_>;                                             \
         if (ev0) hipExtLaunchKernelGGL(kern, grid, dim3(64 * (CM_ * CN_ + NL_)), 0, s, ev0, ev1, 0, b);              \
         else hipLaunchKernelGGL(kern, grid, dim3(64 * (CM_ * CN_ + NL_)), 0, s, b);                                   \
@@ -552,16 +870,22 @@ static int launch_pc_layout(const GemmArgs& a, int cfg, hipStream_t s, hipEvent_
         case 55: SWAT_PC(7, 128, 64, 2, 2, 4, 4) break;
         case 56: SWAT_PC(7, 64, 64, 2, 2, 4, 4) break;
         case 58: SWAT_PC(3, 128, 128, 2, 4, 4, 4) break;
+        case 60: SWAT_PC(3, 96, 64, 2, 2, 4, 7) break;
+        case 61: SWAT_PC(4, 96, 96, 2, 2, 4, 6) break;
+        case 62: SWAT_PC(7, 64, 64, 2, 2, 4, 8) break;
+        case 63: SWAT_PC(1, 128, 128, 2, 2, 4, 5) break;
+        case 64: SWAT_PC(3, 96, 64, 2, 2, 2, 7) break;
+        case 65: SWAT_PC(3, 96, 64, 2, 2, 8, 7) break;
         default: set_error("gemm_pc: unknown tile configuration %d", cfg); return -1;
     }
 #undef SWAT_PC
     return check_launch("swat_gemm_bf16 (pc)");
 }
 
-int launch_gemm_pc(int layout, const GemmArgs& a, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (layout == L_NT) return launch_pc_layout<L_NT>(a, cfg, s, ev0, ev1);
-    if (layout == L_NN) return launch_pc_layout<L_NN>(a, cfg, s, ev0, ev1);
-    return launch_pc_layout<L_TN>(a, cfg, s, ev0, ev1);
+int launch_gemm_pc(int layout, const GemmArgs& a, int batch, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (layout == L_NT) return launch_pc_layout<L_NT>(a, batch, cfg, s, ev0, ev1);
+    if (layout == L_NN) return launch_pc_layout<L_NN>(a, batch, cfg, s, ev0, ev1);
+    return launch_pc_layout<L_TN>(a, batch, cfg, s, ev0, ev1);
 }
 
 }  // namespace swat

@@ -208,6 +208,9 @@ __global__ void embed_tokens_kernel(const int64_t* __restrict__ tok, const float
     }
 }
 
+static int g_split_k = 0;  // split-K planes of the deep N = d products (0 / 1: off, the default: measured 3.59 vs 3.30 ms/step
+                           // with 3 planes on the producer / consumer kernel's 128 x 128 tiles); swat_vit_set_split_k
+
 // dX = dY W with the reduction split over `S` batched launches writing S partial planes (summed by the consumer): the
 // N = d dgrads of the step are ~300 blocks of 64x64 — 1.2 per CU — and 36-48 k-steps deep; splitting K fills the chip.
 static int dgrad_split(const VitDims& D, const unsigned short* dY, int Kred, const unsigned short* W, float* planes, int& S,
@@ -219,7 +222,7 @@ static int dgrad_split(const VitDims& D, const unsigned short* dY, int Kred, con
         // Measured on MI355X (ViT-B/32, B = 32, ms/step): split 4: 4.61, 3: 4.54, 2: 4.55, none: 4.43 — since the lean
         // register-ring kernel took over the deep-K dgrads, the extra fp32 planes cost more than the added workgroups
         // buy.  The plumbing (planes summed inside the LayerNorm backward) stays for shapes with far fewer tiles.
-        constexpr int kDgradSplitMax = 1;
+        const int kDgradSplitMax = g_split_k;
         for (int cand = kDgradSplitMax; cand >= 2; --cand)
             if (Kred % cand == 0 && (Kred / cand) % 64 == 0 && Kred / cand >= 512) { S = cand; break; }
     }
@@ -247,6 +250,36 @@ SWAT_API int swat_linear_wgrad_bias(const void* dY_bf16, const void* X_bf16, flo
         TRY(swat_colsum_bf16(dY_bf16, rows, n_out, ld_dy, dbias, workspace, s));
     }
     return 0;
+}
+
+// The same for up to 4 linear layers in ONE persistent launch over the joint tile list (the weight gradients of a
+// transformer block are independent of each other; each launch pays dispatch, set-up and first-byte latency).  dbias[i]
+// may be null.  Needs rows[i] % 64 == 0 (pad rows zero) for the grouped form; anything else runs layer by layer.
+SWAT_API int swat_linear_wgrad_bias_group(int n, const void* const* dY_bf16, const void* const* X_bf16, float* const* dW,
+                                          float* const* dbias, const int* rows, const int* n_out, const int* n_in,
+                                          const int* ld_dy, const int* ld_x, void* workspace, swat_stream_t stream) {
+    SWAT_REQUIRE(n >= 1 && n <= 4 && dY_bf16 && X_bf16 && dW && dbias && rows && n_out && n_in && ld_dy && ld_x,
+                 "swat_linear_wgrad_bias_group: 1-4 layers, non-null arrays");
+    hipStream_t s = (hipStream_t)stream;
+    bool fused = true;
+    for (int i = 0; i < n; ++i) {
+        SWAT_REQUIRE(dY_bf16[i] && X_bf16[i] && dW[i] && ld_dy[i] % 8 == 0 && ld_x[i] % 8 == 0 && n_in[i] % 4 == 0,
+                     "swat_linear_wgrad_bias_group: layer %d: null pointer, ld not a multiple of 8 or n_in not a multiple of 4", i);
+        fused = fused && rows[i] % 64 == 0 && rows[i] >= 384;
+    }
+    if (!fused || n == 1) {
+        for (int i = 0; i < n; ++i) {
+            if (dbias[i]) TRY(swat_linear_wgrad_bias(dY_bf16[i], X_bf16[i], dW[i], dbias[i], rows[i], n_out[i], n_in[i], ld_dy[i], ld_x[i], workspace, stream));
+            else TRY(gemm_dispatch(L_TN, G(dY_bf16[i], X_bf16[i], dW[i], n_out[i], n_in[i], rows[i], ld_dy[i], ld_x[i], n_in[i], 1), 1, s));
+        }
+        return 0;
+    }
+    GemmArgs a[4];
+    for (int i = 0; i < n; ++i) {
+        a[i] = G(dY_bf16[i], X_bf16[i], dW[i], n_out[i], n_in[i], rows[i], ld_dy[i], ld_x[i], n_in[i], 1);
+        a[i].colsum = dbias[i];
+    }
+    return gemm_group_dispatch(L_TN, a, n, s);
 }
 
 SWAT_API int64_t swat_vit_workspace_bytes(const int32_t* dims) {
@@ -324,7 +357,7 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
         {
             // c_proj: K = mlp is 48 k-steps on only ~300 tiles: split the reduction, the next LayerNorm sums the planes
             pending = 1;
-            constexpr int kFwdSplit = 0;  // re-measured with the current kernels: 2-way split 4.48 vs 4.43 ms/step without
+            const int kFwdSplit = g_split_k;  // 3 planes on the producer / consumer kernel's 128 x 128 tiles (swat_vit_set_split_k)
             if (kFwdSplit && (int64_t)((M + 63) / 64) * ((d + 63) / 64) < 600)
                 for (int cand = kFwdSplit; cand >= 2; --cand)
                     if (D.mlp % cand == 0 && (D.mlp / cand) % 64 == 0 && D.mlp / cand >= 512) { pending = cand; break; }
@@ -379,11 +412,19 @@ struct SideLane {
 };
 static SideLane g_side;
 static int g_overlap = 1;
+static int g_group_wgrad = 0;  // 1: a block's weight-gradient pairs as one persistent grouped launch each (measured equal in
+                               // GEMM time, 3.38 vs 3.30 ms/step: the pair's main loops dominate, not its two launches)
 
 SWAT_API int swat_vit_set_overlap(int mode) {
     SWAT_REQUIRE(mode >= 0 && mode <= 2, "swat_vit_set_overlap: mode must be 0, 1 or 2");
     SWAT_REQUIRE(!g_side.open, "swat_vit_set_overlap: join the open backward first");
     g_overlap = mode;
+    return 0;
+}
+
+SWAT_API int swat_vit_set_split_k(int planes) {
+    SWAT_REQUIRE(planes >= 0 && planes <= 4, "swat_vit_set_split_k: 0-4 planes");
+    swat::g_split_k = planes;
     return 0;
 }
 
@@ -500,8 +541,19 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             }
             // lane: c_proj dW = dx^T g and c_fc dW = dF^T h2, db = colsum(dF) (reductions over Mp rows: pad rows are zero)
             to_lane();
-            TRY(gemm_dispatch(L_TN, G(w.dxb, ga, grads + lo[PRW], d, mlp, D.Mp, d, mlp, mlp, 1), 1, ws));
-            TRY(swat_linear_wgrad_bias(w.dfb, h2, grads + lo[FCW], grads + lo[FCB], D.Mp, mlp, d, mlp, d, w.csws, ws));
+            {
+                const void* dys[2] = {w.dxb, w.dfb};
+                const void* xs2[2] = {ga, h2};
+                float* dws[2] = {grads + lo[PRW], grads + lo[FCW]};
+                float* dbs[2] = {nullptr, grads + lo[FCB]};
+                const int rws[2] = {D.Mp, D.Mp}, nout[2] = {d, mlp}, nin[2] = {mlp, d}, ldy[2] = {d, mlp}, ldx[2] = {mlp, d};
+                if (g_group_wgrad) {
+                    TRY(swat_linear_wgrad_bias_group(2, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                } else {
+                    TRY(swat_linear_wgrad_bias_group(1, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                    TRY(swat_linear_wgrad_bias_group(1, dys + 1, xs2 + 1, dws + 1, dbs + 1, rws + 1, nout + 1, nin + 1, ldy + 1, ldx + 1, w.csws, ws));
+                }
+            }
             lane_done(doneA);  // last lane read of dxb and dfb
             // c_fc: dh2 = dF W
             int S2 = 1;
@@ -518,8 +570,19 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             // lane: out_proj dW = dx1^T a and in_proj dW = dqkv^T h1, db = colsum(dqkv)
             to_lane();
             TRY(swat_layernorm_bwd_finish(w.lnws2, M, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], ws));
-            TRY(gemm_dispatch(L_TN, G(w.dxb2, at, grads + lo[OUTW], d, d, D.Mp, d, d, d, 1), 1, ws));
-            TRY(swat_linear_wgrad_bias(w.dqkv, h1, grads + lo[QKVW], grads + lo[QKVB], D.Mp, 3 * d, d, 3 * d, d, w.csws, ws));
+            {
+                const void* dys[2] = {w.dxb2, w.dqkv};
+                const void* xs2[2] = {at, h1};
+                float* dws[2] = {grads + lo[OUTW], grads + lo[QKVW]};
+                float* dbs[2] = {nullptr, grads + lo[QKVB]};
+                const int rws[2] = {D.Mp, D.Mp}, nout[2] = {d, 3 * d}, nin[2] = {d, d}, ldy[2] = {d, 3 * d}, ldx[2] = {d, d};
+                if (g_group_wgrad) {
+                    TRY(swat_linear_wgrad_bias_group(2, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                } else {
+                    TRY(swat_linear_wgrad_bias_group(1, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                    TRY(swat_linear_wgrad_bias_group(1, dys + 1, xs2 + 1, dws + 1, dbs + 1, rws + 1, nout + 1, nin + 1, ldy + 1, ldx + 1, w.csws, ws));
+                }
+            }
             lane_done(doneB);  // last lane read of dxb2 and dqkv
             // in_proj: dh1 = dqkv W
             int S1 = 1;

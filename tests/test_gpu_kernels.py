@@ -135,6 +135,36 @@ def test_gemm_producer_consumer_wgrad_bias(cfg):
     assert (db - ref).abs().max().item() <= 1e-5 * math.sqrt(M) * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("shapes", [[(1600, 768, 3072, False), (1600, 3072, 768, True)], [(1600, 768, 768, False), (1600, 2304, 768, True)],
+                                    [(1600, 768, 3072, False), (1600, 3072, 768, True), (1600, 768, 768, False), (1600, 2304, 768, True)],
+                                    [(448, 192, 128, True), (448, 96, 104, True), (448, 200, 64, False)], [(100, 72, 96, True), (100, 64, 64, False)]])
+def test_linear_wgrad_bias_group(shapes):
+    """Several layers' weight + bias gradients in one persistent launch over the joint tile list (ragged tile edges,
+    tiles of several products per workgroup); rows % 64 != 0 takes the layer-by-layer path."""
+    import ctypes
+    from swat_amd import _lib
+    lib = _lib.lib()
+    n = len(shapes)
+    dys, xs, dws, dbs = [], [], [], []
+    for i, (M, N, K, bias) in enumerate(shapes):
+        dys.append(rnd(M, N, seed=20 + i, dtype=BF)); xs.append(rnd(M, K, seed=30 + i, dtype=BF))
+        dws.append(torch.full((N, K), float("nan"), device=dev()))
+        dbs.append(torch.full((N,), float("nan"), device=dev()) if bias else None)
+    VP = ctypes.c_void_p * n
+    IA = ctypes.c_int * n
+    ws = torch.empty(lib.swat_colsum_bf16_workspace_bytes(max(s[1] for s in shapes)), dtype=torch.uint8, device=dev())
+    rc = lib.swat_linear_wgrad_bias_group(n, VP(*[t.data_ptr() for t in dys]), VP(*[t.data_ptr() for t in xs]), VP(*[t.data_ptr() for t in dws]),
+                                          VP(*[(t.data_ptr() if t is not None else None) for t in dbs]), IA(*[s[0] for s in shapes]),
+                                          IA(*[s[1] for s in shapes]), IA(*[s[2] for s in shapes]), IA(*[s[1] for s in shapes]),
+                                          IA(*[s[2] for s in shapes]), _lib.ptr(ws), _lib.stream())
+    _lib.check(rc, "swat_linear_wgrad_bias_group")
+    for (M, N, K, bias), dy, x, dw, db in zip(shapes, dys, xs, dws, dbs):
+        close(dw, dy.float().t() @ x.float(), False, M)
+        if bias:
+            ref = dy.float().sum(0)
+            assert (db - ref).abs().max().item() <= 1e-5 * math.sqrt(M) * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
 def test_gemm_epilogues(act):
     from swat_amd import ops

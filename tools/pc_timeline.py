@@ -7,9 +7,10 @@ dev = torch.device("cuda:0"); L = _lib.lib()
 M, d = 1600, 768
 shapes = {"qkv": (ops.NT, M, 3 * d, d), "fc": (ops.NT, M, 4 * d, d), "proj": (ops.NT, M, d, 4 * d), "out": (ops.NT, M, d, d),
           "dproj": (ops.NN, M, 4 * d, d), "dfc": (ops.NN, M, d, 4 * d), "wfc": (ops.TN, 4 * d, d, M), "wqkv": (ops.TN, 3 * d, d, M)}
+PAD = int(os.environ.get('PAD', '0'))
 def run(name, cfg, exp, odt=torch.bfloat16):
     layout, m, n, k = shapes[name]
-    if layout == ops.NT: A = torch.randn(m, k, device=dev).bfloat16(); B = torch.randn(n, k, device=dev).bfloat16(); lda, ldb = k, k
+    if layout == ops.NT: A = torch.randn(m, k + PAD, device=dev).bfloat16(); B = torch.randn(n, k + PAD, device=dev).bfloat16(); lda, ldb = k + PAD, k + PAD
     elif layout == ops.NN: A = torch.randn(m, k, device=dev).bfloat16(); B = torch.randn(k, n, device=dev).bfloat16(); lda, ldb = k, n
     else: A = torch.randn(k, m, device=dev).bfloat16(); B = torch.randn(k, n, device=dev).bfloat16(); lda, ldb = m, n
     C = torch.empty(m, n, device=dev, dtype=odt)
@@ -34,5 +35,5 @@ names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["qkv"]
 cfgs = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [50]
 for nme in names:
     for cfg in cfgs:
-        for exp in (0, 4, 1 | 4, 2 | 4):
+        for exp in [int(e) for e in os.environ.get('EXPS', '0,4,5,6').split(',')]:
             run(nme, cfg, exp)

@@ -12,7 +12,7 @@ shapes = [  # (name, layout, M, N, K, epilogue)  in the kernel's own (rows, cols
     ("wgrad proj", ops.TN, d, 4 * d, M, "f32"), ("wgrad fc", ops.TN, 4 * d, d, M, "f32"), ("wgrad out", ops.TN, d, d, M, "f32"), ("wgrad qkv", ops.TN, 3 * d, d, M, "f32"),
     ("patch", ops.NT, 1568, d, 3072, "f32"),
 ]
-PC_LAYOUTS = {50: (0, 1, 2), 51: (0, 1), 53: (0, 1, 2), 54: (2,), 55: (0, 1, 2), 56: (0, 1, 2), 58: (0, 1)}
+PC_LAYOUTS = {50: (0, 1, 2), 51: (0, 1), 53: (0, 1, 2), 54: (2,), 55: (0, 1, 2), 56: (0, 1, 2), 58: (0, 1), 60: (0, 1), 61: (2,), 62: (0, 1, 2), 63: (0,), 64: (0, 1), 65: (0, 1)}
 cfgs = [14, 30, 43, 33, 50, 51, 53, 54, 55, 56, 58]
 if len(sys.argv) > 1:
     cfgs = [int(c) for c in sys.argv[1].split(",")]

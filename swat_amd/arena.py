@@ -56,12 +56,19 @@ class Arena:
             raise RuntimeError("parameter is not inside this arena")
         return off
 
+    def _version_key(self):
+        """Parameters are attached with `p.data = view`, so each keeps a version counter of its own: an in-place torch
+        write through a Parameter (load_state_dict, p.copy_, WiSE-FT interpolation) bumps p._version and NOT
+        flat._version.  The key covers both routes; kernels that write through raw pointers (AdamW, cast) bump neither
+        and call mark_shadow_fresh() themselves."""
+        return (self.flat._version,) + tuple(p._version for p in self.params)
+
     def refresh_shadow(self, force=False):
-        """bf16 shadow <- fp32 master when the master was modified through torch (in-place ops on a view bump the
-        base tensor's version counter).  The fused AdamW kernel writes both itself and calls mark_shadow_fresh()."""
-        if force or self.flat._version != self._shadow_version:
+        """bf16 shadow <- fp32 master when the master was modified through torch since the shadow was last written."""
+        key = self._version_key()
+        if force or key != self._shadow_version:
             ops.cast_bf16(self.flat, self.shadow)
-            self._shadow_version = self.flat._version
+            self._shadow_version = self._version_key()
 
     def mark_shadow_fresh(self):
-        self._shadow_version = self.flat._version
+        self._shadow_version = self._version_key()

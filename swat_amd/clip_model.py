@@ -288,6 +288,24 @@ class CLIP(nn.Module):
         for blk in self.transformer.resblocks:
             _init_block(blk, tw, 4 * tw)
 
+    def __deepcopy__(self, memo):
+        # the text tower's arena is a cache (swat_amd/text_tower.py keeps it in __dict__): the copy rebuilds its own on
+        # first use instead of dragging a second fp32 + bf16 image of the tower along (ref: copy.deepcopy(model) per
+        # improving epoch, utils/training.py:1534; zeroshot_model / WiSE-FT models, main.py:76-98,555)
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_text_arena":
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        with torch.no_grad():
+            for n_, p in new.named_parameters():
+                if not n_.startswith("visual."):  # the vision tower re-owned its storage in its own __deepcopy__
+                    p.data = p.data.clone()
+        return new
+
     def encode_image(self, images):
         return self.visual(images)
 

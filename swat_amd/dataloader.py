@@ -154,7 +154,10 @@ def extract_train_dataloader(args, model, split, fea_path, preprocess, tokenized
         ds = SyntheticImages(args.synthetic, args.num_classes, seed=1)
     else:
         ds = load_dataset(args.dataset_root, split, build_transform(224, 'train'), tokenized_text_prompts)
-    feats = extract_test_feats(model, DataLoader(ds, batch_size=128, shuffle=False, num_workers=args.num_workers))
+    # like the reference: shuffled batches of bsz with the tail batch dropped BEFORE the features are cached (the stage-2
+    # probing set is len // bsz * bsz samples, and the shuffle draws from the global torch RNG at this point)
+    feats = extract_test_feats(model, DataLoader(ds, batch_size=bsz, pin_memory=True, shuffle=True, num_workers=args.num_workers,
+                                                 drop_last=True))
     os.makedirs(os.path.dirname(fea_path) or '.', exist_ok=True)
     torch.save(feats, fea_path)
     return DataLoader(TensorDataset(data=feats), batch_size=bsz, shuffle=True, drop_last=True, num_workers=0)

@@ -178,14 +178,18 @@ def run_stage2_FSFT(args, logger, loss_logger, model, classifier_head, stage1_be
     args.model_path = stage1_best_model_path
     load_model(args, logger, model, None, classifier_head)
     args.method, args.pre_extracted, args.epochs, args.early_stop, args.freeze_visual = 'finetune', False, 10, False, False
+    args.save_ckpt = False  # ref main.py:486
     args.train_split = args.fewshot_data
     train_loader, val_loader, test_loader = set_dataloaders(args, model, tokenized_text_prompts, preprocess, logger)
-    _prepare(args, model, classifier_head, train_loader, logger)
-    best_model, best_head, best_records, best_logit_scale = train_ce(args, logger, loss_logger, model, classifier_head,
+    logit_scale = _prepare(args, model, classifier_head, train_loader, logger)
+    best_model, best_head, best_records, _ = train_ce(args, logger, loss_logger, model, classifier_head,
                                                                      train_loader, val_loader, test_loader, False)
     test_acc, _, test_cm = validate(args, data_loader=test_loader, model=best_model, classifier_head=best_head, logger=logger,
-                                    loss=args.loss, logit_scale=best_logit_scale, show_confusion_matrix=True, dataset=args.dataset,
+                                    loss=args.loss, logit_scale=args.logit_scale, show_confusion_matrix=True, dataset=args.dataset,
                                     output_dir=args.output_dir, device=args.device, pre_extracted=False)
     logger.info(f"+++++ stage 2 FSFT Test Acc: {round(test_acc, 3)}")
-    path = save_best_model(args, best_records, best_model, best_head, best_logit_scale, test_acc, None, -1, -1, None, None, None, stage=2)
+    # the reference files FSFT under stage 3 (main.py:527-536): stage-2 probing's checkpoint / scores keep their names
+    save_test_scores(calculate_scores(test_cm), test_cm, args.output_dir, 'test', stage=3)
+    path = save_best_model(args, best_records, best_model, best_head, logit_scale, test_acc, None, -1, -1, None, None, None, stage=3)
+    logger.info(f'Stage 2 FSFT Best Model saved to: {path}')
     return test_acc, path

@@ -276,3 +276,48 @@ def test_text_tower_matches_oracle():
         want = ref.encode_text(tok)
     got = model.encode_text(tok.to(dev()))
     assert (got.cpu() - want).abs().max().item() <= 0.02 * want.abs().max().item()
+
+
+def test_bf16_shadow_follows_load_state_dict_into_a_live_arena():
+    """load_state_dict / p.copy_ into a model whose tower already lives in an arena (testing.load_model after _prepare,
+    --skip_stage1, early-stop reload; ref testing.py:76-115, main.py:398-420) must refresh the bf16 shadow the GEMMs read:
+    Parameters are attached with `p.data = view`, so torch bumps the Parameter's own version counter, not the arena's."""
+    ref_a, mine = make_pair(TINY, seed=0)
+    ref_b, fresh = make_pair(TINY, seed=7)
+    x = torch.randn(3, 3, TINY[0], TINY[0], generator=torch.Generator().manual_seed(2)).to(dev())
+    f_a = mine.forward_raw(x)                       # arena + shadow built from weights A
+    mine.load_state_dict(ref_b.state_dict())        # weights B through the Parameters
+    f_b = mine.forward_raw(x)
+    f_fresh = fresh.forward_raw(x)
+    assert (f_a - f_fresh).abs().max().item() > 1e-3, "the two weight sets must differ for the test to mean anything"
+    assert torch.equal(f_b, f_fresh), "stale bf16 shadow: the GEMMs still read the weights from before load_state_dict"
+    with torch.no_grad():                           # a single in-place write through one Parameter
+        p = next(q for n, q in mine.named_parameters() if n.endswith("mlp.c_fc.weight"))
+        p.mul_(1.5)
+        q = next(q for n, q in fresh.named_parameters() if n.endswith("mlp.c_fc.weight"))
+        q.mul_(1.5)
+    a = mine.arena()
+    a.refresh_shadow()
+    o = a.offset_of(p)
+    assert torch.equal(a.shadow[o:o + p.numel()].view(p.shape), p.detach().to(torch.bfloat16))
+    assert torch.equal(mine.forward_raw(x), fresh.forward_raw(x))
+
+
+def test_clip_deepcopy_drops_the_text_arena_cache():
+    """copy.deepcopy(model) (ref main.py:555, utils/training.py:1534) must not drag the text tower's arena along; the copy
+    rebuilds its own on first use and encodes the same."""
+    from swat_amd.clip_model import CLIP
+    torch.manual_seed(3)
+    vis = (32, 16, 64, 1, 1, 32, "quick_gelu")  # head width 64 everywhere
+    m = CLIP("tiny", vision_cfg=vis, text_cfg=(16, 100, 64, 1, 2)).to(dev())
+    tok = torch.randint(1, 99, (4, 16), device=dev())
+    tok[:, -1] = 99
+    t0 = m.encode_text(tok)
+    assert "_text_arena" in m.__dict__
+    c = copy.deepcopy(m)
+    assert "_text_arena" not in c.__dict__
+    assert torch.equal(c.encode_text(tok), t0)
+    with torch.no_grad():
+        c.text_projection.mul_(2.0)
+    assert torch.equal(m.encode_text(tok), t0), "the copy must own its parameters"
+    assert torch.allclose(c.encode_text(tok), 2.0 * t0, rtol=1e-5, atol=1e-6)

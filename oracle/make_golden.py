@@ -6,7 +6,7 @@ golden fixtures under tests/golden/.  Inputs are never stored: every fixture rec
 and the generator below (`synth_*`) is re-run by the tests (numpy's legacy RandomState stream is
 frozen, so the inputs are reproducible bit for bit).
 
-    python oracle/make_golden.py [retrieval] [host] [loop] [vit]
+    python oracle/make_golden.py [retrieval] [host] [loop] [vit] [text]
 
 The reference source never travels: fixtures are plain .npz/.json data.
 """
@@ -334,36 +334,211 @@ def hf_to_oracle_state(hf):
     return out
 
 
-def golden_vit():
-    """G8: the oracle tower vs an INDEPENDENT implementation of the same architecture (HF transformers CLIP)."""
+def _digest(t):
+    """Order-sensitive digest of an activation / gradient tensor: sum, abs-sum, Frobenius norm, and 16 fixed samples."""
+    f = t.detach().double().flatten()
+    idx = torch.linspace(0, f.numel() - 1, 16).long()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item(), f.norm().item()], f[idx].numpy()])
+
+
+VIT_GRAD_NAMES = ["class_embedding", "ln_post.weight", "proj", "transformer.resblocks.0.attn.in_proj_weight",
+                  "transformer.resblocks.1.mlp.c_fc.weight", "conv1.weight"]
+
+
+VIT_CASES = {"b32_quickgelu": ((224, 32, 768, 12, 12, 512), "quick_gelu"), "tiny_gelu": ((56, 14, 128, 2, 2, 64), "gelu")}
+
+
+def vit_case(name):
+    """One G8 case: build the HF tower and the oracle from the same seeded weights, run forward + backward of
+    loss = sum(embeds * w) through both, assert they agree, and return what the fixture stores (from the HF side)."""
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
     from oracle import vit_oracle as vo
+    cfg, act = VIT_CASES[name]
     recs = {}
-    for name, cfg, act in [("b32_quickgelu", (224, 32, 768, 12, 12, 512), "quick_gelu"), ("tiny_gelu", (56, 14, 128, 2, 2, 64), "gelu")]:
-        img, patch, width, layers, heads, embed = cfg
-        torch.manual_seed(0)
-        hf = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=width, intermediate_size=4 * width, num_hidden_layers=layers,
-                                                            num_attention_heads=heads, patch_size=patch, image_size=img,
-                                                            projection_dim=embed, hidden_act=act, layer_norm_eps=1e-5)).eval()
-        with torch.no_grad():
-            for n, p in hf.named_parameters():
-                if n.endswith("bias"):
-                    p.add_(0.02 * torch.randn_like(p))
-        ref = vo.OracleVisionTransformer(img, patch, width, layers, heads, embed, act)
-        ref.load_state_dict(hf_to_oracle_state(hf))
-        x = torch.randn(2, 3, img, img, generator=torch.Generator().manual_seed(1))
-        with torch.no_grad():
-            a = hf(pixel_values=x).image_embeds
-            b = ref(x)
-        err = (a - b).abs().max().item()
-        print(f"[vit/{name}] oracle vs HF max-abs {err:.3e}")
-        assert err < 2e-5
-        recs[name + "_embeds"] = a.numpy()
+    img, patch, width, layers, heads, embed = cfg
+    torch.manual_seed(0)
+    hf = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=width, intermediate_size=4 * width, num_hidden_layers=layers,
+                                                        num_attention_heads=heads, patch_size=patch, image_size=img,
+                                                        projection_dim=embed, hidden_act=act, layer_norm_eps=1e-5)).eval()
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if n.endswith("bias"):
+                p.add_(0.02 * torch.randn_like(p))
+    ref = vo.OracleVisionTransformer(img, patch, width, layers, heads, embed, act)
+    ref.load_state_dict(hf_to_oracle_state(hf))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, img, img, generator=g)
+    w = torch.randn(2, embed, generator=g)
+    out = hf(pixel_values=x, output_hidden_states=True)
+    a = out.image_embeds
+    (a * w).sum().backward()
+    hid = []
+    b = ref(x, hidden=hid)
+    (b * w).sum().backward()
+    err = (a - b).abs().max().item()
+    print(f"[vit/{name}] oracle vs HF embeds max-abs {err:.3e}")
+    assert err < 2e-5
+    recs[name + "_embeds"] = a.detach().numpy()
+    # HF hidden_states[0] is the embedding BEFORE pre_layrnorm; [i >= 1] is the stream after block i
+    for i in range(1, layers + 1):
+        e = (out.hidden_states[i] - hid[i]).abs().max().item()
+        assert e < 5e-4 * max(1.0, hid[i].abs().max().item()), (i, e)
+    recs[name + "_hidden"] = np.stack([_digest(out.hidden_states[i]) for i in range(1, layers + 1)])
+    recs[name + "_hidden_oracle"] = np.stack([_digest(h) for h in hid[1:]])
+    hf_sd = dict(hf.named_parameters())
+    hf_grads = {"class_embedding": hf_sd["vision_model.embeddings.class_embedding"].grad,
+                "ln_post.weight": hf_sd["vision_model.post_layernorm.weight"].grad,
+                "proj": hf_sd["visual_projection.weight"].grad.t(),
+                "transformer.resblocks.0.attn.in_proj_weight": torch.cat([hf_sd[f"vision_model.encoder.layers.0.self_attn.{n}_proj.weight"].grad for n in "qkv"]),
+                "transformer.resblocks.1.mlp.c_fc.weight": hf_sd["vision_model.encoder.layers.1.mlp.fc1.weight"].grad,
+                "conv1.weight": hf_sd["vision_model.embeddings.patch_embedding.weight"].grad}
+    mine = dict(ref.named_parameters())
+    for n in VIT_GRAD_NAMES:
+        r = ((mine[n].grad - hf_grads[n]).norm() / hf_grads[n].norm()).item()
+        print(f"[vit/{name}] grad {n}: oracle vs HF relative L2 {r:.3e}")
+        assert r < 1e-4, (n, r)
+        recs[f"{name}_grad_{n}"] = _digest(hf_grads[n])
+        recs[f"{name}_grad_oracle_{n}"] = _digest(mine[n].grad)
+    return recs
+
+
+def golden_vit():
+    """G8: the oracle tower vs an INDEPENDENT implementation of the same architecture (HF transformers CLIP): embeddings,
+    the residual stream after every block, and the gradients of named parameters of loss = sum(embeds * w)."""
+    recs = {}
+    for name in VIT_CASES:
+        recs.update(vit_case(name))
     np.savez_compressed(os.path.join(GOLD, "vit_hf.npz"), **recs)
     print("wrote tests/golden/vit_hf.npz")
 
 
-SECTIONS.update({"host": golden_host, "loop": golden_loop, "vit": golden_vit})
+def hf_text_to_oracle_state(hf):
+    """HF CLIPTextModelWithProjection -> open_clip CLIP text-tower key names."""
+    sd = hf.state_dict()
+    out = {"token_embedding.weight": sd["text_model.embeddings.token_embedding.weight"],
+           "positional_embedding": sd["text_model.embeddings.position_embedding.weight"],
+           "ln_final.weight": sd["text_model.final_layer_norm.weight"], "ln_final.bias": sd["text_model.final_layer_norm.bias"],
+           "text_projection": sd["text_projection.weight"].t().contiguous()}
+    for i in range(hf.config.num_hidden_layers):
+        h = f"text_model.encoder.layers.{i}."
+        o = f"transformer.resblocks.{i}."
+        out[o + "ln_1.weight"], out[o + "ln_1.bias"] = sd[h + "layer_norm1.weight"], sd[h + "layer_norm1.bias"]
+        out[o + "ln_2.weight"], out[o + "ln_2.bias"] = sd[h + "layer_norm2.weight"], sd[h + "layer_norm2.bias"]
+        out[o + "attn.in_proj_weight"] = torch.cat([sd[h + f"self_attn.{n}_proj.weight"] for n in "qkv"])
+        out[o + "attn.in_proj_bias"] = torch.cat([sd[h + f"self_attn.{n}_proj.bias"] for n in "qkv"])
+        out[o + "attn.out_proj.weight"], out[o + "attn.out_proj.bias"] = sd[h + "self_attn.out_proj.weight"], sd[h + "self_attn.out_proj.bias"]
+        out[o + "mlp.c_fc.weight"], out[o + "mlp.c_fc.bias"] = sd[h + "mlp.fc1.weight"], sd[h + "mlp.fc1.bias"]
+        out[o + "mlp.c_proj.weight"], out[o + "mlp.c_proj.bias"] = sd[h + "mlp.fc2.weight"], sd[h + "mlp.fc2.bias"]
+    return out
+
+
+TEXT_CASES = {  # name: (ctx, vocab, width, heads, layers, embed, act)
+    "b32_text": (77, 49408, 512, 8, 12, 512, "quick_gelu"),
+    "tiny_text": (16, 100, 64, 1, 2, 32, "gelu"),
+}
+
+
+def make_tokens(ctx, vocab, seed):
+    """CLIP-shaped token rows: SOT, a few words, EOT (= the highest id, what argmax pooling keys on), zero padding."""
+    g = torch.Generator().manual_seed(seed)
+    tok = torch.zeros(3, ctx, dtype=torch.long)
+    for r, n in enumerate((3, ctx - 2, 7 if ctx > 9 else 2)):
+        tok[r, 0] = vocab - 2
+        tok[r, 1:1 + n] = torch.randint(1, vocab - 2, (n,), generator=g)
+        tok[r, 1 + n] = vocab - 1
+    return tok
+
+
+def text_case(name):
+    """The oracle's encode_text (causal mask, EOT pooling by argmax, text_projection) vs HF CLIPTextModelWithProjection on
+    the same seeded weights: forward + backward of loss = sum(text_embeds * w)."""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    from oracle import vit_oracle as vo
+    ctx, vocab, width, heads, layers, embed, act = TEXT_CASES[name]
+    recs = {}
+    torch.manual_seed(0)
+    # eos_token_id = 2 selects HF's legacy pooling = argmax over token ids, which is open_clip's rule
+    hf = CLIPTextModelWithProjection(CLIPTextConfig(vocab_size=vocab, hidden_size=width, intermediate_size=4 * width,
+                                                    num_hidden_layers=layers, num_attention_heads=heads,
+                                                    max_position_embeddings=ctx, projection_dim=embed, hidden_act=act,
+                                                    layer_norm_eps=1e-5, eos_token_id=2, bos_token_id=0, pad_token_id=1)).eval()
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if n.endswith("bias"):
+                p.add_(0.02 * torch.randn_like(p))
+    ref = vo.OracleCLIP(vision_cfg=(32, 16, 64, 1, 1, embed, act), text_width=width, text_heads=heads, text_layers=layers,
+                        ctx=ctx, vocab=vocab)
+    missing = ref.load_state_dict(hf_text_to_oracle_state(hf), strict=False)
+    assert all(k.startswith("visual.") or k == "logit_scale" for k in missing.missing_keys), missing
+    tok = make_tokens(ctx, vocab, seed=5)
+    w = torch.randn(3, embed, generator=torch.Generator().manual_seed(6))
+    out = hf(input_ids=tok, output_hidden_states=True)
+    a = out.text_embeds
+    (a * w).sum().backward()
+    hid = []
+    b = ref.encode_text(tok, hidden=hid)
+    (b * w).sum().backward()
+    err = (a - b).abs().max().item()
+    print(f"[text/{name}] oracle vs HF text_embeds max-abs {err:.3e}")
+    assert err < 2e-5
+    for i in range(layers + 1):
+        e = (out.hidden_states[i] - hid[i]).abs().max().item()
+        assert e < 5e-4 * max(1.0, hid[i].abs().max().item()), (i, e)
+    recs[name + "_tokens"] = tok.numpy()
+    recs[name + "_embeds"] = a.detach().numpy()
+    recs[name + "_hidden"] = np.stack([_digest(h) for h in out.hidden_states])
+    recs[name + "_hidden_oracle"] = np.stack([_digest(h) for h in hid])
+    hf_sd = dict(hf.named_parameters())
+    pairs = {"text_projection": hf_sd["text_projection.weight"].grad.t(),
+             "ln_final.weight": hf_sd["text_model.final_layer_norm.weight"].grad,
+             "positional_embedding": hf_sd["text_model.embeddings.position_embedding.weight"].grad,
+             "transformer.resblocks.0.attn.in_proj_weight": torch.cat([hf_sd[f"text_model.encoder.layers.0.self_attn.{n}_proj.weight"].grad for n in "qkv"])}
+    mine = dict(ref.named_parameters())
+    for n, gref in pairs.items():
+        r = ((mine[n].grad - gref).norm() / gref.norm()).item()
+        print(f"[text/{name}] grad {n}: oracle vs HF relative L2 {r:.3e}")
+        assert r < 1e-4, (n, r)
+        recs[f"{name}_grad_{n}"] = _digest(gref)
+        recs[f"{name}_grad_oracle_{n}"] = _digest(mine[n].grad)
+    return recs
+
+
+def golden_text():
+    recs = {}
+    for name in TEXT_CASES:
+        recs.update(text_case(name))
+    np.savez_compressed(os.path.join(GOLD, "text_hf.npz"), **recs)
+    print("wrote tests/golden/text_hf.npz")
+
+
+def export_hf_state(kind, name, path):
+    """Weights of a golden case in the oracle's / open_clip's key names, as a plain tensor dict (tests on the GPU box load
+    them into the HIP towers and compare with what the fixture recorded from the HF side)."""
+    if kind == "vit":
+        from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+        (img, patch, width, layers, heads, embed), act = VIT_CASES[name]
+        torch.manual_seed(0)
+        hf = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=width, intermediate_size=4 * width, num_hidden_layers=layers,
+                                                            num_attention_heads=heads, patch_size=patch, image_size=img,
+                                                            projection_dim=embed, hidden_act=act, layer_norm_eps=1e-5)).eval()
+        conv = hf_to_oracle_state
+    else:
+        from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+        ctx, vocab, width, heads, layers, embed, act = TEXT_CASES[name]
+        torch.manual_seed(0)
+        hf = CLIPTextModelWithProjection(CLIPTextConfig(vocab_size=vocab, hidden_size=width, intermediate_size=4 * width,
+                                                        num_hidden_layers=layers, num_attention_heads=heads,
+                                                        max_position_embeddings=ctx, projection_dim=embed, hidden_act=act,
+                                                        layer_norm_eps=1e-5, eos_token_id=2, bos_token_id=0, pad_token_id=1)).eval()
+        conv = hf_text_to_oracle_state
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if n.endswith("bias"):
+                p.add_(0.02 * torch.randn_like(p))
+    torch.save({k: v.detach().clone() for k, v in conv(hf).items()}, path)
+
+
+SECTIONS.update({"host": golden_host, "loop": golden_loop, "vit": golden_vit, "text": golden_text})
 
 
 if __name__ == "__main__":

@@ -6,6 +6,8 @@ import os
 import re
 from functools import lru_cache
 
+import regex  # \p{L} / \p{N} classes, as open_clip's tokenizer uses
+
 import torch
 
 
@@ -26,7 +28,7 @@ class SimpleTokenizer:
     def __init__(self, bpe_path):
         self.byte_encoder = _bytes_to_unicode()
         merges = gzip.open(bpe_path).read().decode("utf-8").split('\n')[1:49152 - 256 - 2 + 1]
-        merges = [tuple(m.split()) for m in merges]
+        merges = [tuple(m.split()) for m in merges if m.strip()]  # (a shorter, e.g. synthetic, file ends in an empty line)
         vocab = list(self.byte_encoder.values())
         vocab = vocab + [v + '</w>' for v in vocab]
         for m in merges:
@@ -35,8 +37,8 @@ class SimpleTokenizer:
         self.encoder = dict(zip(vocab, range(len(vocab))))
         self.bpe_ranks = dict(zip(merges, range(len(merges))))
         self.cache = {'<start_of_text>': '<start_of_text>', '<end_of_text>': '<end_of_text>'}
-        self.pat = re.compile(r"<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[a-zA-Z]+|[0-9]|[^\sa-zA-Z0-9]+",
-                              re.IGNORECASE)
+        self.pat = regex.compile(r"<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+",
+                                 regex.IGNORECASE)
 
     def bpe(self, token):
         if token in self.cache:
@@ -76,7 +78,7 @@ class SimpleTokenizer:
     def encode(self, text):
         text = re.sub(r'\s+', ' ', html.unescape(html.unescape(text))).strip().lower()
         out = []
-        for token in re.findall(self.pat, text):
+        for token in regex.findall(self.pat, text):
             token = ''.join(self.byte_encoder[b] for b in token.encode('utf-8'))
             out.extend(self.encoder[t] for t in self.bpe(token).split(' '))
         return out

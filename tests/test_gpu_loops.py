@@ -121,3 +121,48 @@ def test_cli_end_to_end_on_synthetic_data(tmp_path, monkeypatch):
     ck = torch.load(out / case / [f for f in files if f.startswith("stage1_model_best")][0], map_location="cpu", weights_only=False)
     assert {"clip", "head", "logit_scale", "test_acc", "best_tau", "wsft_test_acc", "wsft_backbone"} <= set(ck.keys())
     assert "visual.transformer.resblocks.11.mlp.c_proj.weight" in ck["clip"]
+
+
+def test_cli_zeroshot_method_matches_the_oracle(tmp_path, monkeypatch, capsys):
+    """BASELINE config 1 (`--method zeroshot`, ref main.py:219-227, utils/training.py:23-44): the CLI builds the model and the
+    classifier head, validates on the test split through the HIP tower + fused head, prints the 8-field summary and exits.
+    The accuracy and confusion matrix are compared with the fp32 oracle run on the same weights and the same loader."""
+    import sys
+    monkeypatch.chdir(tmp_path)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import main as cli
+    from swat_amd import stages
+    seen = {}
+    real = stages.run_zeroshot
+
+    def spy(args, test_loader, model, logger, loss, logit_scale, classifier_head):
+        seen.update(loader=test_loader, model=model, head=classifier_head, logit_scale=logit_scale)
+        seen["acc"] = real(args, test_loader, model, logger, loss, logit_scale, classifier_head)
+        return seen["acc"]
+
+    monkeypatch.setattr(stages, "run_zeroshot", spy)
+    with pytest.raises(SystemExit) as ex:
+        cli.main(["--synthetic", "48", "--num_classes", "5", "--method", "zeroshot", "--bsz", "16", "--num_workers", "0",
+                  "--log_mode", "file", "--shots", "4", "--folder", str(tmp_path / "out")])
+    assert ex.value.code == 0
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("synthetic,zeroshot,")][-1]
+    parts = line.split(",")
+    assert len(parts) == 8 and float(parts[7]) == round(seen["acc"], 1)
+    # the same pass on the CPU oracle
+    ref = vo.OracleCLIP("ViT-B-32-quickgelu", with_text=False)
+    sd = {k: v.detach().cpu() for k, v in seen["model"].state_dict().items() if k.startswith("visual.") or k == "logit_scale"}
+    ref.load_state_dict(sd)
+    W = seen["head"].linear.weight.detach().cpu()
+    ls = seen["logit_scale"].detach().cpu()
+    right = total = 0
+    flips = 0
+    with torch.no_grad():
+        for inputs, labels, _, _ in seen["loader"]:
+            f = ref.encode_image(inputs.float())
+            logits = (f / f.norm(dim=-1, keepdim=True)) @ W.t() * ls.exp()
+            top2 = logits.topk(2, dim=1).values
+            flips += int(((top2[:, 0] - top2[:, 1]) < 2e-2 * logits.abs().max()).sum())  # near-ties bf16 may flip
+            right += int((logits.argmax(1) == labels).sum())
+            total += labels.numel()
+    want = 100.0 * right / total
+    assert abs(seen["acc"] - want) <= 100.0 * flips / total + 1e-9, (seen["acc"], want, flips)

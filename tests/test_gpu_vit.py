@@ -321,3 +321,67 @@ def test_clip_deepcopy_drops_the_text_arena_cache():
         c.text_projection.mul_(2.0)
     assert torch.equal(m.encode_text(tok), t0), "the copy must own its parameters"
     assert torch.allclose(c.encode_text(tok), 2.0 * t0, rtol=1e-5, atol=1e-6)
+
+
+def _hf_state(kind, name, tmp_path):
+    """The golden case's HF-initialised weights (own process: transformers probes torchvision on import)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / f"{kind}_{name}.pt")
+    code = f"import sys; sys.path.insert(0, {root!r}); from oracle import make_golden as mg; mg.export_hf_state({kind!r}, {name!r}, {path!r})"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return torch.load(path)
+
+
+def _digest(t):
+    f = t.detach().double().flatten().cpu()
+    idx = torch.linspace(0, f.numel() - 1, 16).long()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item(), f.norm().item()], f[idx].numpy()])
+
+
+@pytest.mark.parametrize("name", ["tiny_gelu", "b32_quickgelu"])
+def test_vision_tower_matches_the_hf_golden_forward_and_backward(name, golden_dir, tmp_path):
+    """SURVEY §8(c) G8 on the GPU: the HIP tower with the golden case's weights against what HF CLIP produced — embeddings
+    and the gradients of six named parameters (Frobenius norm + 16 fixed samples each)."""
+    from oracle import make_golden as mg
+    from swat_amd.clip_model import VisionTransformer
+    g = np.load(f"{golden_dir}/vit_hf.npz")
+    (img, patch, width, layers, heads, embed), act = mg.VIT_CASES[name]
+    model = VisionTransformer(img, patch, width, layers, heads, embed, act)
+    model.load_state_dict(_hf_state("vit", name, tmp_path))
+    model.to(dev())
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, img, img, generator=gen)
+    w = torch.randn(2, embed, generator=gen)
+    f = model.forward_raw(x.to(dev()), save=True)
+    want = g[name + "_embeds"]
+    assert np.abs(f.cpu().numpy() - want).max() <= 0.02 * np.abs(want).max()
+    model.backward_raw(w.to(dev()).contiguous())
+    arena = model.arena()
+    params = dict(model.named_parameters())
+    for n in mg.VIT_GRAD_NAMES:
+        p = params[n]
+        o = arena.offset_of(p)
+        got = _digest(arena.grad[o:o + p.numel()].view(p.shape))
+        ref = g[f"{name}_grad_{n}"]
+        assert abs(got[2] - ref[2]) <= 0.03 * ref[2], (n, got[2], ref[2])                       # Frobenius norm
+        assert np.abs(got[3:] - ref[3:]).max() <= 0.06 * max(np.abs(ref[3:]).max(), ref[2] / math.sqrt(p.numel())), n
+
+
+@pytest.mark.parametrize("name", ["tiny_text", "b32_text"])
+def test_text_tower_matches_the_hf_golden(name, golden_dir, tmp_path):
+    """encode_text on the HIP kernels against HF CLIPTextModelWithProjection's text_embeds for the golden case (causal
+    mask, EOT pooling by argmax, text_projection): the text tower's pin to an independent implementation."""
+    from oracle import make_golden as mg
+    from swat_amd.clip_model import CLIP
+    g = np.load(f"{golden_dir}/text_hf.npz")
+    ctx, vocab, width, heads, layers, embed, act = mg.TEXT_CASES[name]
+    model = CLIP(vision_cfg=(32, 16, 64, 1, 1, embed, act), text_cfg=(ctx, vocab, width, heads, layers))
+    missing = model.load_state_dict(_hf_state("text", name, tmp_path), strict=False)
+    assert all(k.startswith("visual.") or k == "logit_scale" for k in missing.missing_keys), missing
+    model.to(dev())
+    tok = torch.from_numpy(g[name + "_tokens"])
+    got = model.encode_text(tok.to(dev())).cpu().numpy()
+    want = g[name + "_embeds"]
+    assert np.abs(got - want).max() <= 0.02 * np.abs(want).max()

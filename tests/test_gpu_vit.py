@@ -1,8 +1,11 @@
 """GPU: the HIP vision tower / fused step (bf16 GEMMs, fp32 accumulate + fp32 residual stream) against the fp32 CPU oracle.
 
-Stated tolerance (BASELINE north_star "logits/loss within a stated fp tolerance"): embeddings within 2% of their
-max-abs, per-tensor gradient relative L2 error < 6%, loss within 2e-2 absolute — bf16 operand rounding (2^-9 relative
-per element) through 12 blocks; an fp32 run of the same graph on the CPU is the reference."""
+Stated tolerance (BASELINE north_star "logits/loss within a stated fp tolerance"): embeddings within 0.7% of their
+max-abs, per-tensor gradient relative L2 error < 1.1%, loss within 2e-2 absolute — bf16 operand rounding (2^-9 relative
+per element) through 12-24 blocks; an fp32 run of the same graph on the CPU is the reference.  The two bounds are 1.5 x
+the worst case measured over TINY / TINY_GELU / ViT-B/32 / ViT-B/16 / ViT-L/14 and two seeds (tools/grad_error.py on
+MI355X: embeddings 0.15-0.41 %, gradients 0.63-0.68 %, the worst tensor is a LayerNorm weight or conv1)."""
+EMB_TOL, GRAD_TOL = 0.007, 0.011
 import copy
 import math
 import types
@@ -56,7 +59,7 @@ def test_forward_backward_match_oracle(cfg, B):
     f_ref = ref(x)
     (f_ref * w).sum().backward()
     f = mine.forward_raw(x.to(dev()), save=True)
-    assert (f.cpu() - f_ref.detach()).abs().max().item() <= 0.02 * f_ref.abs().max().item()
+    assert (f.cpu() - f_ref.detach()).abs().max().item() <= EMB_TOL * f_ref.abs().max().item()
     mine.backward_raw(w.to(dev()).contiguous())
     arena = mine.arena()
     ref_params = dict(ref.named_parameters())
@@ -66,7 +69,7 @@ def test_forward_backward_match_oracle(cfg, B):
         got = arena.grad[o:o + p.numel()].view(p.shape)
         r = rel(got, ref_params[n].grad)
         worst = max(worst, r)
-        assert r < 0.06, f"{n}: relative gradient error {r}"
+        assert r < GRAD_TOL, f"{n}: relative gradient error {r}"
     # inference path (no saved activations) gives the same embedding
     f2 = mine.forward_raw(x.to(dev()), save=False)
     assert torch.equal(f, f2)
@@ -81,7 +84,7 @@ def test_autograd_node_state_dict_deepcopy():
     f.square().sum().backward()
     ref_params = dict(ref.named_parameters())
     for n, p in mine.named_parameters():
-        assert p.grad is not None and rel(p.grad, ref_params[n].grad) < 0.06, n
+        assert p.grad is not None and rel(p.grad, ref_params[n].grad) < GRAD_TOL, n
     # open_clip key names round-trip and deepcopy keeps working (main.py:555, utils/training.py:1515)
     assert set(mine.state_dict().keys()) == set(ref.state_dict().keys())
     twin = copy.deepcopy(mine)
@@ -102,7 +105,7 @@ def test_cutmix_fused_into_patch_embed_matches_paste():
     box = (5, 11, 40, 61)
     f_ref = ref(vo.cutmix_paste(x, perm, box)).detach()
     f = mine.forward_raw(x.to(dev()), perm=perm.to(dev()), box=box)
-    assert (f.cpu() - f_ref).abs().max().item() <= 0.02 * f_ref.abs().max().item()
+    assert (f.cpu() - f_ref).abs().max().item() <= EMB_TOL * f_ref.abs().max().item()
 
 
 def _args(**kw):
@@ -275,7 +278,7 @@ def test_text_tower_matches_oracle():
     with torch.no_grad():
         want = ref.encode_text(tok)
     got = model.encode_text(tok.to(dev()))
-    assert (got.cpu() - want).abs().max().item() <= 0.02 * want.abs().max().item()
+    assert (got.cpu() - want).abs().max().item() <= 0.01 * want.abs().max().item()
 
 
 def test_bf16_shadow_follows_load_state_dict_into_a_live_arena():
@@ -356,7 +359,7 @@ def test_vision_tower_matches_the_hf_golden_forward_and_backward(name, golden_di
     w = torch.randn(2, embed, generator=gen)
     f = model.forward_raw(x.to(dev()), save=True)
     want = g[name + "_embeds"]
-    assert np.abs(f.cpu().numpy() - want).max() <= 0.02 * np.abs(want).max()
+    assert np.abs(f.cpu().numpy() - want).max() <= EMB_TOL * np.abs(want).max()
     model.backward_raw(w.to(dev()).contiguous())
     arena = model.arena()
     params = dict(model.named_parameters())
@@ -365,8 +368,8 @@ def test_vision_tower_matches_the_hf_golden_forward_and_backward(name, golden_di
         o = arena.offset_of(p)
         got = _digest(arena.grad[o:o + p.numel()].view(p.shape))
         ref = g[f"{name}_grad_{n}"]
-        assert abs(got[2] - ref[2]) <= 0.03 * ref[2], (n, got[2], ref[2])                       # Frobenius norm
-        assert np.abs(got[3:] - ref[3:]).max() <= 0.06 * max(np.abs(ref[3:]).max(), ref[2] / math.sqrt(p.numel())), n
+        assert abs(got[2] - ref[2]) <= GRAD_TOL * ref[2], (n, got[2], ref[2])                   # Frobenius norm
+        assert np.abs(got[3:] - ref[3:]).max() <= 0.03 * max(np.abs(ref[3:]).max(), ref[2] / math.sqrt(p.numel())), n  # 16 samples
 
 
 @pytest.mark.parametrize("name", ["tiny_text", "b32_text"])
@@ -384,4 +387,4 @@ def test_text_tower_matches_the_hf_golden(name, golden_dir, tmp_path):
     tok = torch.from_numpy(g[name + "_tokens"])
     got = model.encode_text(tok.to(dev())).cpu().numpy()
     want = g[name + "_embeds"]
-    assert np.abs(got - want).max() <= 0.02 * np.abs(want).max()
+    assert np.abs(got - want).max() <= 0.01 * np.abs(want).max()

@@ -5,10 +5,13 @@
     python main.py --dataset semi-aves --method cutmix --data_source fewshot+retrieved --cls_init REAL-Prompt --shots 4 \
                    --seed 1 --epochs 50 --bsz 32 --retrieval_split T2T500+T2I0.25.txt
     python main.py --synthetic 512 --num_classes 20 --method cutmix --cls_init random --epochs 2 --skip_stage2   # no dataset
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 main.py --dataset semi-aves ...   # data-parallel
+        (one process per GPU over RCCL; the --bsz batch is split over the ranks, --dp_weak gives every rank its own --bsz)
 """
 import copy
 import time
 
+from swat_amd import dp
 from swat_amd.logger import set_logger
 from swat_amd.models import set_classifier, set_model
 from swat_amd.parser import parse_args
@@ -20,6 +23,7 @@ from swat_amd.training import set_training_seed
 def main(argv=None):
     program_start = time.time()
     args = parse_args(argv)
+    dp.init_from_env(args)  # under torch.distributed.run: process group + device BEFORE anything touches the GPU
     if args.synthetic:
         args.dataset, args.cls_init = 'synthetic', 'random'
         args.dataset_root = 'data/synthetic'
@@ -51,7 +55,12 @@ def main(argv=None):
     summary = (f'{args.dataset},{stage1_method},{args.data_source},{args.cls_init},{args.shots},{args.seed},{args.retrieval_split},'
                f'{round(stage1_acc, 1)},{round(wsft_test_acc, 1)},{round(stage2_lp_acc, 1)},{round(stage2_fsft_acc, 1)}')
     logger.info(summary)
-    print(summary)
+    if dp.is_main(args):
+        print(summary)
+    if dp.world(args) > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return summary
 
 

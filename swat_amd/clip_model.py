@@ -210,13 +210,16 @@ class VisionTransformer(nn.Module):
         return ws
 
     # ---- raw passes (no autograd) -----------------------------------------------------------
-    def forward_raw(self, images, save=False, perm=None, box=None):
+    def forward_raw(self, images, save=False, perm=None, box=None, batch=None):
         """encode_image on the current stream.  perm/box: fuse the CutMix paste of ref utils/training.py:1466 into the
-        patch extraction (box = (bbx1, bby1, bbx2, bby2) as rand_bbox returns it)."""
+        patch extraction (box = (bbx1, bby1, bbx2, bby2) as rand_bbox returns it).  batch: number of samples when
+        `images` holds more rows than that (rows >= batch are only read through perm: a data-parallel rank's CutMix
+        partners, swat_amd/dp.py)."""
         if not images.is_cuda:
             raise _lib.SwatHipError("swat_amd vision tower needs GPU tensors (no CPU fallback)")
         images = images.contiguous().float()
-        B = images.shape[0]
+        B = images.shape[0] if batch is None else int(batch)
+        assert B <= images.shape[0]
         assert images.shape[1:] == (3, self.image_size, self.image_size), images.shape
         dims, offs, a = self._tables(B, save)
         a.refresh_shadow()

@@ -119,15 +119,20 @@ def get_dataloader(args, train_split, val_split, test_split, tokenized_text_prom
         tr = load_dataset(args.dataset_root, train_split, build_transform(224, 'train'), tokenized_text_prompts)
         va = load_dataset(args.dataset_root, val_split, preprocess, tokenized_text_prompts)
         te = load_dataset(args.dataset_root, test_split, preprocess, tokenized_text_prompts)
+    # data-parallel, --dp_weak: the shuffled epoch is dealt out by rank (swat_amd/dp.py); otherwise the reference's loader
+    train_kw = dict(shuffle=True)
+    if getattr(args, 'world', 1) > 1 and getattr(args, 'dp_weak', False):
+        from .dp import RankStridedSampler
+        train_kw = dict(sampler=RankStridedSampler(len(tr), args.rank, args.world))
     if getattr(args, 'gpu_transform', False) and not getattr(args, 'synthetic', 0):
         dev = getattr(args, 'device', 'cuda')
         for ds, mode in ((tr, 'train'), (va, 'val'), (te, 'val')):
             ds.transform = DecodeOnly(224, mode)
-        train_loader = DeviceTransformLoader(tr, 224, 'train', dev, batch_size=args.bsz, shuffle=True, drop_last=True, num_workers=args.num_workers)
+        train_loader = DeviceTransformLoader(tr, 224, 'train', dev, batch_size=args.bsz, drop_last=True, num_workers=args.num_workers, **train_kw)
         val_loader = DeviceTransformLoader(va, 224, 'val', dev, batch_size=128, drop_last=False, shuffle=False, num_workers=args.num_workers)
         test_loader = DeviceTransformLoader(te, 224, 'val', dev, batch_size=256, drop_last=False, shuffle=False, num_workers=args.num_workers)
         return train_loader, val_loader, test_loader
-    train_loader = DataLoader(tr, batch_size=args.bsz, pin_memory=True, shuffle=True, drop_last=True, num_workers=args.num_workers)
+    train_loader = DataLoader(tr, batch_size=args.bsz, pin_memory=True, drop_last=True, num_workers=args.num_workers, **train_kw)
     val_loader = DataLoader(va, batch_size=128, drop_last=False, pin_memory=True, shuffle=False, num_workers=args.num_workers)
     test_loader = DataLoader(te, batch_size=256, drop_last=False, pin_memory=True, shuffle=False, num_workers=args.num_workers)
     return train_loader, val_loader, test_loader

@@ -1,0 +1,141 @@
+"""Data-parallel finetuning from the command line: one process per GPU under `torch.distributed.run`,
+`torch.distributed` over RCCL (backend "nccl" on ROCm; gloo for the one-GPU tests), model / optimizer / head replicated.
+
+The reference trains on one GPU (utils/training.py:1452-1489, loaders utils/dataloader.py:107-135).  Two ways to spread it:
+
+* global batch (default): the job's batch stays `--bsz`; every rank iterates the SAME loader (same seed, RNG states
+  re-synchronised from rank 0 at the start of every training loop) and takes rows [rank*b, (rank+1)*b) of each batch.
+  The CutMix scalars (r, lambda, box) and the permutation are the single-process draws; a row's CutMix partner is taken
+  from the rank's own copy of the whole batch.  Per-rank mean losses averaged over ranks = the whole-batch mean, so the
+  optimizer trajectory is the single-process one up to the summation order of the gradient reduction.
+* `--dp_weak`: every rank loads its own `--bsz` rows per step (global batch = world x bsz): the sampler deals the
+  shuffled index list out by rank (same permutation on every rank), CutMix permutes inside the rank's batch.
+
+Validation, logging, checkpoints, WiSE-FT / tau-normalisation and stage-2 probing run on rank 0 only; the metrics that
+steer the loop (val / test accuracy) are broadcast so every rank takes the same branches.  The per-stage gradient
+all-reduce itself lives in swat_amd/step.py (FusedTrainStep, trailing mode)."""
+import os
+import pickle
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import Sampler
+
+
+def init_from_env(args):
+    """Call FIRST in main(): creates the process group before anything touches the GPU (a launcher must not start other
+    programs from a process that has initialised the device, and RCCL wants its device bound at creation)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    args.rank, args.world, args.local_rank = 0, 1, 0
+    if world <= 1:
+        return args
+    rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    ngpu = torch.cuda.device_count()           # counting devices does not initialise the GPU
+    index = local % max(ngpu, 1)               # several ranks per GPU only in the one-GPU tests (gloo)
+    backend = getattr(args, 'dist_backend', 'nccl')
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', index))
+    else:
+        dist.init_process_group(backend)
+    if ngpu:
+        torch.cuda.set_device(index)
+    args.rank, args.world, args.local_rank = rank, world, local
+    return args
+
+
+def world(args):
+    return getattr(args, 'world', 1)
+
+
+def is_main(args):
+    return getattr(args, 'rank', 0) == 0
+
+
+def barrier(args):
+    if world(args) > 1:
+        dist.barrier()
+
+
+def bcast_object(args, obj):
+    """rank 0's (picklable) object on every rank."""
+    if world(args) == 1:
+        return obj
+    box = [obj if is_main(args) else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def sync_rng(args):
+    """Every rank continues from rank 0's torch / numpy / python RNG states: the loaders' shuffles and the CutMix draws
+    stay identical across ranks even after rank 0 alone ran RNG-consuming code (stage-2 probing's shuffled extraction)."""
+    if world(args) == 1:
+        return
+    state = (torch.get_rng_state(), np.random.get_state(), random.getstate(),
+             torch.cuda.get_rng_state() if torch.cuda.is_available() else None)
+    state = bcast_object(args, state)
+    if not is_main(args):
+        torch.set_rng_state(state[0])
+        np.random.set_state(state[1])
+        random.setstate(state[2])
+        if state[3] is not None:
+            torch.cuda.set_rng_state(state[3])
+
+
+def mean_over_ranks(args, value):
+    """Average of a host scalar over ranks (the epoch's training loss for loss.csv: one collective per epoch)."""
+    if world(args) == 1:
+        return value
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.item() / world(args)
+
+
+def shard_batch(images, labels, perm, rank, nranks):
+    """Rows [rank*b, (rank+1)*b) of a global batch -> (images_local, y_a, y_b, perm_local, b).
+
+    With a CutMix permutation over the GLOBAL batch the partners' images are appended behind the rank's own rows and
+    perm_local points at them, so the fused paste (csrc: swat_patchify_cutmix) reads exactly the pixels the
+    single-process step reads; `b` is the number of samples of the step (images_local may hold 2b rows)."""
+    B = images.shape[0]
+    if B % nranks:
+        raise ValueError(f"global batch {B} is not a multiple of the world size {nranks}")
+    b = B // nranks
+    lo, hi = rank * b, (rank + 1) * b
+    if perm is None:
+        return images[lo:hi].contiguous(), labels[lo:hi], labels[lo:hi], None, b
+    partner = perm[lo:hi]
+    local = torch.cat([images[lo:hi], images.index_select(0, partner.to(images.device))]).contiguous()
+    perm_local = torch.arange(b, 2 * b, device=perm.device, dtype=perm.dtype)
+    return local, labels[lo:hi], labels.index_select(0, partner.to(labels.device)), perm_local, b
+
+
+class RankStridedSampler(Sampler):
+    """--dp_weak: the reference's shuffle (torch.randperm from the global RNG, drawn on EVERY rank so the streams stay in
+    step), dealt out by rank: rank r gets elements r, r + W, r + 2W, ... of the permutation (a partition of the epoch)."""
+
+    def __init__(self, n, rank, nranks, shuffle=True):
+        self.n, self.rank, self.nranks, self.shuffle = n, rank, nranks, shuffle
+
+    def __len__(self):
+        return self.n // self.nranks
+
+    def __iter__(self):
+        order = torch.randperm(self.n).tolist() if self.shuffle else list(range(self.n))
+        return iter(order[self.rank:self.n // self.nranks * self.nranks:self.nranks])
+
+
+class _NullLog:
+    """loss.csv stand-in on ranks > 0."""
+
+    def write(self, *_):
+        pass
+
+    def flush(self):
+        pass
+
+    def close(self):
+        pass

@@ -29,6 +29,15 @@ def set_logger(args):
     ckpt_path = f'{output_dir}/model_ckpts'
     os.makedirs(ckpt_path, exist_ok=True)
     os.makedirs(f'{args.dataset_root}/pre_extracted/', exist_ok=True)
+    if getattr(args, 'rank', 0) != 0:  # data-parallel ranks > 0: same directories, no files (swat_amd/dp.py)
+        from .dp import _NullLog
+        logger = logging.getLogger('')
+        for h in list(logger.handlers):
+            logger.removeHandler(h)
+        logger.addHandler(logging.NullHandler())
+        args.device = "cuda" if torch.cuda.is_available() else "cpu"
+        args.output_dir, args.ckpt_path = output_dir, ckpt_path
+        return logger, _NullLog()
     logger = get_logger(output_dir, 'main', args.log_mode)
     logger.info('logging started')
     logger.info(f'case_name: {case_name}')

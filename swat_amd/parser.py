@@ -86,6 +86,11 @@ def build_parser():
     p.add_argument('--save_freq', type=int, default=10)
     p.add_argument('--utrain', type=str, default=None)
     # build-only additions
+    p.add_argument('--dist_backend', type=str, default='nccl', choices=['nccl', 'gloo'],
+                   help="torch.distributed backend when launched under torch.distributed.run (nccl = RCCL on ROCm)")
+    p.add_argument('--dp_weak', action='store_true',
+                   help='data-parallel runs: every rank loads its own --bsz rows (global batch = world x bsz) instead of '
+                        'splitting the --bsz batch')
     p.add_argument('--synthetic', type=int, default=0, help='train on N seeded synthetic images (no dataset needed)')
     p.add_argument('--num_classes', type=int, default=200, help='classes of the synthetic dataset')
     p.add_argument('--config', type=str, default='config.yml')

@@ -11,6 +11,7 @@ import time
 import numpy as np
 import torch
 
+from . import dp
 from .dataloader import extract_dataloader, extract_train_dataloader, set_dataloaders
 from .losses import set_loss
 from .models import MyLinear, save_best_model, save_test_scores
@@ -97,11 +98,13 @@ def run_stage1_finetuning(args, logger, loss_logger, model, classifier_head, zer
         load_model(args, logger, model, test_loader, classifier_head)
     if args.check_zeroshot or args.method == 'zeroshot':
         logger.info("Check Zero-shot Acc ......")
-        zs_test_acc = run_zeroshot(args, test_loader, model, logger, args.loss, logit_scale, classifier_head)
+        zs_test_acc = run_zeroshot(args, test_loader, model, logger, args.loss, logit_scale, classifier_head) if dp.is_main(args) else -1
+        zs_test_acc = dp.bcast_object(args, zs_test_acc)
     if args.zeroshot_only or args.method == 'zeroshot':
         summary = f'{args.dataset},{stage1_method},{args.data_source},{args.cls_init},{args.shots},{args.seed},{args.retrieval_split},{round(zs_test_acc, 1)}'
         logger.info(summary)
-        print(summary)
+        if dp.is_main(args):
+            print(summary)
         raise SystemExit(0)
     reload_model = bool(args.model_path)
     if args.skip_stage1:
@@ -118,6 +121,9 @@ def run_stage1_finetuning(args, logger, loss_logger, model, classifier_head, zer
         raise NotImplementedError(f"Method {args.method}: out of scope of the MI355X hot path (SURVEY §2 row 3b); "
                                   "finetune / cutmix / probing / zeroshot are implemented.")
     best_model, best_head, best_records, best_logit_scale = out
+    if not dp.is_main(args):  # data-parallel ranks > 0: the evaluation fan-out and the checkpoint are rank 0's
+        test_acc, best_model_path, wsft_test_acc = dp.bcast_object(args, None)
+        return test_acc, best_model_path, test_loader_copy, wsft_test_acc
     wsft_backbone, wsft_head, wsft_test_acc = None, None, -1
     if not args.no_wsft:
         wsft_backbone, wsft_head, wsft_test_acc = run_wsft_alpha(args, best_model, best_head, val_loader, test_loader,
@@ -140,12 +146,15 @@ def run_stage1_finetuning(args, logger, loss_logger, model, classifier_head, zer
     best_model_path = save_best_model(args, best_records, best_model, best_head, best_logit_scale, test_acc, best_tau,
                                       best_tau_test_acc, wsft_test_acc, best_tau_head, wsft_backbone, wsft_head, stage=1)
     logger.info(f'Stage 1 Best Model saved to: {best_model_path}')
+    dp.bcast_object(args, (test_acc, best_model_path, wsft_test_acc))  # releases the other ranks once the file exists
     return test_acc, best_model_path, test_loader_copy, wsft_test_acc
 
 
 def run_stage2_probing(args, logger, loss_logger, model, classifier_head, stage1_best_model_path, test_loader,
                        tokenized_text_prompts, preprocess):
     """Classifier retraining on few-shot features of the stage-1 backbone (ref main.py:402-474)."""
+    if not dp.is_main(args):  # pre-extracted features, a head-only step: rank 0 alone; the others wait for its result
+        return dp.bcast_object(args, None)
     logger.info("Run stage 2 classifier retraining ......")
     args.model_path = stage1_best_model_path
     load_model(args, logger, model, None, classifier_head)
@@ -168,6 +177,7 @@ def run_stage2_probing(args, logger, loss_logger, model, classifier_head, stage1
     for suffix in ('_fewshot_features_new.pth', '_test_features_new.pth'):
         if os.path.exists(root + suffix):
             os.remove(root + suffix)
+    dp.bcast_object(args, (test_acc, path))
     return test_acc, path
 
 
@@ -183,7 +193,9 @@ def run_stage2_FSFT(args, logger, loss_logger, model, classifier_head, stage1_be
     train_loader, val_loader, test_loader = set_dataloaders(args, model, tokenized_text_prompts, preprocess, logger)
     logit_scale = _prepare(args, model, classifier_head, train_loader, logger)
     best_model, best_head, best_records, _ = train_ce(args, logger, loss_logger, model, classifier_head,
-                                                                     train_loader, val_loader, test_loader, False)
+                                                      train_loader, val_loader, test_loader, False)
+    if not dp.is_main(args):
+        return dp.bcast_object(args, None)
     test_acc, _, test_cm = validate(args, data_loader=test_loader, model=best_model, classifier_head=best_head, logger=logger,
                                     loss=args.loss, logit_scale=args.logit_scale, show_confusion_matrix=True, dataset=args.dataset,
                                     output_dir=args.output_dir, device=args.device, pre_extracted=False)
@@ -192,4 +204,5 @@ def run_stage2_FSFT(args, logger, loss_logger, model, classifier_head, stage1_be
     save_test_scores(calculate_scores(test_cm), test_cm, args.output_dir, 'test', stage=3)
     path = save_best_model(args, best_records, best_model, best_head, logit_scale, test_acc, None, -1, -1, None, None, None, stage=3)
     logger.info(f'Stage 2 FSFT Best Model saved to: {path}')
+    dp.bcast_object(args, (test_acc, path))
     return test_acc, path

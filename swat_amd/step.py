@@ -66,17 +66,18 @@ class FusedTrainStep:
             self._ws[B] = ws
         return ws
 
-    def __call__(self, images, target_a, target_b=None, lam=1.0, perm=None, box=None):
-        """images fp32 [B,3,H,W] (GPU), targets int64 [B].  Returns the device scalar holding this step's loss."""
+    def __call__(self, images, target_a, target_b=None, lam=1.0, perm=None, box=None, batch=None):
+        """images fp32 [B,3,H,W] (GPU), targets int64 [B].  Returns the device scalar holding this step's loss.
+        batch: number of samples when `images` carries CutMix partner rows behind them (swat_amd/dp.py:shard_batch)."""
         a = self.arena
-        B = images.shape[0]
+        B = images.shape[0] if batch is None else int(batch)
         dev = images.device
         if target_b is None:
             target_b = target_a
         ws, dfeats = self._head_ws(B, dev)
         red = SliceReducer()
         if self.train_visual:
-            feats = self.visual.forward_raw(images, save=True, perm=perm, box=box)
+            feats = self.visual.forward_raw(images, save=True, perm=perm, box=box, batch=B)
         else:
             feats = images.float().contiguous()  # pre-extracted, already normalised features (train_probing)
         g = a.grad

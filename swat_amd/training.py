@@ -17,6 +17,7 @@ import random
 import numpy as np
 import torch
 
+from . import dp
 from .step import FusedTrainStep
 from .testing import validate, calculate_scores, load_model
 from .models import save_model_ckpt
@@ -78,7 +79,10 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
     logit_scale = args.logit_scale
     optimizer = args.optimizer
     scheduler = args.scheduler
-    step = FusedTrainStep(model, classifier_head, logit_scale, optimizer)
+    nranks, rank = dp.world(args), getattr(args, 'rank', 0)
+    split_batch = nranks > 1 and not getattr(args, 'dp_weak', False)  # every rank sees the whole --bsz batch, takes its rows
+    dp.sync_rng(args)  # identical shuffles and CutMix draws on every rank from here on
+    step = FusedTrainStep(model, classifier_head, logit_scale, optimizer, world_size=nranks)
 
     val_loss = -1
     val_acc = -1
@@ -102,19 +106,27 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
                 lam, rand_index, box = 1.0, None, None
             if rand_index is not None:
                 rand_index = rand_index.to(args.device)
+            if split_batch:
+                loc, ya, yb, perm_l, b = dp.shard_batch(images, labels, rand_index, rank, nranks)
+                step(loc, ya, yb, lam, perm=perm_l, box=box, batch=b)
+            elif rand_index is not None:
                 step(images, labels, labels[rand_index], lam, perm=rand_index, box=box)
             else:
                 step(images, labels, labels, 1.0)
             scheduler.step()  # update learning rate for each iteration
 
         train_loss_sum = step.pop_loss_sum()  # the only host sync of the epoch
+        train_loss_sum = dp.mean_over_ranks(args, train_loss_sum)  # data-parallel: one scalar all-reduce per epoch
 
         if args.early_stop or epoch == args.epochs:
-            val_acc, val_loss, confusion_matrix = validate(args, data_loader=val_loader, model=model, logger=logger,
-                                                           loss=args.loss, logit_scale=logit_scale,
-                                                           classifier_head=classifier_head, show_confusion_matrix=True,
-                                                           dataset=args.dataset, output_dir=args.output_dir,
-                                                           device=args.device, pre_extracted=args.pre_extracted)
+            if dp.is_main(args):
+                val_acc, val_loss, confusion_matrix = validate(args, data_loader=val_loader, model=model, logger=logger,
+                                                               loss=args.loss, logit_scale=logit_scale,
+                                                               classifier_head=classifier_head, show_confusion_matrix=True,
+                                                               dataset=args.dataset, output_dir=args.output_dir,
+                                                               device=args.device, pre_extracted=args.pre_extracted)
+            # ranks > 0 take the same branches on rank 0's numbers (the models are replicas)
+            val_acc, val_loss, confusion_matrix = dp.bcast_object(args, (val_acc, val_loss, confusion_matrix if dp.is_main(args) else None))
             scores = calculate_scores(confusion_matrix)
 
         if (args.early_stop or epoch == args.epochs) and val_acc >= best_val_acc:
@@ -134,9 +146,11 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
             best_records['best_confusion_matrix'] = best_confusion_matrix
 
         if args.early_stop or epoch == args.epochs:
-            test_acc, _, _ = validate(args, data_loader=test_loader, model=model, logger=logger, loss=args.loss,
-                                      logit_scale=logit_scale, classifier_head=classifier_head, dataset=args.dataset,
-                                      output_dir=args.output_dir, device=args.device, pre_extracted=args.pre_extracted)
+            if dp.is_main(args):
+                test_acc, _, _ = validate(args, data_loader=test_loader, model=model, logger=logger, loss=args.loss,
+                                          logit_scale=logit_scale, classifier_head=classifier_head, dataset=args.dataset,
+                                          output_dir=args.output_dir, device=args.device, pre_extracted=args.pre_extracted)
+            test_acc = dp.bcast_object(args, test_acc)
 
         train_loss_avg = train_loss_sum / len(train_loader)
         loss_logger.write(f'{epoch},{num_iter},{round(train_loss_avg, 6)},{round(val_loss, 6)},{round(val_acc, 6)},{round(test_acc, 6)}\n')
@@ -146,7 +160,7 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
         if logger.handlers:
             logger.handlers[0].flush()
 
-        if args.save_ckpt and (num_iter % args.save_freq == 0 or epoch == args.epochs):
+        if args.save_ckpt and dp.is_main(args) and (num_iter % args.save_freq == 0 or epoch == args.epochs):
             model_path = save_model_ckpt(args, best_records, model, classifier_head, optimizer, scheduler, logit_scale,
                                          val_acc, epoch, num_iter)
             logger.info(f'Model ckpt saved to: {model_path}')
@@ -191,7 +205,7 @@ def train_probing(args, logger, loss_logger, model, classifier_head, tokenized_t
     optimizer, scheduler = args.optimizer, args.scheduler
     model.eval()
     classifier_head.train()
-    step = FusedTrainStep(model, classifier_head, logit_scale, optimizer)
+    step = FusedTrainStep(model, classifier_head, logit_scale, optimizer, world_size=1)  # rank 0 alone (swat_amd/dp.py)
     best_records = {}
     best_val_acc = -1
     best_model, best_head, best_logit_scale = model, classifier_head, logit_scale

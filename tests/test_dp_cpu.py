@@ -1,0 +1,117 @@
+"""CPU, world_size 2, gloo: the host logic of the command line's data-parallel mode (swat_amd/dp.py) — RNG re-sync,
+global-batch sharding with CutMix partners, the rank-strided sampler, rank-0 broadcasts and the per-epoch loss average."""
+import os
+import random
+import socket
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _paste(images, perm, box):
+    """ref utils/training.py:1466 — inputs[:, :, x1:x2, y1:y2] = inputs[perm, :, x1:x2, y1:y2] through a gathered copy."""
+    x1, y1, x2, y2 = box
+    out = images.clone()
+    out[:, :, x1:x2, y1:y2] = images[perm][:, :, x1:x2, y1:y2]
+    return out
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    try:
+        from swat_amd import dp
+        from swat_amd.training import cutmix_draw
+        args = types.SimpleNamespace(dist_backend="gloo", cutmix_beta=1.0, mix_prob=0.5)
+        dp.init_from_env(args)
+        assert (args.rank, args.world) == (rank, world) and dp.is_main(args) == (rank == 0)
+        # ranks start from different RNG states (rank 0 alone ran RNG-consuming code); sync_rng puts them in step again
+        torch.manual_seed(100 + rank); np.random.seed(200 + rank); random.seed(300 + rank)
+        dp.sync_rng(args)
+        draws = (torch.rand(3).tolist(), np.random.rand(3).tolist(), random.random())
+        assert dp.bcast_object(args, draws) == draws, "RNG streams differ after sync_rng"
+        # global batch: identical draws on every rank, rows split, partners carried along -> the union equals the
+        # single-process CutMix batch
+        B, b = 8, 4
+        g = torch.Generator().manual_seed(5)
+        images, labels = torch.randn(B, 3, 16, 16, generator=g), torch.randint(0, 10, (B,), generator=g)
+        seen_mix = False
+        for it in range(6):
+            lam, perm, box = cutmix_draw(args, images.size())
+            loc, ya, yb, perm_l, nb = dp.shard_batch(images, labels, perm, rank, world)
+            assert nb == b and torch.equal(ya, labels[rank * b:(rank + 1) * b])
+            if perm is None:
+                assert perm_l is None and loc.shape[0] == b and torch.equal(yb, ya)
+                mine = loc
+            else:
+                seen_mix = True
+                assert loc.shape[0] == 2 * b and torch.equal(yb, labels[perm][rank * b:(rank + 1) * b])
+                mine = _paste(loc, torch.cat([perm_l, torch.arange(b, 2 * b)]), box)[:b]  # what the fused paste computes
+            whole = _paste(images, perm, box) if perm is not None else images
+            assert torch.equal(mine, whole[rank * b:(rank + 1) * b])
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            assert torch.equal(torch.cat(gathered), whole)
+        assert seen_mix
+        # --dp_weak: the shuffled epoch is a partition over ranks, drawn from RNG streams that stay in step
+        dp.sync_rng(args)
+        smp = dp.RankStridedSampler(21, rank, world)
+        idx = list(iter(smp))
+        assert len(idx) == len(smp) == 10
+        allidx = [None] * world
+        dist.all_gather_object(allidx, idx)
+        assert len(set(allidx[0]) | set(allidx[1])) == 20 and not set(allidx[0]) & set(allidx[1])
+        nxt = torch.rand(1).item()
+        assert dp.bcast_object(args, nxt) == nxt  # the sampler consumed the same amount of the stream on every rank
+        # one scalar all-reduce per epoch for loss.csv
+        assert abs(dp.mean_over_ranks(args, 1.0 + rank) - 1.5) < 1e-12
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_world2_gloo_data_parallel_host_logic():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_single_process_is_untouched():
+    from swat_amd import dp
+    args = types.SimpleNamespace()
+    os.environ.pop("WORLD_SIZE", None)
+    dp.init_from_env(args)
+    assert (args.rank, args.world) == (0, 1) and dp.is_main(args)
+    assert dp.bcast_object(args, {"a": 1}) == {"a": 1} and dp.mean_over_ranks(args, 2.5) == 2.5
+    dp.sync_rng(args)
+    x = torch.randn(4, 3, 8, 8)
+    y = torch.arange(4)
+    loc, ya, yb, pl, b = dp.shard_batch(x, y, None, 0, 1)
+    assert b == 4 and torch.equal(loc, x) and pl is None

@@ -146,3 +146,62 @@ def test_bench_two_rank_plumbing_prints_one_json_line():
     assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"] + 0.1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_cli(tmp, tag, nproc):
+    """main.py on synthetic data, one process or `torch.distributed.run` with two ranks on the one GPU (gloo)."""
+    import subprocess
+    out = tmp / tag
+    flags = ["--synthetic", "64", "--num_classes", "5", "--method", "cutmix", "--epochs", "2", "--bsz", "16", "--num_workers", "0",
+             "--log_mode", "file", "--shots", "4", "--skip_stage2", "--no_wsft", "--no_tau", "--folder", str(out)]
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "main.py")] + flags
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "main.py"), "--dist_backend", "gloo"] + flags
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=str(tmp), env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import glob
+    csvs = glob.glob(str(out / "**" / "loss.csv"), recursive=True)
+    assert len(csvs) == 1
+    case = os.path.dirname(csvs[0])
+    rows = [l.strip().split(",") for l in open(csvs[0]).read().strip().splitlines()[1:]]
+    ck = [f for f in os.listdir(case) if f.startswith("stage1_model_best")]
+    assert len(ck) == 1
+    summary = [l for l in r.stdout.splitlines() if l.startswith("synthetic,cutmix,")]
+    return rows, torch.load(os.path.join(case, ck[0]), map_location="cpu", weights_only=False), summary
+
+
+def test_cli_under_torchrun_two_ranks_equals_the_single_process_run(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 main.py ...` (global batch --bsz split over the ranks, CutMix
+    partners carried along, per-stage gradient all-reduce, rank-0 validation / log / checkpoint) lands on the loss.csv and
+    the checkpoint of the one-process run on the whole batch (ref loop utils/training.py:1452-1489)."""
+    rows1, ck1, s1 = _run_cli(tmp_path, "one", 1)
+    rows2, ck2, s2 = _run_cli(tmp_path, "two", 2)
+    assert len(s1) == 1 and len(s2) == 1, "exactly one summary line (rank 0 prints)"
+    assert len(rows1) == len(rows2) == 2
+    for a, b in zip(rows1, rows2):
+        assert a[:2] == b[:2]                                           # epoch, iteration
+        assert abs(float(a[2]) - float(b[2])) < 2e-3, (a, b)            # training loss (mean over the global batch)
+        assert abs(float(a[4]) - float(b[4])) <= 100.0 / 16 + 1e-6      # val acc: a near-tie may flip one of 16+ samples
+    h1, h2 = ck1["head"]["linear.weight"], ck2["head"]["linear.weight"]
+    assert (h1 - h2).norm() / h1.norm() < 2e-3
+    worst, worst_key = 0.0, None
+    for k, v in ck1["clip"].items():
+        if k.startswith("visual.") and v.dtype.is_floating_point:
+            # relative to the tensor's scale, with a floor: zero-initialised biases have moved by ~steps x lr_backbone = 1e-5,
+            # where Adam turns rounding-level gradient differences into whole update steps
+            err = ((v - ck2["clip"][k]).abs().max() / max(v.abs().max().item(), 1e-2)).item()
+            if err > worst:
+                worst, worst_key = err, k
+    assert worst < 2e-3, (worst_key, worst)
+    assert set(ck1.keys()) == set(ck2.keys())

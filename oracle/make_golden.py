@@ -6,7 +6,7 @@ golden fixtures under tests/golden/.  Inputs are never stored: every fixture rec
 and the generator below (`synth_*`) is re-run by the tests (numpy's legacy RandomState stream is
 frozen, so the inputs are reproducible bit for bit).
 
-    python oracle/make_golden.py [retrieval] [host] [loop] [vit] [text]
+    python oracle/make_golden.py [retrieval] [host] [loop] [vit] [text] [stages]
 
 The reference source never travels: fixtures are plain .npz/.json data.
 """
@@ -151,7 +151,63 @@ def golden_retrieval():
         print(f"wrote tests/golden/retrieval_{kind}.npz")
 
 
-SECTIONS = {"retrieval": golden_retrieval}
+def golden_retrieval_cli():
+    """B7 / B8 driver level: the reference's own sampling() (sample_retrieval.py:1471-1670) on a mined.pth FILE, with and
+    without --image_dedup, and zeroshot_clip_img_filter (:278-329) on the same index; records <prefix>.txt,
+    <prefix>_num_imgs_sampled.json and the filtered-path sets."""
+    from oracle import ref_shims
+    sr = ref_shims.import_retrieval()
+    import utils.models as rm
+    payload = {}
+    for kind in ("float", "grid"):
+        spec = synth.RETRIEVAL_CASES[kind]
+        case = synth.retrieval_case(**spec)
+        root = tempfile.mkdtemp()
+        os.makedirs(f"{root}/synthetic")
+        torch.save({"image_features": torch.from_numpy(case["img"]), "caption_features": torch.from_numpy(case["cap"]),
+                    "labels": torch.from_numpy(case["labels"]), "filepath": case["paths"]},
+                   f"{root}/synthetic/synthetic_vitb32_openclip_laion400m_mined.pth")
+        cap_map = defaultdict(dict)
+        for p in case["paths"]:
+            cap_map[p.split("/")[-2]][p.split("/")[-1].split(".")[0]] = "caption"
+        with open(f"{root}/cap.map", "wb") as f:
+            pickle.dump(dict(cap_map), f)
+        sr.CAPTION_MAP_DICT["synthetic"] = f"{root}/cap.map"
+        sr.prompt_tensors_dict = {"alternates": {str(c): {"mean": torch.from_numpy(case["queries"][i])}
+                                                 for i, c in enumerate(case["class_ids"])}}
+        sr.logger = _logger()
+        sr.shutil = types.SimpleNamespace(copy=lambda *a, **k: None)
+        sr.device = "cpu"
+        for method, tag in (("T2T-rank-T2I-tshd", "t2t_t2i"), ("T2T-rank", "t2t"), ("T2I-rank", "t2i")):
+            for dedup in (False, True):
+                out = tempfile.mkdtemp()
+                args = types.SimpleNamespace(dataset="synthetic", model_cfg="vitb32_openclip_laion400m", prefix="golden",
+                                             output_folder=out, sampling_method=method, num_samples=spec["k"], image_dedup=dedup,
+                                             zeroshot_img_filter=False, prompt_name="alternates", sampling_threshold=0.0)
+                path, ct = sr.sampling(args, sr.logger, None, None, None, f"{root}/synthetic")
+                key = f"{kind}_{tag}_{'dedup' if dedup else 'plain'}"
+                payload[key + "_txt"] = open(path).read()
+                payload[key + "_counts"] = open(f"{out}/golden_num_imgs_sampled.json").read()
+                payload[key + "_ct"] = np.int64(ct)
+                print(f"[retrieval_cli/{key}] sample_ct {ct}")
+        # zero-shot filter: head = class prompt means; positions-vs-file-id matching rule of the reference
+        pre = sr.transform_extracted_fea(torch.load(f"{root}/synthetic/synthetic_vitb32_openclip_laion400m_mined.pth"))
+        C = max(case["class_ids"]) + 1
+        W = torch.zeros(C, case["queries"].shape[1])
+        for i, c in enumerate(case["class_ids"]):
+            W[c] = torch.from_numpy(case["queries"][i])
+        head = rm.MyLinear(weights=W)
+        os.makedirs(f"{root}/folders", exist_ok=True)
+        for c in case["class_ids"]:
+            os.makedirs(f"{root}/folders/{c}", exist_ok=True)
+        filt = sr.zeroshot_clip_img_filter(None, None, f"{root}/folders", pre_extracted_feats=pre, head=head)
+        payload[f"{kind}_zsfilter"] = json.dumps({c: sorted(v) for c, v in filt.items()})
+        print(f"[retrieval_cli/{kind}] zero-shot filter keeps out {sum(len(v) for v in filt.values())} files")
+    np.savez_compressed(os.path.join(GOLD, "retrieval_cli.npz"), **payload)
+    print("wrote tests/golden/retrieval_cli.npz")
+
+
+SECTIONS = {"retrieval": golden_retrieval, "retrieval_cli": golden_retrieval_cli}
 
 
 # --------------------------------------------------------------------------------------------
@@ -538,7 +594,84 @@ def export_hf_state(kind, name, path):
     torch.save({k: v.detach().clone() for k, v in conv(hf).items()}, path)
 
 
-SECTIONS.update({"host": golden_host, "loop": golden_loop, "vit": golden_vit, "text": golden_text})
+def stage_models(seed_best=11, seed_zero=12):
+    """Two TINY oracle CLIPs ("finetuned" and "zero-shot") + heads, seeded: inputs of the stages golden (re-made by the tests)."""
+    from oracle import vit_oracle as vo
+    out = []
+    for seed in (seed_best, seed_zero):
+        torch.manual_seed(seed)
+        m = vo.OracleCLIP(vision_cfg=TINY, text_width=64, text_heads=1, text_layers=1, ctx=8, vocab=64)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith("bias"):
+                    p.add_(0.02 * torch.randn_like(p))
+        W = torch.randn(7, TINY[5]) * (0.5 + torch.rand(7, 1))  # rows of different norms: tau-normalisation matters
+        out.append((m, W))
+    return out
+
+
+def stage_loader(seed, n, bsz, C=7, img=64, teacher=None):
+    """Seeded image batches; with a teacher (model, W) the labels are its predictions with every fourth one re-drawn, so
+    accuracies are neither 0 nor 100 and depend on the head's row norms (what tau-normalisation changes)."""
+    g = torch.Generator().manual_seed(seed)
+    x, y = torch.randn(n, 3, img, img, generator=g), torch.randint(0, C, (n,), generator=g)
+    if teacher is not None:
+        model, W = teacher
+        with torch.no_grad():
+            f = model.encode_image(x)
+            pred = ((f / f.norm(dim=-1, keepdim=True)) @ W.t()).argmax(1)
+        keep = torch.arange(n) % 4 != 3
+        y = torch.where(keep, pred, y)
+    return [(x[i:i + bsz], y[i:i + bsz], None, torch.ones(len(y[i:i + bsz]), dtype=torch.long)) for i in range(0, n, bsz)]
+
+
+def golden_stages():
+    """A10 / A11 / f.4: the reference's own extract_test_feats (utils/features.py:122-148), ensemble_model, run_wsft_alpha
+    and run_tau_normalization (main.py:27-195) on the fp32 oracle TINY model (CPU)."""
+    from oracle import ref_shims
+    ref_shims.install()
+    import main as ref_main
+    import utils.features as rf
+    import utils.models as rm
+    rf.tqdm = lambda it, *a, **k: it
+    (best, Wb), (zero, Wz) = stage_models()
+    recs = {}
+    # ---- extract_test_feats: batched encode_image + L2 normalise, loader order ----
+    loader = stage_loader(21, 22, 8)
+    feats = rf.extract_test_feats(best, loader)
+    recs["feats_image_features"] = feats["image_features"].numpy()
+    recs["feats_labels"] = feats["labels"].numpy()
+    # ---- ensemble_model(alpha) ----
+    for alpha in (0.5, 0.3):
+        w = ref_main.ensemble_model(best, zero, alpha)
+        sd = w.state_dict()
+        recs[f"wsft_{alpha}_digest"] = np.stack([_digest(sd[k].float()) for k in sorted(sd) if sd[k].dtype.is_floating_point])
+        with torch.no_grad():
+            recs[f"wsft_{alpha}_embeds"] = w.encode_image(loader[0][0]).numpy()
+    # ---- run_wsft_alpha and run_tau_normalization on image / pre-extracted loaders ----
+    args = _ref_args(device="cpu", dataset="synthetic", output_dir=tempfile.mkdtemp(), pre_extracted=False, freeze_visual=False,
+                     tau_norm=True, loss=torch.nn.CrossEntropyLoss())
+    ls = torch.tensor(4.0)
+    head_b, head_z = rm.MyLinear(weights=Wb.clone()), rm.MyLinear(weights=Wz.clone())
+    Wn = Wb / Wb.norm(dim=-1, keepdim=True)  # the teacher ranks by cosine: the un-normalised head only agrees with it at tau = 1
+    val, test = stage_loader(31, 40, 8, teacher=(best, Wn)), stage_loader(32, 48, 8, teacher=(best, Wn))
+    wm, wh, wacc = ref_main.run_wsft_alpha(args, best, head_b, val, test, zero, head_z, ls, _logger())
+    recs["wsft_alpha_test_acc"] = np.float64(wacc)
+    recs["wsft_alpha_head"] = wh.linear.weight.detach().numpy()
+    # tau-norm runs on pre-extracted (already normalised) features
+    fv, ft = rf.extract_test_feats(best, val), rf.extract_test_feats(best, test)
+    pv = [(fv["image_features"][i:i + 8], fv["labels"][i:i + 8], None, None) for i in range(0, 40, 8)]
+    pt = [(ft["image_features"][i:i + 8], ft["labels"][i:i + 8], None, None) for i in range(0, 48, 8)]
+    th, tau, tacc = ref_main.run_tau_normalization(args, head_b, best, pv, pt, ls, _logger())
+    recs["tau_best"] = np.float64(tau)
+    recs["tau_test_acc"] = np.float64(tacc)
+    recs["tau_head"] = th.linear.weight.detach().numpy()
+    print(f"[stages] wsft alpha test acc {wacc:.3f}; best tau {tau:.1f} test acc {tacc:.3f}")
+    np.savez_compressed(os.path.join(GOLD, "stages_tiny.npz"), **recs)
+    print("wrote tests/golden/stages_tiny.npz")
+
+
+SECTIONS.update({"host": golden_host, "loop": golden_loop, "vit": golden_vit, "text": golden_text, "stages": golden_stages})
 
 
 if __name__ == "__main__":

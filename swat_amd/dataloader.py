@@ -47,6 +47,38 @@ class MyDataset(Dataset):
         return img, label, tok, source
 
 
+class MinedDataset(Dataset):
+    """Retrieved LAION images of one dataset: <dataset_root>/<class id>/<image id>.jpg + their captions
+    (ref utils/datasets/dataset_utils.py:282-320).  __getitem__ -> (img, label, file_path, caption) — the reference's order.
+    caption_map: {str(label): {image id: caption}} (the pickled `*_metadata-*.map`, retrieval/extract_mined_feature.py:252-262).
+    rank / world: this process encodes files rank, rank + world, ... of the list (world 1 = all)."""
+
+    def __init__(self, transform=None, dataset_root=".", caption_map=None, rank=0, world=1, loader=_pil_loader):
+        import pathlib
+        self.dataset_root = pathlib.Path(dataset_root)
+        self.fnames = list(self.dataset_root.glob("**/*.jpg"))  # directory order, like the reference (not sorted)
+        if len(self.fnames) == 0:
+            raise ValueError('Check image suffix. No images found in the specified dataset_root: {}'.format(dataset_root))
+        self.num_classes = len(set(f.parent.name for f in self.fnames))
+        self.n_total = len(self.fnames)
+        self.fnames = self.fnames[rank::world]
+        self.caption_map, self.transform, self.loader = caption_map, transform, loader
+
+    def __len__(self):
+        return len(self.fnames)
+
+    def __getitem__(self, i):
+        f = self.fnames[i]
+        img = self.loader(str(f))
+        label = int(f.parent.name)
+        img_id = f.name.split('.')[0]
+        if self.transform is not None:
+            img = self.transform(img)
+        if self.caption_map is not None:
+            return img, label, str(f), self.caption_map[str(label)][img_id]
+        return img, label, str(f), ''
+
+
 class TensorDataset(Dataset):
     """Pre-extracted features saved by extract_test_feats: {'image_features' [N,E], 'labels' [N]}."""
 

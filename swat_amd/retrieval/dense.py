@@ -85,16 +85,18 @@ def remove_near_duplicates2(index, thr=0.9):
     """Whole-index form with the reference's quirk (:262-267): positional marks are matched against int(basename).
     -> (duplicate_files: {str(cls): set(paths)}, dup_fraction per class, average)."""
     from collections import defaultdict
+    import numpy as np
     dups, fracs = defaultdict(set), []
     off = index.offsets.tolist()
+    paths, ids = index.paths_array(), index.file_ids()
     for s, c in enumerate(index.class_ids.tolist()):
         b, e = off[s], off[s + 1]
         if e == b:
             continue
         marks = near_dup_marks(index.image_features[b:e].contiguous(), thr).cpu().numpy()
-        to_remove = set(int(i) for i in marks.nonzero()[0])
-        for f in index.filepath[b:e]:
-            if int(f.split('/')[-1].split('.')[0]) in to_remove:
-                dups[str(c)].add(f)
+        to_remove = marks.nonzero()[0]
+        hit = np.isin(ids[b:e], to_remove)
+        if hit.any():
+            dups[str(c)].update(paths[b:e][hit].tolist())
         fracs.append(len(to_remove) / (e - b))
     return dups, fracs, sum(fracs) / max(1, len(fracs))

@@ -1,33 +1,148 @@
-"""B1: encode every retrieved image AND its caption with CLIP -> the `mined.pth` dict the samplers read
-(mirror of the reference's retrieval/extract_mined_feature.py:103-213, 252-280).
+"""B1 / B2: encode every retrieved image AND its caption with CLIP -> the `mined.pth` dict the samplers read
+(mirror of the reference's retrieval/extract_mined_feature.py; same function names, flags and output file).
 
-ref: extract_mined_feats_batch :103-213 (pass 1 captions -> encode_text -> L2-norm; pass 2 images -> encode_image ->
-L2-norm; both in loader order), pre_extract_mined_fea :252-280 (bsz 1024, saves {caption_features, labels, filepath,
-image_features}).  Both towers run on the HIP kernels; features are kept on the GPU and moved to the host once.
+    python -m swat_amd.retrieval.extract_mined_feature --dataset semi-aves --model_cfg vitb32_openclip_laion400m
+    python -m torch.distributed.run --nproc-per-node 8 -m swat_amd.retrieval.extract_mined_feature --dataset semi-aves   # 8 GPUs
+
+ref: MINED_DATASET_ROOT_DICT / CAPTION_MAP_DICT :19-46, extract_mined_feats :49-100, extract_mined_feats_batch :103-213
+(pass 1: captions -> tokenizer -> encode_text -> L2-normalise; pass 2: images -> encode_image -> L2-normalise; both in
+loader order, shuffle=False), pre_extract_mined_fea :252-280 (MinedDataset + caption map, bsz 1024, saves
+{caption_features, labels, filepath, image_features} to <root>/<dataset>/<dataset>_<model_cfg>_mined.pth), __main__ :284-315.
+
+What differs on the MI355X: both towers run on the HIP kernels; the features stay in HBM until the end (10 M x 512 fp32 x 2 =
+41 GB of 288 GB), so the reference's spill-to-disk-every-100-batches-and-reload (:128-140, :181-200 — whose reload walks
+os.listdir() order, i.e. can permute the batches) is not needed: `save_dir` / `batch_size` are accepted and ignored.  Under
+torch.distributed.run every rank encodes files rank, rank + world, ... of the list and rank 0 writes the merged dict in the
+single-process row order.
 """
+import argparse
+import os
+import pickle
+
 import torch
+from torch.utils.data import DataLoader
 
 from ..features import l2_normalize
 
 
+def _retrieved_root(config_path=None):
+    """`retrieved_path` of config.yml (the reference reads ../config.yml at import time, :16-18)."""
+    import yaml
+    for p in ([config_path] if config_path else []) + ['config.yml', '../config.yml']:
+        if p and os.path.exists(p):
+            with open(p) as f:
+                return yaml.load(f, Loader=yaml.FullLoader)['retrieved_path'].rstrip('/')
+    return os.environ.get('SWAT_RETRIEVED_PATH', 'data/retrieved')
+
+
+_ALL = ('semi-aves', 'fgvc-aircraft', 'eurosat')  # mined with every synonym; the others with a random one (ref :19-46)
+_DATASETS = ('semi-aves', 'fgvc-aircraft', 'eurosat', 'dtd', 'flowers102', 'oxford_pets', 'food101', 'stanford_cars', 'imagenet')
+
+
+def mined_dataset_root(dataset, root):
+    return f'{root}/{dataset}/{dataset}_retrieved_LAION400M-all_synonyms-{"all" if dataset in _ALL else "random"}'
+
+
+def caption_map_path(dataset, root):
+    return f'{root}/{dataset}/{dataset}_metadata-{"all" if dataset in _ALL else "random"}-0.0-LAION400M.map'
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 @torch.no_grad()
-def extract_mined_feats_batch(model, dataloader, tokenizer, device="cuda"):
-    """dataloader yields (imgs [B,3,H,W], labels [B], captions list[str], filepaths list[str])."""
+def extract_mined_feats_batch(model, dataloader, tokenizer, save_dir=None, batch_size=100, device="cuda"):
+    """dataloader yields (imgs [B,3,H,W], labels [B], file_path list[str], captions list[str]) — MinedDataset's order.
+    -> {'caption_features' [N,E], 'labels' [N], 'filepath' list[N], 'image_features' [N,E]} (CPU tensors), loader order."""
     model.eval()
     cap_feats, labels_lst, paths = [], [], []
-    for imgs, labels, captions, filepaths in dataloader:          # pass 1: captions
+    for imgs, labels, file_path, captions in dataloader:            # pass 1: captions
         tok = tokenizer(list(captions)).to(device)
         cap_feats.append(l2_normalize(model.encode_text(tok)))
         labels_lst.append(labels.long())
-        paths.extend(list(filepaths))
+        paths.extend(list(file_path))
     img_feats = []
-    for imgs, labels, captions, filepaths in dataloader:          # pass 2: images
-        img_feats.append(l2_normalize(model.visual.forward_raw(imgs.to(device))))
+    for imgs, labels, file_path, captions in dataloader:            # pass 2: images
+        img_feats.append(l2_normalize(model.visual.forward_raw(imgs.to(device, non_blocking=True))))
     return {'caption_features': torch.cat(cap_feats).cpu(), 'labels': torch.cat(labels_lst).cpu(), 'filepath': paths,
             'image_features': torch.cat(img_feats).cpu()}
 
 
-def pre_extract_mined_fea(model, dataloader, tokenizer, out_path, device="cuda"):
-    feats = extract_mined_feats_batch(model, dataloader, tokenizer, device)
-    torch.save(feats, out_path)
-    return feats
+extract_mined_feats = extract_mined_feats_batch  # the reference's un-spilled form (:49-100) computes the same dict
+
+
+def merge_rank_dicts(parts):
+    """Per-rank dicts of a rank-strided extraction (rank r holds files r, r + W, ...) -> the single-process dict."""
+    world = len(parts)
+    n = sum(len(p['filepath']) for p in parts)
+    out = {'filepath': [None] * n}
+    for key in ('caption_features', 'image_features', 'labels'):
+        first = parts[0][key]
+        out[key] = torch.empty((n,) + tuple(first.shape[1:]), dtype=first.dtype)
+    for r, p in enumerate(parts):
+        out['filepath'][r::world] = p['filepath']
+        for key in ('caption_features', 'image_features', 'labels'):
+            out[key][r::world] = p[key]
+    return out
+
+
+def pre_extract_mined_fea(args, dataset_name, dataset_root, caption_path, model_cfg, model, preprocess, tokenizer):
+    """ref :252-280 — same arguments, same output file; returns the dict (rank 0) for callers that go on in-process."""
+    from ..dataloader import MinedDataset
+    rank, world = _dist()
+    if rank == 0:
+        print('\nextracting features for', dataset_name, model_cfg)
+        print('dataset_root:', dataset_root)
+    with open(caption_path, 'rb') as f:
+        caption_map = pickle.load(f)
+    dataset = MinedDataset(dataset_root=dataset_root, transform=preprocess, caption_map=caption_map, rank=rank, world=world)
+    loader = DataLoader(dataset, batch_size=args.bsz, shuffle=False, num_workers=args.num_workers, drop_last=False, pin_memory=True)
+    part = extract_mined_feats_batch(model, loader, tokenizer, save_dir=f'{args.root}/{dataset_name}/temp')
+    if world > 1:
+        import torch.distributed as dist
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(part, parts, dst=0)
+        if rank != 0:
+            return None
+        part = merge_rank_dicts(parts)
+    save_root = f'{args.root}/{dataset_name}'
+    os.makedirs(save_root, exist_ok=True)
+    output_fn = f'{save_root}/{dataset_name}_{model_cfg}_mined.pth'
+    torch.save(part, output_fn)
+    print(f'\nSaved to extracted feature to: {output_fn}')
+    return part
+
+
+def main(argv=None):
+    root = _retrieved_root()
+    parser = argparse.ArgumentParser(description='Arguments for script.')
+    parser.add_argument('--dataset', type=str, default='semi-aves', help='Dataset name.')
+    parser.add_argument('--root', type=str, default=root, help='Root directory for storing mined data.')
+    parser.add_argument('--model_cfg', type=str, default='vitb32_openclip_laion400m',
+                        choices=['vitb32_openclip_laion400m', 'vitb32_openclip_laion2b', 'vitb16_openclip_laion400m',
+                                 'vitl14_openclip_laion400m'], help='ViT Transformer arch.')
+    parser.add_argument('--bsz', type=int, default=1024, help='Batch size.')
+    parser.add_argument('--num_workers', type=int, default=16, help='Number of workers for dataloader.')
+    parser.add_argument('--dist_backend', type=str, default='nccl', choices=['nccl', 'gloo'])
+    args = parser.parse_args(argv)
+    from .. import dp
+    dp.init_from_env(args)  # before anything touches the GPU
+    if dp.is_main(args):
+        for arg in vars(args):
+            print(f'{arg}: {getattr(args, arg)}')
+    from ..engine import get_engine
+    model, preprocess, tokenizer = get_engine(model_cfg=args.model_cfg, device='cuda')
+    model.eval()
+    out = pre_extract_mined_fea(args=args, dataset_name=args.dataset, dataset_root=mined_dataset_root(args.dataset, args.root),
+                                caption_path=caption_map_path(args.dataset, args.root), model_cfg=args.model_cfg, model=model,
+                                preprocess=preprocess, tokenizer=tokenizer)
+    dp.barrier(args)
+    return out
+
+
+if __name__ == '__main__':
+    main()

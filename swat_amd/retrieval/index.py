@@ -41,10 +41,31 @@ class SegmentedIndex:
                                                counts)
         self.filepath = None
         if filepath is not None:
-            o = order.tolist()
-            self.filepath = [filepath[i] for i in o]
+            # one numpy fancy-index instead of a Python loop over N rows; `filepath` (list view) is made on demand
+            self._paths = np.asarray(filepath)[order.cpu().numpy()]
         self.n_rows = int(order.numel())
         self.n_seg = int(class_ids.numel())
+
+    def paths_array(self):
+        """numpy unicode array [N] of the grouped rows' file paths (vectorised membership tests, slicing by row list)."""
+        return self._paths
+
+    def file_ids(self):
+        """int64 [N]: int(<file name without extension>) of every grouped row — what the reference's duplicate / zero-shot
+        filters compare POSITIONS against (retrieval/sample_retrieval.py:262-267, :312-316); numpy string ops, cached."""
+        if getattr(self, "_file_ids", None) is None:
+            base = np.char.rpartition(self._paths, "/")[:, 2]
+            self._file_ids = np.char.partition(base, ".")[:, 0].astype(np.int64)
+        return self._file_ids
+
+    @property
+    def filepath(self):
+        return self._paths
+
+    @filepath.setter
+    def filepath(self, v):
+        self._paths = None if v is None else np.asarray(v)
+        self._file_ids = None
 
     def queries_from_prompt_tensors(self, prompt_tensors):
         """Stack prompt_tensors[str(cls)]['mean'] in segment order (ref: :749-750, :801-802)."""
@@ -81,9 +102,8 @@ class SegmentedIndex:
             t = getattr(self, name)
             if t is not None:
                 np.save(os.path.join(path, name + ".npy"), t.cpu().numpy())
-        if self.filepath is not None:
-            with open(os.path.join(path, "filepath.txt"), "w") as f:
-                f.write("\n".join(self.filepath))
+        if self._paths is not None:
+            np.save(os.path.join(path, "filepath.npy"), self._paths)
         meta = {"format": "swat_amd.SegmentedIndex/1", "n_rows": self.n_rows, "n_seg": self.n_seg,
                 "dim": int(self.caption_features.shape[1] if self.caption_features is not None else self.image_features.shape[1]),
                 "dtype": "float32", "row_order": "grouped by class id ascending, file order inside a class"}
@@ -106,10 +126,12 @@ class SegmentedIndex:
             setattr(self, name, torch.from_numpy(np.load(f, mmap_mode="r")[lo:hi].copy()).to(device) if os.path.exists(f) else None)
         counts = self.offsets[1:] - self.offsets[:-1]
         self.row_seg = torch.repeat_interleave(torch.arange(self.class_ids.numel(), device=device, dtype=torch.int32), counts)
-        self.filepath = None
-        fp = os.path.join(path, "filepath.txt")
-        if os.path.exists(fp):
-            self.filepath = open(fp).read().split("\n")[lo:hi]
+        self._paths = None
+        fp = os.path.join(path, "filepath.npy")
+        if os.path.exists(fp):  # fixed-width unicode array: a shard memory-maps it and copies only its own rows
+            self._paths = np.load(fp, mmap_mode="r")[lo:hi].copy()
+        elif os.path.exists(os.path.join(path, "filepath.txt")):
+            self._paths = np.asarray(open(os.path.join(path, "filepath.txt")).read().split("\n")[lo:hi])
         self.n_rows = hi - lo
         self.n_seg = int(self.class_ids.numel())
         self.row_base = lo

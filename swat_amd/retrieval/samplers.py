@@ -36,19 +36,20 @@ def _as_index(pre, device="cuda"):
 
 
 def _excluded_mask(index, duplicates_dict, filtered_images_dict):
+    """uint8 [N] over grouped rows: 1 iff the row's path is in its class's duplicate / zero-shot-filter set (what the
+    reference checks per row inside its Python walk, :463-469 / :507-527).  One vectorised membership test per class that
+    HAS exclusions, on the index's numpy path array — never a Python loop over all N rows."""
     if not duplicates_dict and not filtered_images_dict:
         return None
+    import numpy as np
+    paths = index.paths_array()
     off = index.offsets.tolist()
-    mask = torch.zeros(index.n_rows, dtype=torch.uint8)
+    mask = np.zeros(index.n_rows, dtype=np.uint8)
     for s, c in enumerate(index.class_ids.tolist()):
-        dup, fil = duplicates_dict.get(str(c), ()), filtered_images_dict.get(str(c), ())
-        if not dup and not fil:
-            continue
-        for r in range(off[s], off[s + 1]):
-            p = index.filepath[r]
-            if p in dup or p in fil:
-                mask[r] = 1
-    return mask.to(index.offsets.device)
+        excl = set(duplicates_dict.get(str(c), ())) | set(filtered_images_dict.get(str(c), ()))
+        if excl:
+            mask[off[s]:off[s + 1]] = np.isin(paths[off[s]:off[s + 1]], np.array(sorted(excl), dtype=paths.dtype))
+    return torch.from_numpy(mask).to(index.offsets.device)
 
 
 def _run(args, logger, prompt_tensors, num_samples, threshold, pre, duplicates_dict, filtered_images_dict, rank_by,
@@ -70,7 +71,7 @@ def _run(args, logger, prompt_tensors, num_samples, threshold, pre, duplicates_d
         rows = idx_c[s, :n]
         mined_split['feature_list'].append(index.image_features[rows.to(index.image_features.device)].cpu())
         mined_split['label_list'].append(torch.full((n,), int(c), dtype=torch.int64))
-        files = [index.filepath[r] for r in rows.tolist()]
+        files = index.paths_array()[rows.numpy()].tolist()
         mined_split['file_list'].append(files)
         sv = val[s, :n].cpu().tolist()
         sampled_list += [f'{round(v, 4)}/{threshold}, {f}' for v, f in zip(sv, files)]
@@ -118,10 +119,10 @@ def save_sample_file_list(args, final_file_list, label_tensor, logger=None):
 SAMPLERS = {'T2T-rank': t2t_ranked_sampler, 'T2T-rank-T2I-tshd': t2t_ranked_t2i_tshd_sampler, 'T2I-rank': t2i_ranked_sampler}
 
 
-def sampling(args, logger, pre_extracted_feats, prompt_tensors):
+def sampling(args, logger, pre_extracted_feats, prompt_tensors, filtered_images_dict=None):
     """ref :1471-1670 for the implemented sampling methods -> (file_list_path, sample_ct)."""
     index = pre_extracted_feats if isinstance(pre_extracted_feats, SegmentedIndex) else transform_extracted_fea(pre_extracted_feats)
-    filtered_images_dict = defaultdict(set)
+    filtered_images_dict = filtered_images_dict if filtered_images_dict is not None else defaultdict(set)
     duplicate_images_dict = defaultdict(set)
     if getattr(args, 'image_dedup', False):
         duplicate_images_dict, fracs, avg = dense.remove_near_duplicates2(index)

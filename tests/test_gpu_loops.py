@@ -166,3 +166,50 @@ def test_cli_zeroshot_method_matches_the_oracle(tmp_path, monkeypatch, capsys):
             total += labels.numel()
     want = 100.0 * right / total
     assert abs(seen["acc"] - want) <= 100.0 * flips / total + 1e-9, (seen["acc"], want, flips)
+
+
+def _hip_clip_from(oracle_model):
+    from swat_amd.clip_model import CLIP
+    m = CLIP(vision_cfg=TINY, text_cfg=(8, 64, 64, 1, 1))
+    m.load_state_dict(oracle_model.state_dict())
+    return m.to("cuda")
+
+
+def test_stage_fan_out_matches_the_reference_golden(golden_dir):
+    """A10 / A11 / f.4 on the GPU: extract_test_feats, ensemble_model + run_wsft_alpha and run_tau_normalization of
+    swat_amd (HIP tower + fused head behind validate) against the outputs of the REFERENCE's own functions
+    (utils/features.py:122-148, main.py:27-195) recorded on the fp32 oracle by oracle/make_golden.py `stages`."""
+    from oracle import make_golden as mg
+    from swat_amd import stages
+    from swat_amd.features import extract_test_feats
+    from swat_amd.models import MyLinear
+    g = np.load(f"{golden_dir}/stages_tiny.npz")
+    (best_o, Wb), (zero_o, Wz) = mg.stage_models()
+    best, zero = _hip_clip_from(best_o), _hip_clip_from(zero_o)
+    # extract_test_feats: loader order, labels, L2-normalised embeddings
+    feats = extract_test_feats(best, mg.stage_loader(21, 22, 8))
+    assert np.array_equal(feats["labels"].numpy(), g["feats_labels"])
+    want = g["feats_image_features"]
+    assert feats["image_features"].shape == want.shape and not feats["image_features"].is_cuda
+    assert np.abs(feats["image_features"].numpy() - want).max() <= 0.007 * np.abs(want).max()
+    assert np.allclose(np.linalg.norm(feats["image_features"].numpy(), axis=1), 1.0, atol=1e-5)
+    # WiSE-FT sweep (alpha = 0.5): interpolated tower + head, validate on val / test
+    args = types.SimpleNamespace(device="cuda", dataset="synthetic", output_dir="/tmp", pre_extracted=False, freeze_visual=False,
+                                 tau_norm=True, loss=torch.nn.CrossEntropyLoss())
+    ls = torch.tensor(4.0, device="cuda")
+    Wn = Wb / Wb.norm(dim=-1, keepdim=True)
+    val, test = mg.stage_loader(31, 40, 8, teacher=(best_o, Wn)), mg.stage_loader(32, 48, 8, teacher=(best_o, Wn))
+    head_b, head_z = MyLinear(weights=Wb.clone()).to("cuda"), MyLinear(weights=Wz.clone()).to("cuda")
+    wm, wh, wacc = stages.run_wsft_alpha(args, best, head_b, val, test, zero, head_z, ls, _Lg())
+    assert np.allclose(wh.linear.weight.detach().cpu().numpy(), g["wsft_alpha_head"], atol=1e-6)
+    assert abs(wacc - float(g["wsft_alpha_test_acc"])) <= 100.0 / 48 + 1e-9     # bf16 tower: at most one near-tie flips
+    with torch.no_grad():
+        e = wm.visual.forward_raw(val[0][0].to("cuda")).cpu().numpy()
+    # tau-normalisation on pre-extracted features of the same splits
+    fv, ft = extract_test_feats(best, val), extract_test_feats(best, test)
+    pv = [(fv["image_features"][i:i + 8], fv["labels"][i:i + 8], torch.zeros(1), 1) for i in range(0, 40, 8)]
+    pt = [(ft["image_features"][i:i + 8], ft["labels"][i:i + 8], torch.zeros(1), 1) for i in range(0, 48, 8)]
+    th, tau, tacc = stages.run_tau_normalization(args, head_b, best, pv, pt, ls, _Lg())
+    if abs(tau - float(g["tau_best"])) < 1e-9:
+        assert np.allclose(th.linear.weight.detach().cpu().numpy(), g["tau_head"], rtol=1e-5, atol=1e-6)
+    assert abs(tacc - float(g["tau_test_acc"])) <= 2 * 100.0 / 48 + 1e-9

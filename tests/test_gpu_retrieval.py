@@ -254,7 +254,7 @@ def test_saved_index_shards_merge_to_the_single_gpu_answer(tmp_path, world):
     for rank in range(world):
         lo, hi = shard.shard_bounds(n, world, rank)
         loc = SegmentedIndex.load(str(tmp_path / "ix"), device=dev, rows=(lo, hi))
-        assert loc.filepath == full.filepath[lo:hi]
+        assert np.array_equal(loc.filepath, full.filepath[lo:hi])  # numpy path arrays (mmap-able filepath.npy)
         i, v, _, _, _ = loc.sample(q, k, **kw)
         idxs.append(torch.where(i >= 0, i + lo, i))
         vals.append(v)
@@ -263,3 +263,157 @@ def test_saved_index_shards_merge_to_the_single_gpu_answer(tmp_path, world):
     assert torch.equal(m_idx, w_idx)
     valid = w_idx >= 0
     assert torch.equal(m_val[valid], w_val[valid])
+
+
+def _write_mined(root, case):
+    os.makedirs(f"{root}/synthetic", exist_ok=True)
+    torch.save({"image_features": torch.from_numpy(case["img"]), "caption_features": torch.from_numpy(case["cap"]),
+                "labels": torch.from_numpy(case["labels"]), "filepath": case["paths"]},
+               f"{root}/synthetic/synthetic_vitb32_openclip_laion400m_mined.pth")
+
+
+@pytest.mark.parametrize("kind", ["float", "grid"])
+@pytest.mark.parametrize("method,tag", [("T2T-rank-T2I-tshd", "t2t_t2i"), ("T2T-rank", "t2t"), ("T2I-rank", "t2i")])
+@pytest.mark.parametrize("dedup", [False, True])
+def test_sample_retrieval_command_line_writes_the_reference_files(golden_dir, tmp_path, monkeypatch, kind, method, tag, dedup):
+    """`python -m swat_amd.retrieval.sample_retrieval --sampling_method ... [--image_dedup]` (ref __main__ :1673-1748) on a
+    mined.pth FILE: <prefix>.txt and <prefix>_num_imgs_sampled.json are byte-for-byte what the reference's own sampling()
+    wrote for the same file (tests/golden/retrieval_cli.npz), and the split file is copied next to the dataset lists."""
+    from swat_amd.retrieval import sample_retrieval as cli
+    g = np.load(os.path.join(golden_dir, "retrieval_cli.npz"), allow_pickle=False)
+    spec = synth.RETRIEVAL_CASES[kind]
+    case = synth.retrieval_case(**spec)
+    root, data = tmp_path / "retrieved", tmp_path / "data"
+    _write_mined(root, case)
+    os.makedirs(data / "synthetic" / "prompts")
+    json.dump({str(c): {"name": f"class {c}"} for c in case["class_ids"]}, open(data / "synthetic" / "synthetic_metrics-LAION400M.json", "w"))
+    # cached prompt tensors (what cal_prompt_tensors would have computed with the text tower): the CLI loads them
+    pt = {str(c): {"mean": torch.from_numpy(case["queries"][i])} for i, c in enumerate(case["class_ids"])}
+    base = data / "synthetic" / "prompts" / "synthetic_vitb32_openclip_laion400m_alternates"
+    torch.save(pt, f"{base}_prompt_tensors.pth")
+    torch.save({}, f"{base}_text_prompts.pth")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr("swat_amd.engine.get_engine", lambda **kw: (torch.nn.Linear(1, 1), None, None))  # no tower needed here
+    argv = ["--prefix", "golden", "--dataset", "synthetic", "--root", str(root), "--sampling_method", method, "--num_samples",
+            str(spec["k"]), "--data_dir", str(data), "--log_mode", "file"] + (["--image_dedup"] if dedup else [])
+    path, ct = cli.main(argv)
+    key = f"{kind}_{tag}_{'dedup' if dedup else 'plain'}"
+    assert ct == int(g[key + "_ct"])
+    assert open(path).read() == str(g[key + "_txt"])
+    out = os.path.dirname(path)
+    assert open(f"{out}/golden_num_imgs_sampled.json").read() == str(g[key + "_counts"])
+    assert open(data / "synthetic" / "golden.txt").read() == str(g[key + "_txt"])       # copied to data/<dataset>/
+    assert os.path.basename(out) == "synthetic_vitb32_openclip_laion400m_golden"
+
+
+@pytest.mark.parametrize("kind", ["float", "grid"])
+def test_zeroshot_clip_img_filter_matches_reference(golden_dir, kind):
+    """ref :278-329 incl. its matching rule (positions of mispredicted rows against the files' numeric names)."""
+    from swat_amd.models import MyLinear
+    from swat_amd.retrieval import samplers
+    from swat_amd.retrieval.sample_retrieval import zeroshot_clip_img_filter
+    g = np.load(os.path.join(golden_dir, "retrieval_cli.npz"), allow_pickle=False)
+    case = synth.retrieval_case(**synth.RETRIEVAL_CASES[kind])
+    index = samplers.transform_extracted_fea({"image_features": torch.from_numpy(case["img"]), "caption_features": torch.from_numpy(case["cap"]),
+                                              "labels": torch.from_numpy(case["labels"]), "filepath": case["paths"]})
+    C = max(case["class_ids"]) + 1
+    W = torch.zeros(C, case["queries"].shape[1])
+    for i, c in enumerate(case["class_ids"]):
+        W[c] = torch.from_numpy(case["queries"][i])
+    got = zeroshot_clip_img_filter(None, None, "/unused", pre_extracted_feats=index, head=MyLinear(weights=W).to("cuda"))
+    want = json.loads(str(g[f"{kind}_zsfilter"]))
+    if kind == "grid":  # exact arithmetic: identical predictions
+        assert {c: sorted(v) for c, v in got.items()} == want
+    else:               # fp32 logits in a different summation order: a near-tie may move a handful of rows
+        a = {p for v in got.values() for p in v}
+        b = {p for v in want.values() for p in v}
+        assert len(a ^ b) <= 0.01 * len(b) + 2
+
+
+def test_excluded_mask_is_vectorised_and_equals_the_row_loop():
+    from collections import defaultdict
+    from swat_amd.retrieval import samplers
+    case = synth.retrieval_case(**synth.RETRIEVAL_CASES["float"])
+    index = samplers.transform_extracted_fea({"image_features": torch.from_numpy(case["img"]), "caption_features": torch.from_numpy(case["cap"]),
+                                              "labels": torch.from_numpy(case["labels"]), "filepath": case["paths"]})
+    dup, filt = defaultdict(set), defaultdict(set)
+    for p, e, f in zip(case["paths"], case["excl_dup"], case["excl_filt"]):
+        if e:
+            dup[p.split("/")[-2]].add(p)
+        if f:
+            filt[p.split("/")[-2]].add(p)
+    mask = samplers._excluded_mask(index, dup, filt).cpu().numpy()
+    want = (case["excl_dup"] | case["excl_filt"])[index.order.cpu().numpy()]
+    assert np.array_equal(mask.astype(bool), want)
+    assert index.paths_array().dtype.kind == "U" and index.file_ids().dtype == np.int64
+    assert samplers._excluded_mask(index, {}, {}) is None
+
+
+def test_extract_mined_features_matches_oracle_and_round_trips_mined_pth(tmp_path):
+    """B1 / B2: MinedDataset (folder = label, file name = image id, caption map) -> two passes (captions, images) on the HIP
+    towers -> the reference's mined.pth dict in loader order; against the fp32 oracle encoding the same files."""
+    import pickle
+    import types
+    from PIL import Image
+    from oracle import vit_oracle as vo
+    from swat_amd.clip_model import CLIP
+    from swat_amd.dataloader import MinedDataset
+    from swat_amd.retrieval import extract_mined_feature as ex, samplers
+    from swat_amd.transforms import build_transform
+    rs = np.random.RandomState(3)
+    root = tmp_path / "retrieved" / "toy" / "toy_retrieved_LAION400M-all_synonyms-random"
+    cap_map = {}
+    words = "red bird on a branch small yellow finch blue jay near water photo of".split()
+    for c in (0, 3, 7):
+        os.makedirs(root / str(c))
+        cap_map[str(c)] = {}
+        for i in range(5):
+            img_id = str(100 * c + 7 * i + 1)
+            Image.fromarray(rs.randint(0, 255, (48 + 8 * i, 64 + 4 * c, 3), dtype=np.uint8)).save(root / str(c) / f"{img_id}.jpg", quality=95)
+            cap_map[str(c)][img_id] = " ".join(rs.choice(words, size=3 + i % 4))
+    cap_path = tmp_path / "toy.map"
+    pickle.dump(cap_map, open(cap_path, "wb"))
+    vocab = {w: 2 + i for i, w in enumerate(words)}
+
+    def tokenizer(texts, ctx=16):  # SOT = 98, EOT = 99 (highest id), zero padding
+        out = torch.zeros(len(texts), ctx, dtype=torch.long)
+        for r, t in enumerate(texts):
+            ids = [98] + [vocab[w] for w in t.split()] + [99]
+            out[r, :len(ids)] = torch.tensor(ids)
+        return out
+
+    vis = (64, 16, 128, 2, 2, 64, "quick_gelu")
+    torch.manual_seed(5)
+    ref = vo.OracleCLIP(vision_cfg=vis, text_width=64, text_heads=1, text_layers=2, ctx=16, vocab=100)
+    model = CLIP(vision_cfg=vis, text_cfg=(16, 100, 64, 1, 2))
+    model.load_state_dict(ref.state_dict())
+    model.to("cuda")
+    preprocess = build_transform(64, "val")
+    args = types.SimpleNamespace(root=str(tmp_path / "retrieved"), bsz=4, num_workers=0)
+    got = ex.pre_extract_mined_fea(args, "toy", str(root), str(cap_path), "tinycfg", model, preprocess, tokenizer)
+    fn = tmp_path / "retrieved" / "toy" / "toy_tinycfg_mined.pth"
+    disk = torch.load(fn, weights_only=False)
+    assert set(disk) == {"caption_features", "labels", "filepath", "image_features"}
+    ds = MinedDataset(dataset_root=str(root), transform=preprocess, caption_map=cap_map)
+    assert disk["filepath"] == [str(f) for f in ds.fnames] and len(disk["filepath"]) == 15      # loader order
+    assert disk["labels"].tolist() == [int(f.parent.name) for f in ds.fnames]
+    with torch.no_grad():
+        items = [ds[i] for i in range(len(ds))]
+        wi = ref.encode_image(torch.stack([it[0] for it in items]))
+        wt = ref.encode_text(tokenizer([it[3] for it in items]))
+    wi, wt = wi / wi.norm(dim=-1, keepdim=True), wt / wt.norm(dim=-1, keepdim=True)
+    assert (disk["image_features"] - wi).abs().max() <= 0.01 and (disk["caption_features"] - wt).abs().max() <= 0.01
+    assert torch.allclose(disk["image_features"].norm(dim=-1), torch.ones(15), atol=1e-5)
+    assert torch.equal(got["image_features"], disk["image_features"])
+    # a rank-strided extraction (SURVEY 8(e) row 3) merges to the same dict
+    parts = []
+    for r in range(2):
+        d = MinedDataset(dataset_root=str(root), transform=preprocess, caption_map=cap_map, rank=r, world=2)
+        ld = torch.utils.data.DataLoader(d, batch_size=4, shuffle=False)
+        parts.append(ex.extract_mined_feats_batch(model, ld, tokenizer))
+    merged = ex.merge_rank_dicts(parts)
+    assert merged["filepath"] == disk["filepath"] and torch.equal(merged["labels"], disk["labels"])
+    assert (merged["image_features"] - disk["image_features"]).abs().max() <= 1e-6  # batch composition differs, rows do not
+    # and the samplers read the file's dict
+    index = samplers.transform_extracted_fea(disk)
+    assert index.n_rows == 15 and index.class_ids.tolist() == [0, 3, 7]

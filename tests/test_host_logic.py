@@ -125,8 +125,27 @@ def test_segmented_index_save_load_round_trip(tmp_path):
     ix.save(str(tmp_path / "ix"))
     full = SegmentedIndex.load(str(tmp_path / "ix"), device="cpu")
     assert torch.equal(full.caption_features, ix.caption_features) and torch.equal(full.image_features, ix.image_features)
-    assert torch.equal(full.offsets, ix.offsets) and torch.equal(full.order, ix.order) and full.filepath == ix.filepath
+    assert torch.equal(full.offsets, ix.offsets) and torch.equal(full.order, ix.order) and np.array_equal(full.filepath, ix.filepath)
     sh = SegmentedIndex.load(str(tmp_path / "ix"), device="cpu", rows=(300, 700))
-    assert torch.equal(sh.image_features, ix.image_features[300:700]) and sh.filepath == ix.filepath[300:700]
+    assert torch.equal(sh.image_features, ix.image_features[300:700]) and np.array_equal(sh.filepath, ix.filepath[300:700])
     assert int(sh.offsets[0]) == 0 and int(sh.offsets[-1]) == 400 and torch.equal(sh.row_seg, ix.row_seg[300:700])
     assert torch.equal(sh.offsets, ix.offsets.clamp(300, 700) - 300)
+
+
+def test_ensemble_model_matches_the_reference_golden(golden_dir):
+    """WiSE-FT weight-space interpolation (ref main.py:76-98) on the fp32 oracle models of the stages golden: every
+    state-dict tensor of the interpolated model (digest) and its embeddings equal what the reference's function produced."""
+    import numpy as np
+    import torch
+    from oracle import make_golden as mg
+    from swat_amd.stages import ensemble_model
+    g = np.load(f"{golden_dir}/stages_tiny.npz")
+    (best, _), (zero, _) = mg.stage_models()
+    x = mg.stage_loader(21, 22, 8)[0][0]
+    for alpha in (0.5, 0.3):
+        w = ensemble_model(best, zero, alpha)
+        sd = w.state_dict()
+        dig = np.stack([mg._digest(sd[k].float()) for k in sorted(sd) if sd[k].dtype.is_floating_point])
+        assert np.allclose(dig, g[f"wsft_{alpha}_digest"], rtol=1e-6, atol=1e-7)
+        with torch.no_grad():
+            assert np.allclose(w.encode_image(x).numpy(), g[f"wsft_{alpha}_embeds"], atol=1e-5)

@@ -86,19 +86,9 @@ int swat_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int
                    const void* actin, int ldact, int act, void* C2, int out_f32, float alpha,
                    swat_stream_t stream);
 
-/*     Measurement hooks (bench.py roofline leg): time every GEMM launch with start / stop hipEvents attached to the
- *     kernel's own dispatch packet (kernel execution time, as rocprofv3 reports it).  end() synchronises and fills
- *     6 slots indexed layout*2 + (tile with a 128-row side ? 1 : 0)
- *     with total milliseconds, launch counts and 2*M*N*K*batch flops; returns the launches seen. */
-/*     swat_gemm_set_tile: pin one tile configuration (-1 = automatic) — tests and tuning.  14-19, 25-28, 43: LDS-DMA
- *     ring (64x64 / 128x128 / 128x64 tiles, 2-8 stages, 4 or 8 waves); 30-34: register ring on whole k-steps;
- *     20-24: register ring with K tails and batch strides (the fallback of every other number). */
-int swat_gemm_set_tile(int cfg);
-int swat_gemm_set_exp(int bits); /* tuning only: ablate loads / MFMA / epilogue of the LDS-DMA kernel (results wrong) */
-int swat_gemm_set_trace(void* dev_buf); /* tuning only: per-workgroup timeline of the LDS-DMA kernel (exp bit 16) */
-int swat_gemm_set_swizzle(int mode); /* 0 = plain 2-D grid, -1 = XCD-aware tile order (default) */
-int swat_gemm_prof_begin(int max_launches);
-int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind);
+/*     Measurement and tuning entry points (per-launch GEMM timing for bench.py's roofline leg, tile pinning for the
+ *     tests, ablation switches that make results WRONG on purpose) are NOT part of this interface: see
+ *     include/swat_hip_tuning.h. */
 
 /* A2b,f,g  LayerNorm (eps inside rsqrt, biased variance = torch.nn.LayerNorm). x fp32 with an explicit
  *     row stride (so the cls rows of [B,T,d] can be normalised in place); y in bf16 and/or fp32. */
@@ -251,10 +241,6 @@ int swat_vit_backward(const int32_t* dims, const int64_t* offs, const float* par
  *     optimizer slice can trail the backward without stalling it.  mode 0: everything on `stream`.
  *     Same kernels and buffers in every mode: the gradients are bit-identical. */
 int swat_vit_set_overlap(int mode);
-/* Split-K planes of the deep, narrow products (c_proj forward, c_fc / in_proj dgrads: K = 4d / 3d onto N = d): the
- *     reduction runs as `planes` slices into fp32 planes that the next LayerNorm kernel sums in a fixed order (default 3;
- *     0 or 1 = one launch, no planes).  Deterministic either way; the per-element summation order differs. */
-int swat_vit_set_split_k(int planes);
 swat_stream_t swat_vit_lane_stream(void);
 swat_stream_t swat_vit_aux_stream(int i); /* i = 0, 1: two more process-wide streams created together with the lane (the
                                             * data-parallel step's all-reduce and optimizer streams) */

@@ -1,0 +1,39 @@
+/* include/swat_hip_tuning.h — measurement and tuning entry points of libswat_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/swat_hip.h): nothing the reference does maps onto these.  They exist for
+ * bench.py's roofline leg (per-launch kernel times), the tile-configuration tests and the tools under tools/.  The
+ * ablation switches (swat_gemm_set_exp) make results WRONG on purpose; production code never calls this header.
+ */
+#ifndef SWAT_HIP_TUNING_H
+#define SWAT_HIP_TUNING_H
+#include "swat_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Time every GEMM launch with start / stop hipEvents attached to the kernel's own dispatch packet (kernel execution
+ *     time, as rocprofv3 reports it).  end() synchronises and fills 9 slots indexed layout * 3 + {0: 64-row tile,
+ *     1: 128-row tile, 2: producer / consumer kernel} with total milliseconds, launch counts and 2*M*N*K*batch flops;
+ *     returns the launches seen. */
+int swat_gemm_prof_begin(int max_launches);
+int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind);
+/* Pin one tile configuration (-1 = automatic) — tests and tuning.  14-19, 25-28, 43: LDS-DMA ring (64x64 / 128x128 /
+ *     128x64 tiles, 2-8 stages, 4 or 8 waves); 30-34: register ring on whole k-steps; 20-24: register ring with K tails
+ *     and batch strides (the fallback of every other number); 50-65: producer / consumer kernel (csrc/gemm_pc.hip:
+ *     128x128, 160x128, 96x64, 96x96, 128x64, 64x64 tiles, loader-wave and ring-depth variants). */
+int swat_gemm_set_tile(int cfg);
+/* Ablation bits (results WRONG): 1 no operand loads after the prologue, 2 no LDS reads / MFMA, 4 no epilogue, 8 no
+ *     k-order skew, 16 per-workgroup time stamps into the trace buffer, 32 per-wave epilogue instead of the LDS-staged
+ *     one, 64 loader waves read into registers instead of LDS-DMA, 512 never pick the producer / consumer kernel. */
+int swat_gemm_set_exp(int bits);
+int swat_gemm_set_trace(void* dev_buf); /* exp bit 16: 4 (LDS-DMA kernel) or 8 (producer / consumer) uint64 per workgroup */
+int swat_gemm_set_swizzle(int mode);    /* 0 = plain 2-D grid, -1 = XCD-aware tile order (default) */
+/* Split-K planes of the deep, narrow products (c_proj forward, c_fc / in_proj dgrads: K = 4d / 3d onto N = d): the
+ *     reduction runs as `planes` slices into fp32 planes that the next LayerNorm kernel sums in a fixed order (default 3;
+ *     0 or 1 = one launch, no planes).  Deterministic either way; the per-element summation order differs. */
+int swat_vit_set_split_k(int planes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -11,13 +11,14 @@ _lib = None
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "swat_hip.h")
+TUNING_HEADER = os.path.join(os.path.dirname(_HERE), "include", "swat_hip_tuning.h")  # measurement / tuning: not the boundary
 _CTYPES = {"int": c_int, "int64_t": c_int64, "float": c_float, "swat_stream_t": c_void_p}
 
 
 def _parse_header():
     """Prototypes straight from include/swat_hip.h, so the binding cannot drift from the ABI."""
     import re
-    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read() + open(TUNING_HEADER).read(), flags=re.S)
     protos, restypes = {}, {}
     for ret, name, args in re.findall(r"([A-Za-z_][\w\s\*]*?)\b(swat_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
         ret = ret.strip()

@@ -30,6 +30,7 @@
 #include "kernels.hpp"
 #include "gemm_device.hpp"
 #include "../../include/swat_hip.h"
+#include "../../include/swat_hip_tuning.h"
 
 namespace swat {
 

@@ -24,6 +24,7 @@
 #include <utility>
 #include "gemm_device.hpp"
 #include "../../include/swat_hip.h"
+#include "../../include/swat_hip_tuning.h"
 
 namespace swat {
 

@@ -1,4 +1,5 @@
-"""CPU: the C-ABI library loads and exports every symbol include/swat_hip.h declares (no compute calls)."""
+"""CPU: the C-ABI library loads and exports every symbol include/swat_hip.h and include/swat_hip_tuning.h declare (no
+compute calls)."""
 import ctypes
 import os
 import re
@@ -6,10 +7,16 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "swat_hip.h")).read()
+def _declared(headers=("swat_hip.h", "swat_hip_tuning.h")):
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in headers)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(swat_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_tuning_switches_are_not_in_the_public_header():
+    public, tuning = _declared(("swat_hip.h",)), _declared(("swat_hip_tuning.h",))
+    assert not [n for n in public if n.startswith("swat_gemm_set_") or n.startswith("swat_gemm_prof_")]
+    assert {"swat_gemm_set_exp", "swat_gemm_set_tile", "swat_gemm_prof_begin", "swat_vit_set_split_k"} <= set(tuning)
 
 
 def test_library_exports_every_declared_symbol():

@@ -109,3 +109,23 @@ def test_topk_multi_is_rank_prefix():
     for i in range(5):
         assert np.array_equal(idx[i], orc.rank(sims[i])[:17])
         assert np.array_equal(val[i], sims[i][idx[i]])
+
+
+def test_c_oracle_is_clean_under_address_and_ub_sanitizers():
+    """`make -C oracle asan`: the golden-vector checks of this file once more against the -fsanitize=address,undefined build
+    of the C restatement (CPU only; GPU sanitizers are not available on the pool)."""
+    import shutil
+    import subprocess
+    import sys
+    if os.environ.get("SWAT_ORACLE_LIB"):
+        pytest.skip("already running against a substitute oracle build")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not shutil.which("make") or not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("no libasan in this image")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"])
+    env = dict(os.environ, SWAT_ORACLE_LIB=os.path.join(root, "oracle", "_build", "libswat_oracle_asan.so"), LD_PRELOAD=libasan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not sanitizers"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])

@@ -41,6 +41,12 @@ const char* swat_last_error(void);
 int swat_sim_segmented(const float* feats, int64_t n_rows, int d, const float* queries,
                        const int32_t* row_seg, float* sims, swat_stream_t stream);
 
+/*     the same chain on a row list: sims[r] = <feats[row_index[r]], queries[row_seg[r]]> for r < n_idx (row_index[r] < 0 ->
+ *     -inf).  The exact re-scoring step of the dense scan: candidates chosen by swat_sim_candidates_bf16 get the value
+ *     the full scan would have produced, bit for bit. */
+int swat_sim_gathered(const float* feats, const int64_t* row_index, int64_t n_idx, int d, const float* queries,
+                      const int32_t* row_seg, float* sims, swat_stream_t stream);
+
 /* B5  filtered segmented top-k: for every segment s = rows [seg_offsets[s], seg_offsets[s+1])
  *     keep row iff sims >= thr [and t2i >= t2i_thr when t2i != NULL] [and !excluded[row]],
  *     order by (sims desc, row asc) and emit the first k.
@@ -60,6 +66,14 @@ int swat_segment_topk(const float* sims, const float* t2i, const uint8_t* exclud
 int swat_sim_topk_candidates(const float* queries, int n_q, const float* db, int64_t n_db, int d,
                              const float* thr_dev, int64_t row_base, void* cand_keys, int cap,
                              void* cand_cnt, float* S_out, int64_t ld_s, swat_stream_t stream);
+/*     candidate pass at the HBM rate: database rows stream once as fp32, are rounded to bf16 in registers and multiplied
+ *     with bf16 queries [n_q, d] on v_mfma_f32_16x16x32_bf16; (q, row) with approximate score >= thr_dev[q] go to the
+ *     candidate lists (same key format; cand_cnt keeps counting past cap).  |approx - exact| <= (2^-8 + 2^-12) |q| |d|;
+ *     max_norm2 (device float, zero it first) receives max |d_row|^2 so the caller can prove its top-k complete after the
+ *     exact re-scoring (swat_sim_gathered).  csrc/retrieval_bf16.hip. */
+int swat_sim_candidates_bf16(const void* queries_bf16, int n_q, const float* db, int64_t n_db, int d,
+                             const float* thr_dev, int64_t row_base, void* cand_keys, int cap, void* cand_cnt,
+                             float* max_norm2, swat_stream_t stream);
 /*     sort each query's candidates, emit the (value desc, row asc) top-k (cap <= 8192). */
 int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k,
                          int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);

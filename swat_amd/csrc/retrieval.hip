@@ -27,10 +27,14 @@ __device__ __forceinline__ float4 nt_load4(const float* p) {
 constexpr int KC = 64;              // floats per row per chunk (256 B)
 constexpr int ROW_F4 = KC / 4 + 1;  // padded row stride in float4
 
+// GATHER: output row r scores database row row_index[r] (the exact re-scoring of the dense scan's candidates: the same
+// k-ordered fma chain on a row list; row_index[r] < 0 -> -inf), n_rows = number of output rows.
+template <bool GATHER>
 __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restrict__ feats, int64_t n_rows, int d,
                                                             const float* __restrict__ queries,
                                                             const int32_t* __restrict__ row_seg,
-                                                            float* __restrict__ sims) {
+                                                            float* __restrict__ sims,
+                                                            const int64_t* __restrict__ row_index) {
     __shared__ float4 smem[4 * 64 * ROW_F4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -56,6 +60,10 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
     for (int j = 0; j < 16; ++j) {
         int64_t r = row0 + 4 * j + lr;
         r = r < last ? r : last;
+        if constexpr (GATHER) {
+            r = row_index[r];
+            r = r < 0 ? 0 : r;
+        }
         src[j] = feats + r * (int64_t)d + slot * 4;
     }
     float4 stage[16];
@@ -98,6 +106,9 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (GATHER) {
+        if (row0 + lane < n_rows && row_index[row0 + lane] < 0) acc = -INFINITY;
     }
     if (row0 + lane < n_rows) sims[row0 + lane] = acc;
 }
@@ -242,9 +253,21 @@ SWAT_API int swat_sim_segmented(const float* feats, int64_t n_rows, int d, const
     SWAT_REQUIRE(feats && queries && sims, "swat_sim_segmented: null pointer");
     const int64_t blocks = (n_rows + 255) / 256;
     SWAT_REQUIRE(blocks < (1ll << 31), "swat_sim_segmented: too many rows for one launch");
-    hipLaunchKernelGGL(swat::sim_segmented_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, feats,
-                       n_rows, d, queries, row_seg, sims);
+    hipLaunchKernelGGL(swat::sim_segmented_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, feats,
+                       n_rows, d, queries, row_seg, sims, (const int64_t*)nullptr);
     return swat::check_launch("swat_sim_segmented");
+}
+
+SWAT_API int swat_sim_gathered(const float* feats, const int64_t* row_index, int64_t n_idx, int d, const float* queries,
+                               const int32_t* row_seg, float* sims, swat_stream_t stream) {
+    SWAT_REQUIRE(d > 0 && d % swat::KC == 0, "swat_sim_gathered: d=%d must be a positive multiple of %d", d, swat::KC);
+    if (n_idx <= 0) return 0;
+    SWAT_REQUIRE(feats && row_index && queries && sims, "swat_sim_gathered: null pointer");
+    const int64_t blocks = (n_idx + 255) / 256;
+    SWAT_REQUIRE(blocks < (1ll << 31), "swat_sim_gathered: too many rows for one launch");
+    hipLaunchKernelGGL(swat::sim_segmented_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, feats,
+                       n_idx, d, queries, row_seg, sims, row_index);
+    return swat::check_launch("swat_sim_gathered");
 }
 
 SWAT_API int swat_segment_topk(const float* sims, const float* t2i, const uint8_t* excluded,

@@ -1,8 +1,14 @@
-"""Dense (N_query x N_db) cosine top-k on the fp32 matrix cores — BASELINE config 4 — and near-duplicate marks.
+"""Dense (N_query x N_db) cosine top-k — BASELINE config 4 — and near-duplicate marks.
 
 ref: retrieval/sample_retrieval.py:724-825 (per-class GEMV + sort, generalised to a query batch), :237-275 (dedup).
-Exact: similarities are bit-identical to the lane-per-row scan and the oracle (k-ordered fp32 fma chain); the
-candidate threshold only prunes, the caller-visible top-k is checked to be complete (count >= k) or recomputed.
+
+topk_dense: ONE pass over the database at the HBM rate selects candidates with bf16 MFMA scores (csrc/retrieval_bf16.hip),
+the best K2 ~ 2k candidates per query are re-scored with the canonical k-ordered fp32 fma chain (bit-identical to the
+lane-per-row scan and the oracle) and the exact (value desc, row asc) top-k is taken from them.  The result is proved
+complete on the device from the bf16 error bound |approx - exact| <= (2^-8 + 2^-12) |q| |d| — every row that was not
+re-scored has exact < the k-th kept value — else the call falls back to the exact f32-matrix-core scan
+(topk_dense_exact).  One host synchronisation per call (the proof flag); thresholds and bf16 queries are cached per
+(database, queries) pair.
 """
 import torch
 
@@ -41,7 +47,7 @@ def _thresholds(queries, db, k, sample, boost):
     return val[:, rank - 1].contiguous()
 
 
-def topk_dense(db, queries, k, row_base=0, sample=16384):
+def topk_dense_exact(db, queries, k, row_base=0, sample=16384):
     """-> (idx [n_q, k] int64 global rows (-1 padded), val [n_q, k] fp32, cnt [n_q]) in (value desc, row asc) order."""
     assert db.dtype == torch.float32 and queries.dtype == torch.float32 and k <= CAP
     n, d = db.shape
@@ -69,6 +75,76 @@ def topk_dense(db, queries, k, row_base=0, sample=16384):
     rc = _lib.lib().swat_candidates_topk(_lib.ptr(keys), CAP, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt),
                                          _lib.stream())
     _lib.check(rc, "swat_candidates_topk")
+    return idx, val, out_cnt
+
+
+EPS_BF16 = 2.0 ** -8 + 2.0 ** -12  # two bf16 roundings per product ((1 + 2^-9)^2 - 1) + fp32 accumulation over <= 1024 terms
+_cache = {}
+
+
+def _prepared(db, queries, k, sample):
+    """Per (database, queries, k): pruning thresholds (from a row sample, exact scores), bf16 queries, |q| max, the static
+    index tensors of the re-scoring step.  Keyed on storage + version, so in-place updates invalidate it."""
+    key = (db.data_ptr(), db.shape, db._version, queries.data_ptr(), queries.shape, queries._version, k)
+    hit = _cache.get("key") == key
+    if not hit:
+        nq = queries.shape[0]
+        K2 = min(TOPK2_MAX, max(64, (max(2 * k, k + 256) + 63) // 64 * 64))
+        thr = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)))
+        dev = db.device
+        _cache.clear()
+        _cache.update(key=key, thr=thr, qb=queries.to(torch.bfloat16).contiguous(), qn=queries.norm(dim=1).max(), K2=K2,
+                      row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
+                      off=torch.arange(0, (nq + 1) * K2, K2, device=dev, dtype=torch.int64),
+                      keys=torch.empty((nq, CAP), dtype=torch.int64, device=dev), cnt=torch.zeros(nq, dtype=torch.int32, device=dev),
+                      n2=torch.zeros(1, dtype=torch.float32, device=dev))
+    return _cache
+
+
+TOPK2_MAX = 2048
+BIG = 1 << 62
+last_path = None  # which route the last topk_dense call took (tests, bench.py)
+
+
+def topk_dense(db, queries, k, row_base=0, sample=16384):
+    """-> (idx [n_q, k] int64 global rows (-1 padded), val [n_q, k] fp32, cnt [n_q]) in (value desc, row asc) order;
+    values and indices are those of the exact scan (oracle order), bit for bit."""
+    assert db.dtype == torch.float32 and queries.dtype == torch.float32 and k <= CAP
+    n, d = db.shape
+    nq = queries.shape[0]
+    need = min(k, n)
+    global last_path
+    if 2 * k > TOPK2_MAX or d % 64 != 0:
+        last_path = "exact"
+        return topk_dense_exact(db, queries, k, row_base, sample)
+    c = _prepared(db, queries, k, sample)
+    K2, thr, keys, cnt, n2 = c["K2"], c["thr"], c["keys"], c["cnt"], c["n2"]
+    L = _lib.lib()
+    cnt.zero_()
+    n2.zero_()
+    _lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(thr), int(row_base), _lib.ptr(keys), CAP,
+                                          _lib.ptr(cnt), _lib.ptr(n2), _lib.stream()), "swat_sim_candidates_bf16")
+    dev = db.device
+    idx2 = torch.empty((nq, K2), dtype=torch.int64, device=dev)
+    val2 = torch.empty((nq, K2), dtype=torch.float32, device=dev)
+    cnt2 = torch.empty(nq, dtype=torch.int64, device=dev)
+    _lib.check(L.swat_candidates_topk(_lib.ptr(keys), CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2),
+                                      _lib.stream()), "swat_candidates_topk")
+    # re-score in ascending row order, so that exact ties resolve by global row like the full scan's (value desc, row asc)
+    rows = torch.sort(torch.where(idx2 < 0, BIG, idx2 - row_base), dim=1).values
+    rows = torch.where(rows >= BIG, -1, rows).contiguous()
+    exact = ops.sim_gathered(db, rows.view(-1), queries, c["row_seg"])
+    pos, val, out_cnt = ops.segment_topk(exact, c["off"], k, thr=-3.0e38)
+    idx = torch.where(pos >= 0, rows.view(-1)[pos.clamp_min(0)] + row_base, -1)
+    # completeness, proved on the device: a row that was not re-scored has approx <= bound_q (the K2-th kept approximate
+    # score, or the threshold when fewer than K2 candidates exist), hence exact <= bound_q + delta < the k-th exact value
+    delta = EPS_BF16 * c["qn"] * n2.sqrt()
+    bound = torch.where(cnt.long() >= K2, val2[:, K2 - 1], thr)
+    ok = (out_cnt >= need) & (val[:, need - 1] > bound + delta) & (cnt.long() <= CAP)
+    if not bool(ok.all().item()):  # the one host synchronisation of the call
+        last_path = "exact-fallback"
+        return topk_dense_exact(db, queries, k, row_base, sample)
+    last_path = "bf16-candidates+exact-rescore"
     return idx, val, out_cnt
 
 

@@ -179,6 +179,51 @@ def test_dense_mfma_topk_bit_exact_vs_oracle(n, nq, k):
     assert (idx[:, 1:][ties] > idx[:, :-1][ties]).all()
 
 
+@pytest.mark.parametrize("n,nq,k,scale", [(150001, 200, 500, 1.0), (40000, 37, 100, 1.0), (60000, 64, 256, 3.5), (5000, 10, 20, 1.0)])
+def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale):
+    """topk_dense = bf16 MFMA candidate pass + exact re-scoring + on-device completeness proof: the same (rows, values) as
+    the exact f32-matrix-core scan for EVERY query, duplicates (exact ties) included, with a row_base and with rows that
+    are not unit-norm (the error bound scales with |q| |d|); and the fast route is the one that ran."""
+    from swat_amd.retrieval import dense
+    dev = _dev()
+    rs = np.random.RandomState(n * 7 + nq)
+    db = synth.unit_rows(rs, n, 512) * np.float32(scale)
+    for _ in range(n // 10):
+        a, b = rs.randint(n), rs.randint(n)
+        db[a] = db[b]
+    centres = synth.unit_rows(rs, nq, 512)
+    db[rs.randint(n, size=4 * nq)] += np.repeat(centres, 4, axis=0) * np.float32(0.4)  # a few strong hits per query
+    d_db, d_q = torch.from_numpy(db).to(dev), torch.from_numpy(centres).to(dev)
+    idx, val, cnt = dense.topk_dense(d_db, d_q, k, row_base=1000)
+    assert dense.last_path == "bf16-candidates+exact-rescore"
+    e_idx, e_val, e_cnt = dense.topk_dense_exact(d_db, d_q, k, row_base=1000)
+    assert torch.equal(idx, e_idx) and torch.equal(val, e_val) and torch.equal(cnt, e_cnt)
+    # second call: cached thresholds / bf16 queries, same answer; an in-place change of the queries invalidates the cache
+    idx2, val2, _ = dense.topk_dense(d_db, d_q, k, row_base=1000)
+    assert torch.equal(idx2, idx) and torch.equal(val2, val)
+    d_q.mul_(-1.0)
+    idx3, val3, _ = dense.topk_dense(d_db, d_q, k, row_base=1000)
+    e3_idx, e3_val, _ = dense.topk_dense_exact(d_db, d_q, k, row_base=1000)
+    assert torch.equal(idx3, e3_idx) and torch.equal(val3, e3_val)
+
+
+def test_sim_gathered_is_the_scan_on_a_row_list():
+    from swat_amd.retrieval import ops
+    dev = _dev()
+    rs = np.random.RandomState(4)
+    db = torch.from_numpy(synth.unit_rows(rs, 5000, 512)).to(dev)
+    q = torch.from_numpy(synth.unit_rows(rs, 3, 512)).to(dev)
+    rows = torch.from_numpy(rs.randint(0, 5000, size=3 * 128)).to(dev)
+    rows[5] = -1
+    seg = torch.arange(3, device=dev, dtype=torch.int32).repeat_interleave(128)
+    got = ops.sim_gathered(db, rows, q, seg)
+    for s in range(3):
+        full = ops.similarity_segmented(db, q[s:s + 1].contiguous())
+        r = rows[128 * s:128 * (s + 1)]
+        want = torch.where(r >= 0, full[r.clamp_min(0)], torch.tensor(float("-inf"), device=dev))
+        assert torch.equal(got[128 * s:128 * (s + 1)], want)
+
+
 @pytest.mark.parametrize("kind", ["grid", "float"])
 def test_near_dup_matches_reference_golden(golden_dir, kind):
     from swat_amd.retrieval import SegmentedIndex, dense

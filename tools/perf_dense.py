@@ -1,0 +1,62 @@
+"""Dev tool: the dense (N_query x N_db) top-k of BASELINE config 4 on one shard, stage by stage (HIP events)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from swat_amd import _lib
+from swat_amd.retrieval import dense, ops
+dev = torch.device("cuda:0"); L = _lib.lib()
+n, d, nq, k = int(os.environ.get("N", 1_250_000)), 512, int(os.environ.get("NQ", 200)), 500
+g = torch.Generator(device=dev).manual_seed(7)
+db = torch.randn(n, d, device=dev, generator=g); db /= db.norm(dim=-1, keepdim=True)
+q = torch.randn(nq, d, device=dev, generator=g); q /= q.norm(dim=-1, keepdim=True)
+def ev(): return torch.cuda.Event(enable_timing=True)
+dense.topk_dense(db, q, k); torch.cuda.synchronize()
+print("route:", dense.last_path, "| SWAT_DENSE_NF =", os.environ.get("SWAT_DENSE_NF", "1"))
+c = dense._cache
+for rep in range(3):
+    a, b = ev(), ev()
+    a.record()
+    for _ in range(5): dense.topk_dense(db, q, k)
+    b.record(); torch.cuda.synchronize()
+    tot = a.elapsed_time(b) / 5
+    c["cnt"].zero_(); c["n2"].zero_()
+    a, b = ev(), ev(); a.record()
+    for _ in range(5):
+        _lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(c["thr"]), 0, _lib.ptr(c["keys"]), dense.CAP,
+                                              _lib.ptr(c["cnt"]), _lib.ptr(c["n2"]), _lib.stream()), "cand")
+    b.record(); torch.cuda.synchronize()
+    tc = a.elapsed_time(b) / 5
+    print(f"pass {tot:.3f} ms = {nq / tot * 1e3:,.0f} queries/s; candidate kernel {tc:.3f} ms = {n * d * 4 / tc / 1e6:.0f} GB/s "
+          f"({n * d * 4 / tc / 1e6 / 8000:.3f} of 8 TB/s), whole pass {n * d * 4 / tot / 1e6 / 8000:.3f} of 8 TB/s; "
+          f"candidates per query {c['cnt'].float().mean().item() / 5:.0f} (min {c['cnt'].min().item() // 5}), max |d| {c['n2'].sqrt().item():.4f}")
+a, b = ev(), ev(); a.record()
+dense.topk_dense_exact(db, q, k)
+b.record(); torch.cuda.synchronize()
+print(f"exact f32-matrix-core scan: {a.elapsed_time(b):.3f} ms")
+# ---- stage breakdown of one pass (events between the stages of dense.topk_dense) ----
+K2, thr, keys, cnt, n2 = c["K2"], c["thr"], c["keys"], c["cnt"], c["n2"]
+marks = [ev() for _ in range(8)]
+torch.cuda.synchronize()
+marks[0].record()
+cnt.zero_(); n2.zero_()
+_lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(thr), 0, _lib.ptr(keys), dense.CAP, _lib.ptr(cnt), _lib.ptr(n2), _lib.stream()), "cand")
+marks[1].record()
+idx2 = torch.empty((nq, K2), dtype=torch.int64, device=dev); val2 = torch.empty((nq, K2), dtype=torch.float32, device=dev); cnt2 = torch.empty(nq, dtype=torch.int64, device=dev)
+_lib.check(L.swat_candidates_topk(_lib.ptr(keys), dense.CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2), _lib.stream()), "ctk")
+marks[2].record()
+rows = torch.sort(torch.where(idx2 < 0, dense.BIG, idx2), dim=1).values
+rows = torch.where(rows >= dense.BIG, -1, rows).contiguous()
+marks[3].record()
+exact = ops.sim_gathered(db, rows.view(-1), q, c["row_seg"])
+marks[4].record()
+pos, val, out_cnt = ops.segment_topk(exact, c["off"], k, thr=-3.0e38)
+marks[5].record()
+idx = torch.where(pos >= 0, rows.view(-1)[pos.clamp_min(0)], -1)
+delta = dense.EPS_BF16 * c["qn"] * n2.sqrt()
+bound = torch.where(cnt.long() >= K2, val2[:, K2 - 1], thr)
+ok = (out_cnt >= k) & (val[:, k - 1] > bound + delta) & (cnt.long() <= dense.CAP)
+marks[6].record()
+flag = bool(ok.all().item())
+marks[7].record(); torch.cuda.synchronize()
+names = ["candidates (bf16 MFMA scan)", "candidates_topk (sort, top K2)", "torch sort rows", "sim_gathered (exact re-score)", "segment_topk", "torch glue + proof", "item()"]
+print(f"K2 = {K2}; " + "; ".join(f"{nme} {marks[i].elapsed_time(marks[i + 1]):.3f}" for i, nme in enumerate(names)) + f"  (ms); complete: {flag}")

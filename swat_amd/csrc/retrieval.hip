@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
                                                             const float* __restrict__ queries,
                                                             const int32_t* __restrict__ row_seg,
                                                             float* __restrict__ sims,
-                                                            const int64_t* __restrict__ row_index) {
+                                                            const int64_t* __restrict__ row_index,
+                                                            unsigned long long* __restrict__ keys_out, int64_t row_base) {
     __shared__ float4 smem[4 * 64 * ROW_F4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
         int64_t r = row0 + 4 * j + lr;
         r = r < last ? r : last;
         if constexpr (GATHER) {
-            r = row_index[r];
+            r = row_index[r] - row_base;  // the list holds global rows (row_base + local), negative = padding
             r = r < 0 ? 0 : r;
         }
         src[j] = feats + r * (int64_t)d + slot * 4;
@@ -108,9 +109,39 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
         __builtin_amdgcn_wave_barrier();
     }
     if constexpr (GATHER) {
-        if (row0 + lane < n_rows && row_index[row0 + lane] < 0) acc = -INFINITY;
+        if (row0 + lane < n_rows) {
+            const int64_t gr = row_index[row0 + lane];
+            if (gr < 0) acc = -INFINITY;
+            if (sims) sims[row0 + lane] = acc;
+            // (value desc, global row asc) sort key of the dense top-k (csrc/retrieval_mfma.hip: candidates_topk_kernel); 0 sorts last
+            if (keys_out) {
+                float sv = acc == 0.0f ? 0.0f : acc;
+                const uint32_t u = __float_as_uint(sv);
+                const uint32_t o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                keys_out[row0 + lane] = gr < 0 ? 0ull : (((unsigned long long)o << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)gr));
+            }
+        }
+        return;
     }
     if (row0 + lane < n_rows) sims[row0 + lane] = acc;
+}
+
+// Completeness proof of the dense top-k (swat_amd/retrieval/dense.py): query q passes iff it kept `need` rows, no candidate
+// list overflowed and its need-th exact value is strictly above bound_q + delta, bound_q = the K2-th best approximate score
+// (or the pruning threshold when fewer than K2 candidates exist), delta = eps |q|max |d|max.  fails[0] += failing queries.
+__global__ void dense_proof_kernel(const unsigned* __restrict__ cand_cnt, int cap, int K2, const float* __restrict__ approx_val,
+                                   const float* __restrict__ thr, const float* __restrict__ exact_val, int k,
+                                   const int64_t* __restrict__ out_cnt, int need, float eps_qn, const float* __restrict__ max_norm2,
+                                   int n_q, int* __restrict__ fails) {
+    const float delta = eps_qn * sqrtf(max_norm2[0]);
+    int bad = 0;
+    for (int q = threadIdx.x; q < n_q; q += blockDim.x) {
+        const unsigned c = cand_cnt[q];
+        const float bound = c >= (unsigned)K2 ? approx_val[(int64_t)q * K2 + K2 - 1] : thr[q];
+        const bool ok = out_cnt[q] >= need && c <= (unsigned)cap && exact_val[(int64_t)q * k + need - 1] > bound + delta;
+        bad += ok ? 0 : 1;
+    }
+    if (bad) atomicAdd(fails, bad);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -254,20 +285,31 @@ SWAT_API int swat_sim_segmented(const float* feats, int64_t n_rows, int d, const
     const int64_t blocks = (n_rows + 255) / 256;
     SWAT_REQUIRE(blocks < (1ll << 31), "swat_sim_segmented: too many rows for one launch");
     hipLaunchKernelGGL(swat::sim_segmented_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, feats,
-                       n_rows, d, queries, row_seg, sims, (const int64_t*)nullptr);
+                       n_rows, d, queries, row_seg, sims, (const int64_t*)nullptr, (unsigned long long*)nullptr, (int64_t)0);
     return swat::check_launch("swat_sim_segmented");
 }
 
 SWAT_API int swat_sim_gathered(const float* feats, const int64_t* row_index, int64_t n_idx, int d, const float* queries,
-                               const int32_t* row_seg, float* sims, swat_stream_t stream) {
+                               const int32_t* row_seg, float* sims, void* keys_out, int64_t row_base, swat_stream_t stream) {
     SWAT_REQUIRE(d > 0 && d % swat::KC == 0, "swat_sim_gathered: d=%d must be a positive multiple of %d", d, swat::KC);
     if (n_idx <= 0) return 0;
-    SWAT_REQUIRE(feats && row_index && queries && sims, "swat_sim_gathered: null pointer");
+    SWAT_REQUIRE(feats && row_index && queries && (sims || keys_out), "swat_sim_gathered: null pointer");
     const int64_t blocks = (n_idx + 255) / 256;
     SWAT_REQUIRE(blocks < (1ll << 31), "swat_sim_gathered: too many rows for one launch");
     hipLaunchKernelGGL(swat::sim_segmented_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, feats,
-                       n_idx, d, queries, row_seg, sims, row_index);
+                       n_idx, d, queries, row_seg, sims, row_index, (unsigned long long*)keys_out, row_base);
     return swat::check_launch("swat_sim_gathered");
+}
+
+SWAT_API int swat_dense_topk_proof(const void* cand_cnt, int cap, int K2, const float* approx_val, const float* thr_dev,
+                                   const float* exact_val, int k, const int64_t* out_cnt, int need, float eps_qnorm,
+                                   const float* max_norm2, int n_q, int* fails, swat_stream_t stream) {
+    SWAT_REQUIRE(cand_cnt && approx_val && thr_dev && exact_val && out_cnt && max_norm2 && fails, "swat_dense_topk_proof: null pointer");
+    SWAT_REQUIRE(n_q > 0 && need >= 1 && need <= k && K2 >= 1, "swat_dense_topk_proof: bad sizes");
+    SWAT_HIP(hipMemsetAsync(fails, 0, sizeof(int), (hipStream_t)stream));
+    hipLaunchKernelGGL(swat::dense_proof_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const unsigned*)cand_cnt, cap, K2,
+                       approx_val, thr_dev, exact_val, k, out_cnt, need, eps_qnorm, max_norm2, n_q, fails);
+    return swat::check_launch("swat_dense_topk_proof");
 }
 
 SWAT_API int swat_segment_topk(const float* sims, const float* t2i, const uint8_t* excluded,

@@ -16,6 +16,14 @@
 // ahead of the MFMAs.  Query chunks [16 NQT][64] bf16 (L2-resident, 213 KB per 128-row block) go global -> LDS by
 // LDS-DMA into two buffers with the 16-B-slot XOR of the GEMM's k-contiguous image (gemm_device.hpp: kc_off).
 // Workgroups walk blocks b, b + grid, ...; the chunk stream is continuous across blocks.
+//
+// Measured (MI355X, 200 queries x 1.25 M rows, tools/perf_dense.py): 0.80 ms = 3.2 TB/s for this kernel (0.40 of the 8 TB/s
+// peak; 4.8 TB/s with 32 queries), 1.05 ms for the whole exact top-k (re-scoring, two sorts, proof: 0.21 ms) against
+// 3.6 ms for the f32-matrix-core scan.  What bounds it: one 64-deep chunk per wave in flight (12 waves x 4 KB per CU) against
+// the HBM latency; deeper register rings do not compose with the per-step LDS-DMA of the query chunk (vmcnt completes in
+// order, so waiting for the newest query piece drains every older database load).  Tried and dropped: two fragments per
+// wave (128-row blocks, 2 workgroups per CU: 1.00 ms), a fifth wave touching the database 8 / 16 steps ahead with LDS-DMA
+// sector loads (1.27 ms: the extra wave costs a workgroup of residency and the touches did not shorten the loads).
 #include <stdlib.h>
 #include "common.hpp"
 #include "../../include/swat_hip.h"
@@ -197,10 +205,10 @@ SWAT_API int swat_sim_candidates_bf16(const void* queries_bf16, int n_q, const f
     SWAT_REQUIRE(row_base + n_db < (1ll << 32), "swat_sim_candidates_bf16: global rows must fit 32 bits");
     SWAT_REQUIRE((int64_t)n_q * d < (1ll << 30), "swat_sim_candidates_bf16: query matrix too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)s;
-    static int variant = -1;  // SWAT_DENSE_NF=2: two 16-row fragments per wave (128-row blocks, 2 workgroups per CU)
+    static int variant = -1;  // tuning (SWAT_DENSE_VARIANT): 1 = one 16-row fragment per wave, 3 workgroups per CU (default); 2 = two fragments, 2 per CU
     if (variant < 0) {
-        const char* e = getenv("SWAT_DENSE_NF");
-        variant = (e && atoi(e) == 2) ? 2 : 1;
+        const char* e = getenv("SWAT_DENSE_VARIANT");
+        variant = e ? atoi(e) : 1;
     }
 #define SWAT_CAND(NQT_, NF_, MAXG_)                                                                                      \
     {                                                                                                                    \

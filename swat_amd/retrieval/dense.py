@@ -93,9 +93,11 @@ def _prepared(db, queries, k, sample):
         thr = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)))
         dev = db.device
         _cache.clear()
-        _cache.update(key=key, thr=thr, qb=queries.to(torch.bfloat16).contiguous(), qn=queries.norm(dim=1).max(), K2=K2,
+        _cache.update(key=key, thr=thr, qb=queries.to(torch.bfloat16).contiguous(), qn=float(queries.norm(dim=1).max().item()), K2=K2,
                       row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
-                      off=torch.arange(0, (nq + 1) * K2, K2, device=dev, dtype=torch.int64),
+                      idx2=torch.empty((nq, K2), dtype=torch.int64, device=dev), val2=torch.empty((nq, K2), dtype=torch.float32, device=dev),
+                      cnt2=torch.empty(nq, dtype=torch.int64, device=dev), keys2=torch.empty((nq, K2), dtype=torch.int64, device=dev),
+                      fails=torch.zeros(1, dtype=torch.int32, device=dev),
                       keys=torch.empty((nq, CAP), dtype=torch.int64, device=dev), cnt=torch.zeros(nq, dtype=torch.int32, device=dev),
                       n2=torch.zeros(1, dtype=torch.float32, device=dev))
     return _cache
@@ -124,24 +126,23 @@ def topk_dense(db, queries, k, row_base=0, sample=16384):
     n2.zero_()
     _lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(thr), int(row_base), _lib.ptr(keys), CAP,
                                           _lib.ptr(cnt), _lib.ptr(n2), _lib.stream()), "swat_sim_candidates_bf16")
-    dev = db.device
-    idx2 = torch.empty((nq, K2), dtype=torch.int64, device=dev)
-    val2 = torch.empty((nq, K2), dtype=torch.float32, device=dev)
-    cnt2 = torch.empty(nq, dtype=torch.int64, device=dev)
+    idx2, val2, cnt2, keys2 = c["idx2"], c["val2"], c["cnt2"], c["keys2"]
     _lib.check(L.swat_candidates_topk(_lib.ptr(keys), CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2),
                                       _lib.stream()), "swat_candidates_topk")
-    # re-score in ascending row order, so that exact ties resolve by global row like the full scan's (value desc, row asc)
-    rows = torch.sort(torch.where(idx2 < 0, BIG, idx2 - row_base), dim=1).values
-    rows = torch.where(rows >= BIG, -1, rows).contiguous()
-    exact = ops.sim_gathered(db, rows.view(-1), queries, c["row_seg"])
-    pos, val, out_cnt = ops.segment_topk(exact, c["off"], k, thr=-3.0e38)
-    idx = torch.where(pos >= 0, rows.view(-1)[pos.clamp_min(0)] + row_base, -1)
+    # exact value of the K2 best approximate rows of every query, as (value desc, global row asc) sort keys
+    ops.sim_gathered(db, idx2.view(-1), queries, c["row_seg"], keys_out=keys2, row_base=row_base, want_sims=False)
+    dev = db.device
+    idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    val = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_cnt = torch.empty(nq, dtype=torch.int64, device=dev)
+    _lib.check(L.swat_candidates_topk(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt),
+                                      _lib.stream()), "swat_candidates_topk")
     # completeness, proved on the device: a row that was not re-scored has approx <= bound_q (the K2-th kept approximate
     # score, or the threshold when fewer than K2 candidates exist), hence exact <= bound_q + delta < the k-th exact value
-    delta = EPS_BF16 * c["qn"] * n2.sqrt()
-    bound = torch.where(cnt.long() >= K2, val2[:, K2 - 1], thr)
-    ok = (out_cnt >= need) & (val[:, need - 1] > bound + delta) & (cnt.long() <= CAP)
-    if not bool(ok.all().item()):  # the one host synchronisation of the call
+    _lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), need,
+                                       float(EPS_BF16 * c["qn"]), _lib.ptr(n2), nq, _lib.ptr(c["fails"]), _lib.stream()),
+               "swat_dense_topk_proof")
+    if c["fails"].item() != 0:  # the one host synchronisation of the call
         last_path = "exact-fallback"
         return topk_dense_exact(db, queries, k, row_base, sample)
     last_path = "bf16-candidates+exact-rescore"

@@ -21,16 +21,17 @@ def similarity_segmented(feats, queries, row_seg=None, out=None):
     return out
 
 
-def sim_gathered(feats, row_index, queries, row_seg, out=None):
-    """sims[r] = <feats[row_index[r]], queries[row_seg[r]]> — the same k-ordered fp32 fma chain as similarity_segmented on a
-    row list (row_index[r] < 0 -> -inf): the exact re-scoring of the dense scan's candidates."""
+def sim_gathered(feats, row_index, queries, row_seg, out=None, keys_out=None, row_base=0, want_sims=True):
+    """s_r = <feats[row_index[r] - row_base], queries[row_seg[r]]> — the same k-ordered fp32 fma chain as
+    similarity_segmented on a row list (row_index[r] < 0 -> -inf): the exact re-scoring of the dense scan's candidates.
+    keys_out (int64 [n]): (value desc, row asc) sort keys for swat_candidates_topk."""
     assert feats.dtype == torch.float32 and queries.dtype == torch.float32 and row_index.dtype == torch.int64
     assert row_seg.dtype == torch.int32 and row_seg.numel() == row_index.numel()
     n = row_index.numel()
-    if out is None:
+    if out is None and want_sims:
         out = torch.empty(n, dtype=torch.float32, device=feats.device)
     rc = _lib.lib().swat_sim_gathered(_lib.ptr(feats), _lib.ptr(row_index), n, feats.shape[1], _lib.ptr(queries), _lib.ptr(row_seg),
-                                      _lib.ptr(out), _lib.stream())
+                                      _lib.ptr(out), _lib.ptr(keys_out), int(row_base), _lib.stream())
     _lib.check(rc, "swat_sim_gathered")
     return out
 

@@ -11,7 +11,7 @@ db = torch.randn(n, d, device=dev, generator=g); db /= db.norm(dim=-1, keepdim=T
 q = torch.randn(nq, d, device=dev, generator=g); q /= q.norm(dim=-1, keepdim=True)
 def ev(): return torch.cuda.Event(enable_timing=True)
 dense.topk_dense(db, q, k); torch.cuda.synchronize()
-print("route:", dense.last_path, "| SWAT_DENSE_NF =", os.environ.get("SWAT_DENSE_NF", "1"))
+print("route:", dense.last_path, "| SWAT_DENSE_VARIANT =", os.environ.get("SWAT_DENSE_VARIANT", "1"))
 c = dense._cache
 for rep in range(3):
     a, b = ev(), ev()
@@ -35,28 +35,23 @@ b.record(); torch.cuda.synchronize()
 print(f"exact f32-matrix-core scan: {a.elapsed_time(b):.3f} ms")
 # ---- stage breakdown of one pass (events between the stages of dense.topk_dense) ----
 K2, thr, keys, cnt, n2 = c["K2"], c["thr"], c["keys"], c["cnt"], c["n2"]
-marks = [ev() for _ in range(8)]
+idx2, val2, cnt2, keys2 = c["idx2"], c["val2"], c["cnt2"], c["keys2"]
+marks = [ev() for _ in range(7)]
 torch.cuda.synchronize()
 marks[0].record()
 cnt.zero_(); n2.zero_()
 _lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(thr), 0, _lib.ptr(keys), dense.CAP, _lib.ptr(cnt), _lib.ptr(n2), _lib.stream()), "cand")
 marks[1].record()
-idx2 = torch.empty((nq, K2), dtype=torch.int64, device=dev); val2 = torch.empty((nq, K2), dtype=torch.float32, device=dev); cnt2 = torch.empty(nq, dtype=torch.int64, device=dev)
 _lib.check(L.swat_candidates_topk(_lib.ptr(keys), dense.CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2), _lib.stream()), "ctk")
 marks[2].record()
-rows = torch.sort(torch.where(idx2 < 0, dense.BIG, idx2), dim=1).values
-rows = torch.where(rows >= dense.BIG, -1, rows).contiguous()
+ops.sim_gathered(db, idx2.view(-1), q, c["row_seg"], keys_out=keys2, want_sims=False)
 marks[3].record()
-exact = ops.sim_gathered(db, rows.view(-1), q, c["row_seg"])
+idx = torch.empty((nq, k), dtype=torch.int64, device=dev); val = torch.empty((nq, k), dtype=torch.float32, device=dev); out_cnt = torch.empty(nq, dtype=torch.int64, device=dev)
+_lib.check(L.swat_candidates_topk(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt), _lib.stream()), "ctk2")
 marks[4].record()
-pos, val, out_cnt = ops.segment_topk(exact, c["off"], k, thr=-3.0e38)
+_lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), k, float(dense.EPS_BF16 * c["qn"]), _lib.ptr(n2), nq, _lib.ptr(c["fails"]), _lib.stream()), "proof")
 marks[5].record()
-idx = torch.where(pos >= 0, rows.view(-1)[pos.clamp_min(0)], -1)
-delta = dense.EPS_BF16 * c["qn"] * n2.sqrt()
-bound = torch.where(cnt.long() >= K2, val2[:, K2 - 1], thr)
-ok = (out_cnt >= k) & (val[:, k - 1] > bound + delta) & (cnt.long() <= dense.CAP)
-marks[6].record()
-flag = bool(ok.all().item())
-marks[7].record(); torch.cuda.synchronize()
-names = ["candidates (bf16 MFMA scan)", "candidates_topk (sort, top K2)", "torch sort rows", "sim_gathered (exact re-score)", "segment_topk", "torch glue + proof", "item()"]
-print(f"K2 = {K2}; " + "; ".join(f"{nme} {marks[i].elapsed_time(marks[i + 1]):.3f}" for i, nme in enumerate(names)) + f"  (ms); complete: {flag}")
+flag = c["fails"].item()
+marks[6].record(); torch.cuda.synchronize()
+names = ["candidates (bf16 MFMA scan)", "candidates_topk (approx, top K2)", "sim_gathered (exact re-score -> keys)", "candidates_topk (exact, top k)", "proof", "item()"]
+print(f"K2 = {K2}; " + "; ".join(f"{nme} {marks[i].elapsed_time(marks[i + 1]):.3f}" for i, nme in enumerate(names)) + f"  (ms); failing queries: {flag}")

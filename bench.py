@@ -101,10 +101,10 @@ def gemm_roofline(args, step, sched, images, labels, n_steps, bsz, overlap=1):
     per_kind = {names[i]: {"launches_per_step": cnt[i] / n_steps, "avg_us": (1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0,
                            "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0} for i in range(9) if cnt[i]}
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")
     if os.path.exists(tpath):  # PMC passes cannot run inside this process: the committed rocprofv3 --pmc result of this command
         traffic = round(json.load(open(tpath))["hbm_bytes_per_gemm_launch"])
-        traffic_src = "profiles/r01_gemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per GEMM launch)"
+        traffic_src = "profiles/r02_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes, mean bytes per GEMM launch)"
     return {"bound": "mfma", "kernel": "gemm_pc_kernel / gemm_dma_kernel / gemm_ring2_kernel / gemm_ring_kernel (all GEMM instantiations)",
             "achieved": round(achieved, 2),
             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -146,57 +146,146 @@ def cpu_baseline(bsz=32, n_cls=200, budget_s=20.0):
             "sample": f"{n} steps of the fp32 oracle (oracle/vit_oracle.py, torch CPU) at B={bsz}, ViT-B/32, after 1 warm-up"}
 
 
-def retrieval_secondary(dev, steps=5):
-    """Path B on one shard (1.25 M x 512 fp32 = the per-GPU share of 10 M rows): T2T-rank + T2I-threshold sampler,
-    1000 class queries, k = 500.  HBM roofline of the similarity scan (2048 B/row/matrix)."""
-    from swat_amd.retrieval import ops
-    n, d, nseg, k = 1_250_000, 512, 1000, 500
+def _unit(x):
+    return x.div_(x.norm(dim=-1, keepdim=True))
+
+
+def retrieval_shard(dev, n, d, nseg, rank=0):
+    """One rank's synthetic shard of the class-grouped index: n rows in nseg equal class segments.  Queries come from
+    seed 7 (the same on every rank), rows from seed 7 + rank.  Rows are prompt-correlated the way mined LAION rows are:
+    caption features cos(q, cap) spread over ~[0, 0.62] (all above the T2T threshold 0), image features cos(q, img)
+    over ~[0, 0.48] with the median near the reference's T2I threshold 0.25, so about half of every class passes it."""
     g = torch.Generator(device=dev).manual_seed(7)
-    cap = torch.randn(n, d, device=dev, generator=g)
-    cap /= cap.norm(dim=-1, keepdim=True)
-    img = torch.randn(n, d, device=dev, generator=g)
-    img /= img.norm(dim=-1, keepdim=True)
-    q = torch.randn(nseg, d, device=dev, generator=g)
-    q /= q.norm(dim=-1, keepdim=True)
+    q = _unit(torch.randn(nseg, d, device=dev, generator=g))
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
     per = n // nseg
-    off = torch.arange(0, n + 1, per, device=dev, dtype=torch.int64)
     row_seg = torch.repeat_interleave(torch.arange(nseg, device=dev, dtype=torch.int32), per)
+    off = torch.arange(0, n + 1, per, device=dev, dtype=torch.int64)
+
+    def rows(hi):
+        x = torch.randn(n, d, device=dev, generator=g).mul_(d ** -0.5)
+        a = torch.rand(n, 1, device=dev, generator=g).mul_(hi)
+        for lo in range(0, n, 1 << 18):  # q[row_seg] in slices: no second n x d temporary
+            x[lo:lo + (1 << 18)].addcmul_(q[row_seg[lo:lo + (1 << 18)].long()], a[lo:lo + (1 << 18)])
+        return _unit(x)
+    return rows(0.8), rows(0.55), q, off, row_seg
+
+
+def _set_omp_threads(n):
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+
+
+def retrieval_cpu_baseline(cap, img, q, off, k, gpu_idx, gpu_cnt):
+    """oracle/retrieval_oracle.c (the reference's per-class GEMV + stable sort + filter walk, canonical fp32 order) on the
+    host cores over the WHOLE shard — all cores, then one thread — and the check that the GPU lists are the oracle's."""
+    from oracle import retrieval_oracle as orc
+    cores = orc.num_threads()
+    h = [t.cpu().numpy() for t in (cap, img, q, off)]
+    nseg = q.shape[0]
+    t0 = time.perf_counter()
+    idx, cnt = orc.sample_index(h[0], h[1], h[2], h[3], k, thr=0.0, t2i_thr=0.25, use_t2i_thr=True)
+    t_all = time.perf_counter() - t0
+    same = bool((idx == gpu_idx.cpu().numpy()).all() and (cnt == gpu_cnt.cpu().numpy()).all())
+    sub = max(1, nseg // 8)
+    _set_omp_threads(1)
+    t0 = time.perf_counter()
+    orc.sample_index(h[0], h[1], h[2][:sub], h[3][:sub + 1], k, thr=0.0, t2i_thr=0.25, use_t2i_thr=True)
+    t_one = (time.perf_counter() - t0) * nseg / sub
+    _set_omp_threads(cores)
+    return {"value": round(nseg / t_all, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"the whole shard ({cap.shape[0]} rows x 2 matrices, {nseg} class queries), one pass of oracle/retrieval_oracle.c "
+                      "orc_sample_index (OpenMP over classes)",
+            "one_thread": {"value": round(nseg / t_one, 1), "unit": "queries/s", "cores": 1,
+                           "sample": f"first {sub} classes on one thread, scaled x{nseg / sub:g} (classes are independent and equal-sized)"},
+            "gpu_lists_equal_oracle": same}
+
+
+def retrieval_secondary(dev, rank=0, world=1, d=512, steps=5, with_cpu=True):
+    """Path B on one shard per GPU (1.25 M x d fp32 = the per-GPU share of 10 M rows): T2T-rank + T2I-threshold (0.25)
+    sampler, 1000 class queries, k = 500.  N > 1: every rank scans its own shard (rows of all classes), one all_gather of
+    the [1000, 500] lists and a k-way merge finish the query (retrieval/shard.py) — weak scaling, N x 1.25 M rows.
+    HBM roofline of the similarity scan (4 d B/row/matrix)."""
+    from swat_amd.retrieval import ops, shard
+    n, nseg, k = 1_250_000, 1000, 500
+    cap, img, q, off, row_seg = retrieval_shard(dev, n, d, nseg, rank)
     s1 = torch.empty(n, device=dev)
     s2 = torch.empty(n, device=dev)
 
     def once():
         ops.similarity_segmented(cap, q, row_seg, out=s1)
         ops.similarity_segmented(img, q, row_seg, out=s2)
-        return ops.segment_topk(s1, off, k, thr=0.0, t2i=s2, t2i_thr=0.0)
+        idx, val, cnt = ops.segment_topk(s1, off, k, thr=0.0, t2i=s2, t2i_thr=0.25)
+        if world > 1:
+            gidx = torch.where(idx >= 0, idx + rank * n, idx)
+            return shard.gather_and_merge(gidx, val, k)
+        return idx, val, cnt
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     once()
-    torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        idx, val, cnt = once()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_all = dt / steps * 1e3
     e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     e[0].record()
     for _ in range(steps):
-        once()
+        ops.similarity_segmented(cap, q, row_seg, out=s1)
     e[1].record()
     e[2].record()
     for _ in range(steps):
-        ops.similarity_segmented(cap, q, row_seg, out=s1)
+        ops.segment_topk(s1, off, k, thr=0.0, t2i=s2, t2i_thr=0.25)
     e[3].record()
     torch.cuda.synchronize()
-    ms_all = e[0].elapsed_time(e[1]) / steps
-    ms_sim = e[2].elapsed_time(e[3]) / steps
+    ms_sim = e[0].elapsed_time(e[1]) / steps
+    ms_topk = e[2].elapsed_time(e[3]) / steps
     gbs = n * d * 4 / 1e9 / (ms_sim * 1e-3)
-    return {"metric": "retrieval top-k queries/s (T2T-rank-T2I-tshd, per-class queries)", "value": round(nseg / (ms_all * 1e-3), 1),
-            "unit": "queries/s", "config": {"workload": f"{n} x {d} fp32 rows x 2 matrices, {nseg} class segments, k={k}"},
-            "ms_per_pass": round(ms_all, 3),
-            "roofline": {"bound": "hbm", "kernel": "sim_segmented_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(ms_sim, 4)}}
+    passing = float((s2 > 0.25).float().mean().item())
+    rec = {"metric": "retrieval top-k queries/s (T2T-rank-T2I-tshd, per-class queries)", "value": round(nseg / (ms_all * 1e-3), 1),
+           "unit": "queries/s", "n_gpus": world, "scaling": "weak", "dtype": "f32",
+           "config": {"workload": f"{world} x {n} x {d} fp32 rows x 2 matrices (caption + image features), {nseg} class queries, k={k}, "
+                                  f"thr=0.0, t2i_thr=0.25 (synthetic T2I cosines straddle it: {100 * passing:.0f} % of the {n // nseg} rows of a class pass)"
+                                  + (", all_gather + k-way merge of the per-rank lists" if world > 1 else "")},
+           "ms_per_pass": round(ms_all, 3), "ms_segment_topk": round(ms_topk, 4),
+           "roofline": {"bound": "hbm", "kernel": "sim_segmented_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("sim_segmented_kernel", d),
+                        "algorithmic_bytes_per_launch": n * d * 4, "avg_ms": round(ms_sim, 4),
+                        "pass_frac": round(2 * n * d * 4 / 1e9 / (ms_all * 1e-3) / HBM_PEAK_GBS, 4)}}
+    if with_cpu and world == 1:
+        rec["cpu_baseline"] = retrieval_cpu_baseline(cap, img, q, off, k, idx, cnt)
+    return rec
 
 
-def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=10, warmup=4):
-    """The same fused step on another BASELINE config (configs[2] ViT-B/16, configs[4] ViT-L/14), one GPU, B = 32."""
-    args, model, head, step, sched = build_job(dev, 1, bsz, arch=arch)
+def _pmc_traffic(kernel, d=512):
+    """HBM bytes per launch of a retrieval kernel from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh;
+    counters cannot be collected inside this process).  None when the profile is absent or was taken at another d."""
+    p = os.path.join(ROOT, "profiles", "r02_retrieval_pmc.json")
+    if not os.path.exists(p) or d != 512:
+        return None
+    recs = [v for n, v in json.load(open(p)).items() if n.startswith(kernel) and isinstance(v, dict)]
+    return round(max(r["hbm_bytes_per_launch"] for r in recs)) if recs else None  # the shard scan is the largest launch of its kernel
+
+
+_ARCH_CLASSES = {"ViT-B-16": 200, "ViT-L-14": 1000}  # semi-aves; ImageNet (BASELINE configs[5], SURVEY §8(d))
+
+
+def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=20, warmup=5):
+    """The same fused step on another BASELINE config (ViT-B/16 semi-aves; ViT-L/14 ImageNet, C = 1000), one GPU, B = 32."""
+    n_cls = _ARCH_CLASSES[arch]
+    args, model, head, step, sched = build_job(dev, 1, bsz, n_cls=n_cls, arch=arch)
     g = torch.Generator(device=dev).manual_seed(4321)
     images = torch.randn(bsz, 3, 224, 224, device=dev, generator=g)
-    labels = torch.randint(0, 200, (bsz,), device=dev, generator=g)
+    labels = torch.randint(0, n_cls, (bsz,), device=dev, generator=g)
     run_steps(args, step, sched, images, labels, warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -207,7 +296,7 @@ def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=10, warmup=4):
     del step, model, head
     return {"metric": f"finetune img/s ({arch} bsz={bsz})", "value": round(bsz / dt, 1), "unit": "img/s",
             "ms_per_step": round(dt * 1e3, 3), "steps": steps,
-            "config": {"workload": f"{arch} (random init) --method cutmix finetune step, 200 classes, one GPU"},
+            "config": {"workload": f"{arch} (random init) --method cutmix finetune step, {n_cls} classes, one GPU"},
             "step_mfma_frac": round(gflop_per_img * 1e9 * bsz / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "algorithmic_gflop_per_img": gflop_per_img}
 
@@ -227,29 +316,113 @@ def finetune_secondary_subprocess(arch):
     return json.loads(lines[-1])
 
 
-def retrieval_dense_secondary(dev, steps=3):
-    """BASELINE config 4 on one shard: N_query = 200 random unit queries against 1.25 M x 512 fp32 rows (the per-GPU share
-    of 10 M), k = 500, exact (value desc, row asc) top-k on the fp32 matrix cores (157.3 TF peak)."""
+def dense_cpu_baseline(db, q, k, gpu_idx, gpu_val, budget_rows=250_000):
+    """oracle/retrieval_oracle.c orc_topk_multi on a bounded row slice (Nq = 200 all cores, Nq = 200 one thread on a
+    smaller slice, Nq = 1 over the whole shard) and the reference's own formulation on the host (torch `@` + stable
+    descending sort, BLAS order — not bit-ordered) on the same slice.  Rates are scaled linearly in rows to the shard."""
+    from oracle import retrieval_oracle as orc
+    cores = orc.num_threads()
+    n, nq = db.shape[0], q.shape[0]
+    hdb, hq = db[:budget_rows].cpu().numpy(), q.cpu().numpy()
+    ns = hdb.shape[0]
+    t0 = time.perf_counter()
+    oi, ov = orc.topk_multi(hdb, hq, k)
+    t_all = (time.perf_counter() - t0) * n / ns
+    # check: the GPU top-k of the same slice is the oracle's, bit for bit
     from swat_amd.retrieval import dense
+    gi, gv, _ = dense.topk_dense(db[:ns].contiguous(), q, k)
+    same = bool((gi.cpu().numpy() == oi).all() and (gv.cpu().numpy().view(np.uint32) == ov.view(np.uint32)).all())
+    _set_omp_threads(1)
+    n1 = max(k, ns // 20)
+    t0 = time.perf_counter()
+    orc.topk_multi(hdb[:n1], hq, k)
+    t_one = (time.perf_counter() - t0) * n / n1
+    _set_omp_threads(cores)
+    full = db.cpu().numpy()
+    t0 = time.perf_counter()
+    orc.topk_multi(full, hq[:1], k)
+    t_q1 = time.perf_counter() - t0
+    del full
+    tdb, tq = torch.from_numpy(hdb), torch.from_numpy(hq)
+    t0 = time.perf_counter()
+    S = tq @ tdb.t()
+    torch.sort(S, dim=1, descending=True, stable=True)
+    t_blas = (time.perf_counter() - t0) * n / ns
+    return {"value": round(nq / t_all, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"Nq={nq} x first {ns} rows of the shard, one pass of orc_topk_multi (canonical k-ordered fp32 chains, OpenMP), "
+                      f"time scaled x{n / ns:g} to {n} rows",
+            "one_thread": {"value": round(nq / t_one, 3), "unit": "queries/s", "cores": 1, "sample": f"Nq={nq} x {n1} rows, scaled x{n / n1:g}"},
+            "nq1": {"value": round(1.0 / t_q1, 2), "unit": "queries/s", "cores": cores, "sample": f"Nq=1 x all {n} rows, no scaling"},
+            "torch_matmul_stable_sort": {"value": round(nq / t_blas, 2), "unit": "queries/s", "cores": torch.get_num_threads(),
+                                         "sample": f"torch CPU `q @ db.T` + torch.sort(stable, descending) on Nq={nq} x {ns} rows (BLAS order, "
+                                                   f"full sort as the reference's sorted()), scaled x{n / ns:g}"},
+            "gpu_lists_equal_oracle": same}
+
+
+def retrieval_dense_secondary(dev, rank=0, world=1, steps=5, with_cpu=True):
+    """BASELINE config 4 on one shard per GPU: N_query = 200 random unit queries against 1.25 M x 512 fp32 rows (the
+    per-GPU share of 10 M), k = 500, exact (value desc, row asc) top-k: one bf16-MFMA candidate pass over the shard at
+    the HBM rate + exact fp32 re-score of the candidates (retrieval/dense.py).  N > 1: per-rank shards with row_base =
+    rank x n, one all_gather of the [200, 500] lists + merge."""
+    from swat_amd import _lib
+    from swat_amd.retrieval import dense, shard
     n, d, nq, k = 1_250_000, 512, 200, 500
     g = torch.Generator(device=dev).manual_seed(7)
-    db = torch.randn(n, d, device=dev, generator=g)
-    db /= db.norm(dim=-1, keepdim=True)
-    q = torch.randn(nq, d, device=dev, generator=g)
-    q /= q.norm(dim=-1, keepdim=True)
-    dense.topk_dense(db, q, k)
-    torch.cuda.synchronize()
+    q = _unit(torch.randn(nq, d, device=dev, generator=g))
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    db = _unit(torch.randn(n, d, device=dev, generator=g))
+
+    def once():
+        idx, val, cnt = dense.topk_dense(db, q, k, row_base=rank * n)
+        if world > 1:
+            return shard.gather_and_merge(idx, val, k)
+        return idx, val, cnt
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    once()
+    fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        idx, val, cnt = dense.topk_dense(db, q, k)
+        idx, val, cnt = once()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    dt /= steps
+    path = dense.last_path
+    # the candidate kernel alone, on the buffers the call above prepared
+    c = dense._prepared(db, q, k, 16384)
+    L = _lib.lib()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        c["cnt"].zero_()
+        _lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(c["thr"]), 0, _lib.ptr(c["keys"]), dense.CAP,
+                                              _lib.ptr(c["cnt"]), _lib.ptr(c["n2"]), _lib.stream()), "swat_sim_candidates_bf16")
+    e1.record()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    tf = 2.0 * nq * n * d / dt / 1e12
-    return {"metric": "retrieval top-k queries/s (dense N_query x N_db, exact fp32)", "value": round(nq / dt, 1), "unit": "queries/s",
-            "config": {"workload": f"{nq} queries x {n} x {d} fp32 rows, k={k}, threshold-pruned exact top-k"},
-            "ms_per_pass": round(dt * 1e3, 3),
-            "roofline": {"bound": "mfma", "kernel": "sim_topk_candidates_wide_kernel (v_mfma_f32_32x32x2_f32; 128 DB rows x 224 queries per workgroup)", "achieved": round(tf, 1),
-                         "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None}}
+    ms_k = e0.elapsed_time(e1) / steps
+    gbs = n * d * 4 / 1e9 / (ms_k * 1e-3)
+    tf = 2.0 * nq * n * d / (ms_k * 1e-3) / 1e12
+    rec = {"metric": "retrieval top-k queries/s (dense N_query x N_db, exact fp32 order)", "value": round(nq / dt, 1), "unit": "queries/s",
+           "n_gpus": world, "scaling": "weak", "dtype": "bf16 candidates + f32 exact re-score",
+           "config": {"workload": f"{nq} queries x {world} x {n} x {d} fp32 rows, k={k}, bit-exact (value desc, row asc) lists"
+                                  + (", all_gather + merge of the per-rank lists" if world > 1 else ""), "route": path},
+           "ms_per_pass": round(dt * 1e3, 3),
+           "roofline": {"bound": "hbm", "kernel": "sim_candidates_bf16_kernel (fp32 rows read once, bf16 v_mfma_f32_16x16x32_bf16 scores)",
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": _pmc_traffic("sim_candidates_bf16_kernel"), "algorithmic_bytes_per_launch": n * d * 4,
+                        "avg_ms": round(ms_k, 4), "pass_frac": round(n * d * 4 / 1e9 / dt / HBM_PEAK_GBS, 4),
+                        "mfma": {"achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}}}
+    if with_cpu and world == 1:
+        rec["cpu_baseline"] = dense_cpu_baseline(db, q, k, idx, val)
+    return rec
 
 
 def preprocess_secondary(dev, bsz=32, h=375, w=500, steps=50):
@@ -373,13 +546,20 @@ def main():
     if rank == 0:
         out["roofline"] = roof
         out["cpu_baseline"] = None
-    if world == 1:
-        if not a.no_cpu_baseline:
-            del step, model
-            out["cpu_baseline"] = cpu_baseline(a.bsz)
-        if not a.no_secondary:
-            ft = [finetune_secondary_subprocess(arch) for arch in ("ViT-B-16", "ViT-L-14")]
-            out["secondary"] = [retrieval_secondary(dev), retrieval_dense_secondary(dev), preprocess_secondary(dev)] + ft
+    del step, model, head, images
+    torch.cuda.empty_cache()
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.bsz)
+    if not a.no_secondary:
+        # path B runs at every N: one shard per rank, all_gather + merge of the per-rank lists (no other exchange)
+        with_cpu = not a.no_cpu_baseline
+        sec = [retrieval_secondary(dev, rank, world, with_cpu=with_cpu), retrieval_dense_secondary(dev, rank, world, with_cpu=with_cpu)]
+        if world == 1:
+            sec.append(retrieval_secondary(dev, d=768, with_cpu=False))  # ViT-L/14 embedding width
+            sec.append(preprocess_secondary(dev))
+            sec += [finetune_secondary_subprocess(arch) for arch in ("ViT-B-16", "ViT-L-14")]
+        if rank == 0:
+            out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

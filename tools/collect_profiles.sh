@@ -61,5 +61,36 @@ for k, e in out["kernels"].items():
           f"lds conflicts {e['counters'].get('SQ_LDS_BANK_CONFLICT', 0):.0f}  fetch {e.get('hbm_fetch_bytes', 0) / 1e6:.1f} MB  write {e.get('hbm_write_bytes', 0) / 1e6:.1f} MB")
 print("hbm bytes per GEMM launch:", out.get("hbm_bytes_per_gemm_launch"))
 PY
+# ---- path B: the two retrieval passes of bench.py on their own (tools/perf_retrieval.py)
+RET="python3 $ROOT/tools/perf_retrieval.py"
+rm -rf $O/${TAG}_ret_stats $O/${TAG}_ret_fetch $O/${TAG}_ret_write
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_ret_stats -- $RET > $O/${TAG}_ret_stats.json 2> /dev/null
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_ret_fetch -- $RET --steps 2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_ret_write -- $RET --steps 2 > /dev/null 2>&1
+python3 - <<PY
+import csv, glob, json, collections
+O, TAG = "$O", "$TAG"
+def load(d, counter):
+    res = collections.defaultdict(list)
+    for f in glob.glob(f"{O}/{TAG}_{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "swat::" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                res[r["Kernel_Name"].split("(")[0].replace("void swat::", "")].append(float(r["Counter_Value"]))
+    return res
+fe, wr = load("ret_fetch", "FETCH_SIZE"), load("ret_write", "WRITE_SIZE")
+out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no trace domain) over `python3 tools/perf_retrieval.py --steps 2` "
+                 "(1.25 M x 512 fp32 shard: segmented sampler pass with 1000 class queries, dense pass with 200 queries, k = 500)",
+       "reading": "bytes per launch = 2 x FETCH_SIZE KB (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KB; "
+                  "per kernel: mean over launches, and the largest launch (the shard scan; small launches of the same kernel are the threshold sample "
+                  "or the re-score of the candidates)"}
+for k in sorted(set(fe) | set(wr)):
+    f, w = fe.get(k, [0.0]), wr.get(k, [0.0])
+    out[k] = {"launches_seen": len(f), "fetch_bytes_mean": 2048 * sum(f) / len(f), "write_bytes_mean": 1024 * sum(w) / len(w),
+              "fetch_bytes_max": 2048 * max(f), "write_bytes_max": 1024 * max(w), "hbm_bytes_per_launch": 2048 * max(f) + 1024 * max(w)}
+    print(f"{k[:70]:70s} n={len(f):4d} fetch max {2048 * max(f) / 1e6:9.1f} MB  mean {2048 * sum(f) / len(f) / 1e6:9.1f} MB   write max {1024 * max(w) / 1e6:8.1f} MB")
+json.dump(out, open(f"{O}/{TAG}_retrieval_pmc.json", "w"), indent=1)
+PY
+cat $O/${TAG}_ret_stats.json | cut -c1-1200
+(cd $ROOT && python3 tools/stats_top.py gpurun_out/${TAG}_ret_stats 1 16)
 tail -1 $O/${TAG}_prof_stats.json | cut -c1-300
 cd $ROOT && python3 tools/stats_top.py gpurun_out/${TAG}_prof_stats0 25 22

@@ -1,28 +1,26 @@
-"""Quick on-GPU timing of the path B kernels (dev tool; bench.py is the judged entry)."""
-import sys, os, time
+"""Path B legs of bench.py on their own (one GPU): the segmented sampler pass and the dense top-k pass on a 1.25 M-row
+shard.  tools/collect_profiles.sh runs this under rocprofv3 (--kernel-trace --stats; FETCH_SIZE; WRITE_SIZE) to produce
+profiles/<tag>_retrieval_kernel_stats.csv and profiles/<tag>_retrieval_pmc.json.
+
+    python3 tools/perf_retrieval.py [--cpu] [--d 512] [--steps 5]
+"""
+import argparse
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from swat_amd.retrieval import ops
 
-dev = torch.device("cuda:0")
-n, d, nseg, k = int(os.environ.get("N", 1_250_000)), 512, 125, 500
-feats = torch.randn(n, d, device=dev); feats /= feats.norm(dim=-1, keepdim=True)
-q = torch.randn(nseg, d, device=dev); q /= q.norm(dim=-1, keepdim=True)
-per = n // nseg
-off = torch.arange(0, per * nseg + 1, per, device=dev, dtype=torch.int64)
-row_seg = torch.repeat_interleave(torch.arange(nseg, device=dev, dtype=torch.int32), per)
-n = per * nseg
-feats = feats[:n].contiguous()
-sims = torch.empty(n, device=dev)
-for name, fn in [("sim", lambda: ops.similarity_segmented(feats, q, row_seg, out=sims)),
-                 ("topk", lambda: ops.segment_topk(sims, off, k, thr=0.0)),
-                 ("copy", lambda: feats.clone())]:
-    for _ in range(3): fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20): fn()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
-    gb = n * d * 4 / 1e9
-    print(f"{name}: {ms:.3f} ms  ({gb/ms*1e3:.0f} GB/s on {gb:.2f} GB matrix)")
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cpu", action="store_true", help="also time the CPU baselines (oracle) and check the GPU lists against them")
+ap.add_argument("--d", type=int, default=512)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+for rec in (bench.retrieval_secondary(dev, d=a.d, steps=a.steps, with_cpu=a.cpu),
+            bench.retrieval_dense_secondary(dev, steps=a.steps, with_cpu=a.cpu)):
+    print(json.dumps(rec), flush=True)

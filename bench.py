@@ -403,8 +403,7 @@ def retrieval_dense_secondary(dev, rank=0, world=1, steps=5, with_cpu=True):
     e0.record()
     for _ in range(steps):
         c["cnt"].zero_()
-        _lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(c["thr"]), 0, _lib.ptr(c["keys"]), dense.CAP,
-                                              _lib.ptr(c["cnt"]), _lib.ptr(c["n2"]), _lib.stream()), "swat_sim_candidates_bf16")
+        dense.candidates(c, db)
     e1.record()
     torch.cuda.synchronize()
     ms_k = e0.elapsed_time(e1) / steps

@@ -81,6 +81,18 @@ int swat_sim_topk_candidates(const float* queries, int n_q, const float* db, int
 int swat_sim_candidates_bf16(const void* queries_bf16, int n_q, const float* db, int64_t n_db, int d,
                              const float* thr_dev, int64_t row_base, void* cand_keys, int cap, void* cand_cnt,
                              float* max_norm2, swat_stream_t stream);
+/*     the same pass in its fastest form (d % 128 == 0, n_q <= 4096): queries as the packed bf16 image made by
+ *     swat_dense_pack_queries (fp32 [n_q, d] -> per 32-deep chunk and 16-query tile the 1 KiB LDS image the kernel reads
+ *     linearly; swat_dense_packed_bytes(n_q, d) bytes, 0 when d is not supported) and a device workspace of
+ *     swat_dense_workspace_bytes(n_q) bytes (0 when n_q is not supported) in which every wave stages its candidate
+ *     records without atomics; a second launch files them into cand_keys / cand_cnt.  Same outputs, same error bound;
+ *     an overflowing staging area is reported as cand_cnt[0] >= 2^31. */
+int64_t swat_dense_packed_bytes(int n_q, int d);
+int64_t swat_dense_workspace_bytes(int n_q);
+int swat_dense_pack_queries(const float* queries, int n_q, int d, void* packed, swat_stream_t stream);
+int swat_sim_candidates_packed(const void* packed, int n_q, const float* db, int64_t n_db, int d,
+                               const float* thr_dev, int64_t row_base, void* cand_keys, int cap, void* cand_cnt,
+                               float* max_norm2, void* workspace, int64_t workspace_bytes, swat_stream_t stream);
 /*     sort each query's candidates, emit the (value desc, row asc) top-k (cap <= 8192). */
 int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k,
                          int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);

@@ -25,6 +25,7 @@
 // wave (128-row blocks, 2 workgroups per CU: 1.00 ms), a fifth wave touching the database 8 / 16 steps ahead with LDS-DMA
 // sector loads (1.27 ms: the extra wave costs a workgroup of residency and the touches did not shorten the loads).
 #include <stdlib.h>
+#include <utility>
 #include "common.hpp"
 #include "../../include/swat_hip.h"
 
@@ -189,13 +190,297 @@ __global__ __launch_bounds__(256, NF == 1 ? 3 : 2) void sim_candidates_bf16_kern
     if (lane == 0) atomicMax(max_norm2_bits, __float_as_uint(norm2_max));  // non-negative floats order like their bits
 }
 
+template <int N_, typename F, int... Is>
+__device__ __forceinline__ void rb_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N_, typename F>
+__device__ __forceinline__ void rb_static_for(F&& f) {
+    rb_static_for_impl<N_>(f, std::make_integer_sequence<int, N_>{});
+}
+
+// inline-asm LDS fragment reads with hand-counted waits: behind a global_load_lds the compiler guards every LDS read it
+// knows about with vmcnt(0) (it cannot tell the ring buffers apart), which would drain the loads just issued
+template <int IMM>
+__device__ __forceinline__ rb_bf16x8_t rb_lds_b128(unsigned addr) {
+    rb_bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+template <int N_>
+__device__ __forceinline__ void rb_wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_) : "memory");
+}
+__device__ __forceinline__ void rb_pin(rb_bf16x8_t& v) { asm volatile("" : "+v"(v)); }
+
+// The deep form (d % (32 D) == 0): 32-deep steps, database registers D steps ahead (a ring of D register sets, the step loop
+// unrolled D times), query chunks [16 NQT][32] bf16 two steps ahead in a ring of four LDS buffers.  Per step every wave issues,
+// in this order, the query pieces of step s + 2 and its database loads of step s + D; vmcnt completes in order, so at the top
+// of step s "at most LPS + 4 outstanding" (the database loads of steps s-2+D and s-1+D and the query pieces of step s+1) means
+// the query pieces of step s and the database registers of step s have landed while up to D-1 steps of database rows stay in
+// flight.  Past the end of the stream the same loads are re-issued on the last position, which keeps the counts uniform.
+template <int NQT, int D, int WAVES, int ABL = 0>  // WAVES x 16 database rows per block share one query chunk.   ABL: timing ablations (tuning only; results are wrong): 1 no MFMA, 2 no query DMA, 4 no barrier
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates_bf16_deep_kernel(const unsigned short* __restrict__ qp, int n_tiles, int n_q, int q0,
+                                                                          const float* __restrict__ db, int64_t n_db, int d,
+                                                                          const float* __restrict__ thr, int64_t row_base,
+                                                                          uint4* __restrict__ stage, unsigned stage_cap,
+                                                                          unsigned* __restrict__ stage_cnt, unsigned* __restrict__ max_norm2_bits) {
+    static_assert(D % 4 == 0, "the LDS ring index is static: D must be a multiple of the ring size");
+    constexpr int QROWS = 16 * NQT;
+    constexpr int QBYTES = QROWS * 64;       // one 32-deep query chunk
+    constexpr int QP = NQT;                  // 1 KiB pieces (16 rows x 64 B) per chunk
+    constexpr int LPS = (QP + WAVES - 1) / WAVES;  // pieces of the busiest wave; wave w issues my_lps = its share, no repeats
+    constexpr int BR = 16 * WAVES;           // database rows per block
+    static_assert(LPS <= 4, "counted waits cover up to four pieces per wave");
+    constexpr int RING = 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * QBYTES];
+    __shared__ float sthr[QROWS];  // thresholds of this pass's queries: the block epilogue's common path issues no memory op
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nchunk = d >> 5;
+    const int64_t nblocks = (n_db + BR - 1) / BR;
+    if ((int64_t)blockIdx.x >= nblocks) return;
+    if (tid < QROWS) sthr[tid] = q0 + tid < n_q ? thr[q0 + tid] : INFINITY;  // visible after the first step's barrier
+    const int wave_slot = blockIdx.x * WAVES + wave;
+    uint4* __restrict__ my_stage = stage + (size_t)wave_slot * stage_cap;
+    unsigned wcount = __builtin_amdgcn_readfirstlane(stage_cnt[wave_slot]);  // earlier passes of the same call
+    const int64_t my_blocks = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int64_t steps = my_blocks * nchunk;
+
+    // query pieces of this wave: piece p = tile q0 / 16 + p of the packed image (pack_queries_kernel: the 1 KiB LDS image of
+    // 16 queries x 32 k, contiguous per (chunk, tile)) — one linear 1 KiB read per instruction: scalar base + lane * 16
+    int qdst[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) qdst[i] = (wave + WAVES * i) * 1024;
+    const int my_lps = wave < QP ? (QP - 1 - wave) / WAVES + 1 : 0;  // uniform per wave
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const char* qbase = reinterpret_cast<const char*>(qp) + (size_t)(q0 >> 4) * 1024;  // uniform
+    const size_t chunk_stride = (size_t)n_tiles * 1024;
+    auto issue_q = [&](int buf, int c) {
+#pragma unroll
+        for (int i = 0; i < LPS; ++i)
+            if (i < my_lps) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + c * chunk_stride + qdst[i] + lane16),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * QBYTES + qdst[i]), 16, 0, 0);
+    };
+    // database fragment of a step: lane reads k = 32 c + 8 g .. + 7 of row blk * BR + wave * 16 + r16 (16 rows x 128 B lines):
+    // a scalar base (block, chunk) + one constant 32-bit lane offset; the last, partial block clamps its rows to n_db - 1
+    const unsigned row_in_blk = (unsigned)(wave * 16 + r16);
+    const unsigned voff = (row_in_blk * (unsigned)d + 8u * g) * 4u;
+    const int64_t last_blk = nblocks - 1;
+    const unsigned last_rows = (unsigned)(n_db - last_blk * BR);  // 1 .. BR
+    const unsigned voff_last = ((row_in_blk < last_rows ? row_in_blk : last_rows - 1) * (unsigned)d + 8u * g) * 4u;
+    const size_t blk_bytes = (size_t)BR * d * 4;
+    rb_f32x4_t nx[D][2];
+    const unsigned qr = (unsigned)(r16 * 64 + ((g ^ ((r16 >> 2) & 3)) << 4));
+    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
+    rb_f32x4_t acc[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) acc[t] = (rb_f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float ss = 0.f, norm2_max = 0.f;
+
+    // positions: compute (blk, c); database loads D steps ahead (lblk, lc); query chunk two steps ahead (qc)
+    int64_t blk = blockIdx.x, lblk = blockIdx.x, ls = 0;
+    int c = 0, lc = 0, qc = 0;
+    auto next_q = [&]() { qc = qc + 1 == nchunk ? 0 : qc + 1; };
+    auto next_l = [&]() {
+        if (ls + 1 < steps) {  // past the end: stay on the last position
+            ++ls;
+            if (++lc == nchunk) { lc = 0; lblk += gridDim.x; }
+        }
+    };
+    issue_q(0, qc); next_q();
+    // database loads are inline asm: the compiler's own bookkeeping would drain the queue (vmcnt(0)) at every use because it
+    // cannot count across the loop's merges; the registers are handed to the compiler by the pin behind the counted wait
+    auto load_db = [&](rb_f32x4_t (&dst)[2]) {
+        const char* base = reinterpret_cast<const char*>(db) + lblk * blk_bytes + (size_t)lc * 128;  // uniform
+        const unsigned off = lblk == last_blk ? voff_last : voff;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0]) : "v"(off), "s"(base));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst[1]) : "v"(off), "s"(base));
+        next_l();
+    };
+    load_db(nx[0]);
+    issue_q(1, qc); next_q();
+    rb_static_for<D - 1>([&](auto R) { load_db(nx[decltype(R)::value + 1]); });
+
+    for (int64_t s0 = 0; s0 < steps; s0 += D) {
+        rb_static_for<D>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            if (s0 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first D steps drain the prologue
+            else if ((ABL & 2) || my_lps == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (LPS == 1 || my_lps == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (LPS == 2 || my_lps == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (LPS == 3 || my_lps == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+            asm volatile("" : "+v"(nx[r][0]), "+v"(nx[r][1])::"memory");  // landed: the counted wait above covers them
+            const rb_f32x4_t a = nx[r][0], b = nx[r][1];
+            ss = fmaf(a[0], a[0], ss); ss = fmaf(a[1], a[1], ss); ss = fmaf(a[2], a[2], ss); ss = fmaf(a[3], a[3], ss);
+            ss = fmaf(b[0], b[0], ss); ss = fmaf(b[1], b[1], ss); ss = fmaf(b[2], b[2], ss); ss = fmaf(b[3], b[3], ss);
+            unsigned w0 = pack_bf16x2(a[0], a[1]), w1 = pack_bf16x2(a[2], a[3]), w2 = pack_bf16x2(b[0], b[1]), w3 = pack_bf16x2(b[2], b[3]);
+            // the registers of this step are consumed HERE, before the loads below are issued: a use behind them would have to
+            // wait for the youngest load (the compiler cannot count across the LDS-DMA pieces and drains the queue)
+            asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(ss)::"memory");
+            const uint4 u = make_uint4(w0, w1, w2, w3);
+            const rb_bf16x8_t dfr = __builtin_bit_cast(rb_bf16x8_t, u);
+            // step s + 2's query chunk (its buffer was last read in step s - 2: everyone is past that), step s + D's rows
+            if constexpr (!(ABL & 2)) { issue_q((r + 2) & 3, qc); next_q(); }
+            load_db(nx[r]);
+            // NQT fragment reads, QD in flight: read t + QD reuses the register of tile t behind its MFMA
+            constexpr int QD = NQT < 4 ? NQT : 4;
+            const unsigned qs = lds_base + (unsigned)((r & 3) * QBYTES) + qr;
+            rb_bf16x8_t qf[QD];
+            if constexpr (ABL & 1) {
+                acc[r % NQT][0] += __builtin_bit_cast(float, u.x ^ u.y ^ u.z ^ u.w);
+            } else {
+            rb_static_for<QD>([&](auto T) { qf[decltype(T)::value] = rb_lds_b128<decltype(T)::value * 1024>(qs); });
+            rb_static_for<NQT>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                rb_wait_lgkm<(NQT - 1 - t < QD - 1 ? NQT - 1 - t : QD - 1)>();
+                rb_pin(qf[t % QD]);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, qf[t % QD], acc[t], 0, 0, 0);
+                if constexpr (t + QD < NQT) qf[t % QD] = rb_lds_b128<(t + QD) * 1024>(qs);
+            });
+            }
+            if constexpr (r == D - 1) {  // nchunk % D == 0: a block can only end on the last step of the unrolled group
+                if (c + 1 == nchunk) {
+                    // block done: lane holds S[db row 4 g + e][query 16 t + r16].  Candidates go to this wave's private staging
+                    // slot — 16-B records (key lo, key hi, query), positions from a ballot prefix and a wave-uniform counter: no
+                    // atomic, no load, so nothing here waits on the database loads in flight (an atomic with return would drain
+                    // them: vmcnt completes in order).  regroup_candidates_kernel files the records under their queries.
+                    float v = ss;
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    const unsigned row0 = (unsigned)(blk * BR) + wave * 16, n_db32 = (unsigned)n_db;  // row_base + n_db < 2^32
+                    if (row0 + r16 < n_db32) norm2_max = fmaxf(norm2_max, v);
+                    ss = 0.f;
+                    const unsigned key0 = 0xFFFFFFFFu - (uint32_t)row_base - row0 - 4u * g;
+#pragma unroll
+                    for (int t = 0; t < NQT; ++t) {
+                        asm volatile("" ::: "memory");  // one threshold live at a time (the compiler would hoist all NQT reads)
+                        const float tq = sthr[16 * t + r16];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float sc = acc[t][e];
+                            const unsigned row = row0 + 4 * g + e;
+                            const bool hit = ((ABL & 15) ? sc == 123.456f : (ABL & 16) ? sc >= tq + 100.f : sc >= tq) && row < n_db32;
+                            const unsigned long long m = __ballot(hit);
+                            if (m) {
+                                const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                if (hit && pos < stage_cap) {
+                                    // three dword stores off a scalar base: a 16-B store needs a fresh aligned register quad, which
+                                    // at this pressure costs a spill reload (a scratch load, i.e. a drain of the queue) per hit
+                                    const unsigned o = pos * 16u, k_lo = key0 - e, k_hi = rb_ordered_bits(sc), qq = (unsigned)(q0 + 16 * t) + r16;
+                                    asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(k_lo), "s"(my_stage) : "memory");
+                                    asm volatile("global_store_dword %0, %1, %2 offset:4" ::"v"(o), "v"(k_hi), "s"(my_stage) : "memory");
+                                    asm volatile("global_store_dword %0, %1, %2 offset:8" ::"v"(o), "v"(qq), "s"(my_stage) : "memory");
+                                }
+                                wcount += (unsigned)__popcll(m);
+                            }
+                        }
+                        acc[t] = (rb_f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    }
+                    c = 0;
+                    blk += gridDim.x;
+                } else {
+                    ++c;
+                }
+            } else {
+                ++c;
+            }
+        });
+    }
+    // the re-issued tail pieces must land before the LDS is handed back, and the tail's database registers stay reserved
+    // until their loads have landed
+#pragma unroll
+    for (int r = 0; r < D; ++r) asm volatile("s_waitcnt vmcnt(0)" ::"v"(nx[r][0]), "v"(nx[r][1]) : "memory");
+    norm2_max = wave_max(norm2_max);
+    if (lane == 0) {
+        atomicMax(max_norm2_bits, __float_as_uint(norm2_max));
+        stage_cnt[wave_slot] = wcount;  // may exceed stage_cap: the regroup pass reports the overflow
+    }
+}
+
+// Files the staged candidate records under their queries: cand[q, pos] = key with pos from cnt[q].  A block takes 16 wave
+// slots, counts its records per query in LDS, reserves one range per (block, query) with a single global atomic and scatters.
+// A staging slot that overflowed sets the top bit of cnt[0], which every consumer reads as "list overflowed".
+__global__ __launch_bounds__(256) void regroup_candidates_kernel(const uint4* __restrict__ stage, unsigned stage_cap,
+                                                                 const unsigned* __restrict__ stage_cnt, int n_slots,
+                                                                 unsigned long long* __restrict__ cand, int cap,
+                                                                 unsigned* __restrict__ cnt, int n_q) {
+    extern __shared__ unsigned rg_sh[];
+    unsigned* hist = rg_sh;
+    unsigned* base = rg_sh + n_q;
+    unsigned* fill = rg_sh + 2 * n_q;
+    __shared__ unsigned slot_n[16];
+    const int tid = threadIdx.x, s0 = blockIdx.x * 16;
+    for (int q = tid; q < n_q; q += 256) { hist[q] = 0u; fill[q] = 0u; }
+    if (tid < 16) {
+        unsigned n = s0 + tid < n_slots ? stage_cnt[s0 + tid] : 0u;
+        if (n > stage_cap) {
+            atomicOr(&cnt[0], 0x80000000u);
+            n = stage_cap;
+        }
+        slot_n[tid] = n;
+    }
+    __syncthreads();
+    for (int sl = 0; sl < 16; ++sl) {
+        const uint4* src = stage + (size_t)(s0 + sl) * stage_cap;
+        for (unsigned i = tid; i < slot_n[sl]; i += 256) atomicAdd(&hist[src[i].z], 1u);
+    }
+    __syncthreads();
+    for (int q = tid; q < n_q; q += 256)
+        if (hist[q]) base[q] = atomicAdd(&cnt[q], hist[q]);
+    __syncthreads();
+    for (int sl = 0; sl < 16; ++sl) {
+        const uint4* src = stage + (size_t)(s0 + sl) * stage_cap;
+        for (unsigned i = tid; i < slot_n[sl]; i += 256) {
+            const uint4 rec = src[i];
+            const unsigned pos = base[rec.z] + atomicAdd(&fill[rec.z], 1u);
+            if (pos < (unsigned)cap) cand[rec.z * (size_t)cap + pos] = ((unsigned long long)rec.y << 32) | rec.x;
+        }
+    }
+}
+
+// Packed query image for the deep form: [d / 32 chunks][n_tiles][1 KiB] bf16, where the 1 KiB of (chunk c, tile T) is the LDS
+// image of queries 16T .. 16T+15, k 32c .. 32c+31: 16-B unit L holds row L / 4, k-slot (L % 4) ^ ((L / 16) % 4) — eight
+// consecutive rows of a fragment read then cover all 64 banks.  Rows >= n_q are zero.
+__global__ void pack_queries_kernel(const float* __restrict__ q, int n_q, int d, int n_tiles, unsigned short* __restrict__ out) {
+    const int64_t unit = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // one 16-B unit (8 bf16)
+    const int64_t total = (int64_t)(d >> 5) * n_tiles * 64;
+    if (unit >= total) return;
+    const int L = (int)(unit & 63);
+    const int64_t ct = unit >> 6;
+    const int T = (int)(ct % n_tiles), c = (int)(ct / n_tiles);
+    const int row = 16 * T + (L >> 2);
+    const int k0 = 32 * c + 8 * ((L & 3) ^ ((L >> 4) & 3));
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < n_q) {
+        const float* src = q + (int64_t)row * d + k0;
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        v = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+    }
+    *reinterpret_cast<uint4*>(out + unit * 8) = v;
+}
+
 }  // namespace swat
 using namespace swat;
 
-// Candidate pass: queries_bf16 [n_q, d] (bf16, row-major), db [n_db, d] fp32.  Every (q, row) with approximate score >=
-// thr_dev[q] is appended to cand_keys [n_q, cap] (uint64: ordered(approx) << 32 | ~(row_base + row)), cand_cnt [n_q]
-// (uint32, zero it first; counts keep growing past cap: overflow is visible).  max_norm2 (device float, zero it first)
-// receives max |d_row|^2.  See include/swat_hip.h.
+static int dense_variant() {
+    // tuning (SWAT_DENSE_VARIANT), row-major entry only: 1 = one 16-row fragment per wave, 3 workgroups per CU (default);
+    // 2 = two fragments, 2 per CU
+    static int variant = -1;
+    if (variant < 0) {
+        const char* e = getenv("SWAT_DENSE_VARIANT");
+        variant = e ? atoi(e) : 1;
+    }
+    return variant;
+}
+
+// Candidate pass, row-major queries (any d % 64 == 0): queries_bf16 [n_q, d] (bf16), db [n_db, d] fp32.  Every (q, row) with
+// approximate score >= thr_dev[q] is appended to cand_keys [n_q, cap] (uint64: ordered(approx) << 32 | ~(row_base + row)),
+// cand_cnt [n_q] (uint32, zero it first; counts keep growing past cap: overflow is visible).  max_norm2 (device float, zero it
+// first) receives max |d_row|^2.  See include/swat_hip.h.
 SWAT_API int swat_sim_candidates_bf16(const void* queries_bf16, int n_q, const float* db, int64_t n_db, int d,
                                       const float* thr_dev, int64_t row_base, void* cand_keys, int cap, void* cand_cnt,
                                       float* max_norm2, swat_stream_t s) {
@@ -205,11 +490,7 @@ SWAT_API int swat_sim_candidates_bf16(const void* queries_bf16, int n_q, const f
     SWAT_REQUIRE(row_base + n_db < (1ll << 32), "swat_sim_candidates_bf16: global rows must fit 32 bits");
     SWAT_REQUIRE((int64_t)n_q * d < (1ll << 30), "swat_sim_candidates_bf16: query matrix too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)s;
-    static int variant = -1;  // tuning (SWAT_DENSE_VARIANT): 1 = one 16-row fragment per wave, 3 workgroups per CU (default); 2 = two fragments, 2 per CU
-    if (variant < 0) {
-        const char* e = getenv("SWAT_DENSE_VARIANT");
-        variant = e ? atoi(e) : 1;
-    }
+    const int variant = dense_variant();
 #define SWAT_CAND(NQT_, NF_, MAXG_)                                                                                      \
     {                                                                                                                    \
         const int64_t nblocks = (n_db + 64 * NF_ - 1) / (64 * NF_);                                                      \
@@ -233,4 +514,94 @@ SWAT_API int swat_sim_candidates_bf16(const void* queries_bf16, int n_q, const f
     }
 #undef SWAT_CAND
     return check_launch("swat_sim_candidates_bf16");
+}
+
+// Packed query image of the deep form: bytes to allocate, and the packing itself (fp32 queries [n_q, d] -> bf16 image).
+// The image carries 13 zero tiles of slack so that the last pass of swat_sim_candidates_packed never reads past it.
+static int dense_tiles(int n_q) { return (n_q + 15) / 16 + 13; }
+
+SWAT_API int64_t swat_dense_packed_bytes(int n_q, int d) {
+    if (n_q <= 0 || d <= 0 || d % 128 != 0) return 0;
+    return (int64_t)(d / 32) * dense_tiles(n_q) * 1024;
+}
+
+SWAT_API int swat_dense_pack_queries(const float* queries, int n_q, int d, void* packed, swat_stream_t s) {
+    SWAT_REQUIRE(queries && packed, "swat_dense_pack_queries: null pointer");
+    SWAT_REQUIRE(n_q > 0 && d > 0 && d % 128 == 0, "swat_dense_pack_queries: d=%d must be a multiple of 128", d);
+    const int n_tiles = dense_tiles(n_q);
+    const int64_t units = (int64_t)(d / 32) * n_tiles * 64;
+    hipLaunchKernelGGL(pack_queries_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)s, queries, n_q, d, n_tiles,
+                       (unsigned short*)packed);
+    return check_launch("swat_dense_pack_queries");
+}
+
+// Staging area of the deep form: 3072 wave slots (768 workgroups x 4 waves) of 16-B records behind their counters.
+static const int kDenseSlots = 3072;
+static const int64_t kDenseCntBytes = 16384;
+
+SWAT_API int64_t swat_dense_workspace_bytes(int n_q) {
+    if (n_q <= 0 || n_q > 4096) return 0;
+    int64_t per_slot = ((int64_t)3 * n_q + 63) / 64 * 64;  // ~6000 records per query in total: three times what the thresholds aim at
+    if (per_slot < 256) per_slot = 256;
+    return kDenseCntBytes + kDenseSlots * per_slot * 16;
+}
+
+// Candidate pass, deep form (d % 128 == 0, n_q <= 4096): as swat_sim_candidates_bf16 with the queries given as the packed
+// image and a workspace of swat_dense_workspace_bytes(n_q) bytes for the per-wave staging of the candidate records.
+SWAT_API int swat_sim_candidates_packed(const void* packed, int n_q, const float* db, int64_t n_db, int d, const float* thr_dev,
+                                        int64_t row_base, void* cand_keys, int cap, void* cand_cnt, float* max_norm2,
+                                        void* workspace, int64_t workspace_bytes, swat_stream_t s) {
+    SWAT_REQUIRE(packed && db && thr_dev && cand_keys && cand_cnt && max_norm2 && workspace, "swat_sim_candidates_packed: null pointer");
+    SWAT_REQUIRE(n_q <= 4096, "swat_sim_candidates_packed: n_q=%d above 4096", n_q);
+    SWAT_REQUIRE(workspace_bytes >= swat_dense_workspace_bytes(n_q), "swat_sim_candidates_packed: workspace of %lld bytes is too small",
+                 (long long)workspace_bytes);
+    const unsigned stage_cap = (unsigned)((workspace_bytes - kDenseCntBytes) / (kDenseSlots * 16));
+    unsigned* stage_cnt = (unsigned*)workspace;
+    uint4* stage = (uint4*)((char*)workspace + kDenseCntBytes);
+    SWAT_HIP(hipMemsetAsync(stage_cnt, 0, kDenseSlots * sizeof(unsigned), (hipStream_t)s));
+    SWAT_REQUIRE(d > 0 && d % 128 == 0, "swat_sim_candidates_packed: d=%d must be a multiple of 128", d);
+    SWAT_REQUIRE(n_q > 0 && n_db > 0, "swat_sim_candidates_packed: empty operand");
+    SWAT_REQUIRE(row_base + n_db < (1ll << 32), "swat_sim_candidates_packed: global rows must fit 32 bits");
+    hipStream_t st = (hipStream_t)s;
+    const int n_tiles = dense_tiles(n_q);
+    static const int abl = getenv("SWAT_DENSE_ABL") ? atoi(getenv("SWAT_DENSE_ABL")) : 0;  // tuning: timing ablations, wrong results
+    static const int waves = getenv("SWAT_DENSE_WAVES") ? atoi(getenv("SWAT_DENSE_WAVES")) : 12;  // tuning: 4 = 64-row blocks, 3 workgroups per CU
+#define SWAT_CAND_DEEP(NQT_, ABL_)                                                                                       \
+    if (waves == 12) {                                                                                                   \
+        const int64_t nblocks = (n_db + 191) / 192;                                                                      \
+        const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);                                                 \
+        hipLaunchKernelGGL((sim_candidates_bf16_deep_kernel<NQT_, 4, 12, ABL_>), dim3(grid), dim3(768), 0, st,           \
+                           (const unsigned short*)packed, n_tiles, n_q, q0, db, n_db, d, thr_dev, row_base, stage,       \
+                           stage_cap, stage_cnt, (unsigned*)max_norm2);                                                  \
+    } else {                                                                                                             \
+        const int64_t nblocks = (n_db + 63) / 64;                                                                        \
+        const unsigned grid = (unsigned)(nblocks < 768 ? nblocks : 768);                                                 \
+        hipLaunchKernelGGL((sim_candidates_bf16_deep_kernel<NQT_, 4, 4, ABL_>), dim3(grid), dim3(256), 0, st,            \
+                           (const unsigned short*)packed, n_tiles, n_q, q0, db, n_db, d, thr_dev, row_base, stage,       \
+                           stage_cap, stage_cnt, (unsigned*)max_norm2);                                                  \
+    }
+    for (int q0 = 0; q0 < n_q;) {
+        const int left = n_q - q0;
+        if (left > 128) {  // 13 query tiles = 208 queries, 53 KB of LDS: three workgroups per CU, all resident
+            switch (abl) {
+                case 0: SWAT_CAND_DEEP(13, 0) break;
+                case 1: SWAT_CAND_DEEP(13, 1) break;
+                case 2: SWAT_CAND_DEEP(13, 2) break;
+                case 4: SWAT_CAND_DEEP(13, 4) break;
+                case 16: SWAT_CAND_DEEP(13, 16) break;
+                default: SWAT_CAND_DEEP(13, 7) break;
+            }
+            q0 += 16 * 13;
+        } else if (left > 32) {
+            SWAT_CAND_DEEP(8, 0)
+            q0 += 128;
+        } else {
+            SWAT_CAND_DEEP(2, 0)
+            q0 += 32;
+        }
+    }
+#undef SWAT_CAND_DEEP
+    hipLaunchKernelGGL(regroup_candidates_kernel, dim3(kDenseSlots / 16), dim3(256), 3 * n_q * sizeof(unsigned), st, stage, stage_cap,
+                       stage_cnt, kDenseSlots, (unsigned long long*)cand_keys, cap, (unsigned*)cand_cnt, n_q);
+    return check_launch("swat_sim_candidates_packed");
 }

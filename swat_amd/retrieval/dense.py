@@ -92,8 +92,17 @@ def _prepared(db, queries, k, sample):
         K2 = min(TOPK2_MAX, max(64, (max(2 * k, k + 256) + 63) // 64 * 64))
         thr = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)))
         dev = db.device
+        d = queries.shape[1]
+        nbytes, wbytes = int(_lib.lib().swat_dense_packed_bytes(nq, d)), int(_lib.lib().swat_dense_workspace_bytes(nq))
+        ws = None
+        if nbytes and wbytes:  # d % 128 == 0, n_q <= 4096: the packed image the deep kernel reads linearly (csrc/retrieval_bf16.hip)
+            qb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(_lib.lib().swat_dense_pack_queries(_lib.ptr(queries), nq, d, _lib.ptr(qb), _lib.stream()), "swat_dense_pack_queries")
+            ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        else:
+            qb = queries.to(torch.bfloat16).contiguous()
         _cache.clear()
-        _cache.update(key=key, thr=thr, qb=queries.to(torch.bfloat16).contiguous(), qn=float(queries.norm(dim=1).max().item()), K2=K2,
+        _cache.update(key=key, thr=thr, qb=qb, ws=ws, qn=float(queries.norm(dim=1).max().item()), K2=K2,
                       row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
                       idx2=torch.empty((nq, K2), dtype=torch.int64, device=dev), val2=torch.empty((nq, K2), dtype=torch.float32, device=dev),
                       cnt2=torch.empty(nq, dtype=torch.int64, device=dev), keys2=torch.empty((nq, K2), dtype=torch.int64, device=dev),
@@ -101,6 +110,18 @@ def _prepared(db, queries, k, sample):
                       keys=torch.empty((nq, CAP), dtype=torch.int64, device=dev), cnt=torch.zeros(nq, dtype=torch.int32, device=dev),
                       n2=torch.zeros(1, dtype=torch.float32, device=dev))
     return _cache
+
+
+def candidates(c, db, row_base=0):
+    """The candidate pass on prepared buffers c (= _prepared(...)): appends to c["keys"] / c["cnt"], max |row|^2 to c["n2"]."""
+    L = _lib.lib()
+    nq = c["cnt"].numel()
+    args = (_lib.ptr(c["qb"]), nq, _lib.ptr(db), db.shape[0], db.shape[1], _lib.ptr(c["thr"]), int(row_base), _lib.ptr(c["keys"]), CAP,
+            _lib.ptr(c["cnt"]), _lib.ptr(c["n2"]))
+    if c["ws"] is not None:
+        _lib.check(L.swat_sim_candidates_packed(*args, _lib.ptr(c["ws"]), c["ws"].numel(), _lib.stream()), "swat_sim_candidates_packed")
+    else:
+        _lib.check(L.swat_sim_candidates_bf16(*args, _lib.stream()), "swat_sim_candidates_bf16")
 
 
 TOPK2_MAX = 2048
@@ -124,8 +145,7 @@ def topk_dense(db, queries, k, row_base=0, sample=16384):
     L = _lib.lib()
     cnt.zero_()
     n2.zero_()
-    _lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(thr), int(row_base), _lib.ptr(keys), CAP,
-                                          _lib.ptr(cnt), _lib.ptr(n2), _lib.stream()), "swat_sim_candidates_bf16")
+    candidates(c, db, row_base)
     idx2, val2, cnt2, keys2 = c["idx2"], c["val2"], c["cnt2"], c["keys2"]
     _lib.check(L.swat_candidates_topk(_lib.ptr(keys), CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2),
                                       _lib.stream()), "swat_candidates_topk")

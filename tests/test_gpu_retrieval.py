@@ -179,19 +179,22 @@ def test_dense_mfma_topk_bit_exact_vs_oracle(n, nq, k):
     assert (idx[:, 1:][ties] > idx[:, :-1][ties]).all()
 
 
-@pytest.mark.parametrize("n,nq,k,scale", [(150001, 200, 500, 1.0), (40000, 37, 100, 1.0), (60000, 64, 256, 3.5), (5000, 10, 20, 1.0)])
-def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale):
+@pytest.mark.parametrize("n,nq,k,scale,d", [(150001, 200, 500, 1.0, 512), (40000, 37, 100, 1.0, 512), (60000, 64, 256, 3.5, 512),
+                                             (5000, 10, 20, 1.0, 512), (70003, 150, 300, 1.0, 768), (30000, 230, 64, 2.0, 128),
+                                             (30000, 40, 64, 1.0, 192)])
+def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale, d):
     """topk_dense = bf16 MFMA candidate pass + exact re-scoring + on-device completeness proof: the same (rows, values) as
     the exact f32-matrix-core scan for EVERY query, duplicates (exact ties) included, with a row_base and with rows that
-    are not unit-norm (the error bound scales with |q| |d|); and the fast route is the one that ran."""
+    are not unit-norm (the error bound scales with |q| |d|); and the fast route is the one that ran.  d % 128 == 0 takes
+    the packed-query deep kernel (one to three passes of 13 / 8 / 2 query tiles), d = 192 the row-major one."""
     from swat_amd.retrieval import dense
     dev = _dev()
     rs = np.random.RandomState(n * 7 + nq)
-    db = synth.unit_rows(rs, n, 512) * np.float32(scale)
+    db = synth.unit_rows(rs, n, d) * np.float32(scale)
     for _ in range(n // 10):
         a, b = rs.randint(n), rs.randint(n)
         db[a] = db[b]
-    centres = synth.unit_rows(rs, nq, 512)
+    centres = synth.unit_rows(rs, nq, d)
     db[rs.randint(n, size=4 * nq)] += np.repeat(centres, 4, axis=0) * np.float32(0.4)  # a few strong hits per query
     d_db, d_q = torch.from_numpy(db).to(dev), torch.from_numpy(centres).to(dev)
     idx, val, cnt = dense.topk_dense(d_db, d_q, k, row_base=1000)
@@ -205,6 +208,29 @@ def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale):
     idx3, val3, _ = dense.topk_dense(d_db, d_q, k, row_base=1000)
     e3_idx, e3_val, _ = dense.topk_dense_exact(d_db, d_q, k, row_base=1000)
     assert torch.equal(idx3, e3_idx) and torch.equal(val3, e3_val)
+
+
+def test_packed_query_image_layout():
+    """swat_dense_pack_queries: per (32-deep chunk, 16-query tile) a 1 KiB block whose 16-B unit L holds query 16T + L/4,
+    k = 32c + 8 ((L % 4) ^ ((L / 16) % 4)) .. +7, rounded to bf16 (RNE); rows >= n_q and the 13 slack tiles are zero."""
+    from swat_amd import _lib
+    dev = _dev()
+    nq, d = 37, 256
+    q = torch.randn(nq, d, device=dev)
+    nbytes = int(_lib.lib().swat_dense_packed_bytes(nq, d))
+    tiles = (nq + 15) // 16 + 13
+    assert nbytes == (d // 32) * tiles * 1024 and _lib.lib().swat_dense_packed_bytes(nq, 192) == 0
+    out = torch.full((nbytes // 2,), 0x7fff, dtype=torch.int16, device=dev)
+    _lib.check(_lib.lib().swat_dense_pack_queries(_lib.ptr(q), nq, d, _lib.ptr(out), _lib.stream()), "pack")
+    got = out.view(torch.bfloat16).view(d // 32, tiles, 64, 8).float().cpu()
+    qb = torch.zeros(tiles * 16, d)
+    qb[:nq] = q.to(torch.bfloat16).float().cpu()
+    L = torch.arange(64)
+    slot = (L % 4) ^ ((L // 16) % 4)
+    for c in range(d // 32):
+        for T in (0, 1, 2, 3, tiles - 1):
+            want = torch.stack([qb[16 * T + int(L[i]) // 4, 32 * c + 8 * int(slot[i]):32 * c + 8 * int(slot[i]) + 8] for i in range(64)])
+            assert torch.equal(got[c, T], want), (c, T)
 
 
 def test_sim_gathered_is_the_scan_on_a_row_list():

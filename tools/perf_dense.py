@@ -22,8 +22,7 @@ for rep in range(3):
     c["cnt"].zero_(); c["n2"].zero_()
     a, b = ev(), ev(); a.record()
     for _ in range(5):
-        _lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(c["thr"]), 0, _lib.ptr(c["keys"]), dense.CAP,
-                                              _lib.ptr(c["cnt"]), _lib.ptr(c["n2"]), _lib.stream()), "cand")
+        dense.candidates(c, db)
     b.record(); torch.cuda.synchronize()
     tc = a.elapsed_time(b) / 5
     print(f"pass {tot:.3f} ms = {nq / tot * 1e3:,.0f} queries/s; candidate kernel {tc:.3f} ms = {n * d * 4 / tc / 1e6:.0f} GB/s "
@@ -40,7 +39,7 @@ marks = [ev() for _ in range(7)]
 torch.cuda.synchronize()
 marks[0].record()
 cnt.zero_(); n2.zero_()
-_lib.check(L.swat_sim_candidates_bf16(_lib.ptr(c["qb"]), nq, _lib.ptr(db), n, d, _lib.ptr(thr), 0, _lib.ptr(keys), dense.CAP, _lib.ptr(cnt), _lib.ptr(n2), _lib.stream()), "cand")
+dense.candidates(c, db)
 marks[1].record()
 _lib.check(L.swat_candidates_topk(_lib.ptr(keys), dense.CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2), _lib.stream()), "ctk")
 marks[2].record()

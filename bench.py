@@ -10,7 +10,9 @@ bf16 MFMA operands, fp32 accumulation / residual stream / master weights.
 
 Prints ONE JSON line (rank 0): whole-job img/s, the MFMA roofline of the GEMM kernels (HIP start/stop events attached to
 every GEMM dispatch in an instrumented replay of the same steps, lanes serialised), a CPU baseline (the fp32 oracle on
-the host cores, N = 1 only) and, as secondary records, the retrieval scan and the dense exact top-k (path B).
+the host cores, N = 1 only) and, as secondary records, path B at every N (segmented sampler pass and dense top-k on one
+1.25 M-row shard per GPU, lists merged over one all_gather; CPU baselines and oracle equality at N = 1), the d = 768 scan,
+the image transform and the same fused step on ViT-B/16 and ViT-L/14 (C = 1000).
 """
 import argparse
 import ctypes
@@ -414,9 +416,9 @@ def retrieval_dense_secondary(dev, rank=0, world=1, steps=5, with_cpu=True):
            "config": {"workload": f"{nq} queries x {world} x {n} x {d} fp32 rows, k={k}, bit-exact (value desc, row asc) lists"
                                   + (", all_gather + merge of the per-rank lists" if world > 1 else ""), "route": path},
            "ms_per_pass": round(dt * 1e3, 3),
-           "roofline": {"bound": "hbm", "kernel": "sim_candidates_bf16_kernel (fp32 rows read once, bf16 v_mfma_f32_16x16x32_bf16 scores)",
+           "roofline": {"bound": "hbm", "kernel": "sim_candidates_bf16_deep_kernel (fp32 rows read once, bf16 v_mfma_f32_16x16x32_bf16 scores; timed with its staging memset and regroup_candidates_kernel)",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                        "traffic": _pmc_traffic("sim_candidates_bf16_kernel"), "algorithmic_bytes_per_launch": n * d * 4,
+                        "traffic": _pmc_traffic("sim_candidates_bf16_deep_kernel"), "algorithmic_bytes_per_launch": n * d * 4,
                         "avg_ms": round(ms_k, 4), "pass_frac": round(n * d * 4 / 1e9 / dt / HBM_PEAK_GBS, 4),
                         "mfma": {"achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}}}
     if with_cpu and world == 1:

@@ -10,20 +10,33 @@
 // bound |approx - exact| <= (2^-8 + 2^-12) |q| |d| (two bf16 roundings per product + fp32 accumulation), for which this
 // kernel also returns max |d|^2 over the rows it saw — so the final top-k indices stay bit-exact.
 //
-// Structure: 4 waves per workgroup, each wave owns 32 database rows of a 128-row block (two 16-row MFMA fragments)
-// against ALL query tiles (NQT x 16 queries: NQT x 2 accumulators of 16x16).  Database fragments never touch LDS: lane
-// (r16, g) loads 32 B = k 8g..8g+7 of row r16 — 16 rows x 128 B full lines per instruction pair — one 64-deep chunk
-// ahead of the MFMAs.  Query chunks [16 NQT][64] bf16 (L2-resident, 213 KB per 128-row block) go global -> LDS by
-// LDS-DMA into two buffers with the 16-B-slot XOR of the GEMM's k-contiguous image (gemm_device.hpp: kc_off).
-// Workgroups walk blocks b, b + grid, ...; the chunk stream is continuous across blocks.
+// Two forms.  The DEEP form (sim_candidates_bf16_deep_kernel; d % 128 == 0, n_q <= 4096, queries as the packed image of
+// pack_queries_kernel) is the product path for every CLIP width (512 / 768 / 1024):
+//   * 12 waves per workgroup, one workgroup per CU, each wave owns 16 database rows of a 192-row block against ALL query tiles
+//     (NQT x 16 queries, NQT accumulators of 16x16); the twelve waves share one query chunk, so the L2 -> LDS query stream is
+//     0.55x the database bytes (1.66x with 4 waves per workgroup — measured as the largest single cost of that shape);
+//   * 32-deep steps; database fragments never touch LDS: lane (r16, g) loads 32 B = k 8g..8g+7 of row r16 straight into the
+//     MFMA A-fragment registers, FOUR steps ahead (a ring of four register sets, loop unrolled four times, inline-asm loads
+//     off a scalar base so the compiler neither counts nor drains them);
+//   * query chunks [16 NQT][32] bf16 come from the packed image — 1 KiB per (chunk, tile), already in LDS order, read
+//     linearly by LDS-DMA — two steps ahead into a ring of four LDS buffers; one s_barrier and one COUNTED vmcnt wait per
+//     step (vmcnt completes in order: "at most my_pieces + 4 outstanding" = this step's operands have landed, three steps
+//     of database rows still fly); fragment reads are inline-asm ds_read_b128 with counted lgkmcnt (a compiler-visible LDS
+//     read behind a global_load_lds is guarded with vmcnt(0), which would drain the queue every step);
+//   * candidates leave without atomics: ballot prefix + a wave-uniform counter place 12-B records in the wave's private
+//     staging slot (dword stores off a scalar base).  An atomic with return in the block epilogue cost 0.23 ms of the
+//     0.88 ms pass — its wait drains every database load in flight.  regroup_candidates_kernel (20 us) files the records
+//     under their queries with one global atomic per (16 slots, query).
+// The 64-DEEP form (sim_candidates_bf16_kernel, row-major bf16 queries, any d % 64 == 0) is the earlier shape — 4 waves,
+// 64-row blocks, one step ahead — kept for widths the deep form does not take.
 //
-// Measured (MI355X, 200 queries x 1.25 M rows, tools/perf_dense.py): 0.80 ms = 3.2 TB/s for this kernel (0.40 of the 8 TB/s
-// peak; 4.8 TB/s with 32 queries), 1.05 ms for the whole exact top-k (re-scoring, two sorts, proof: 0.21 ms) against
-// 3.6 ms for the f32-matrix-core scan.  What bounds it: one 64-deep chunk per wave in flight (12 waves x 4 KB per CU) against
-// the HBM latency; deeper register rings do not compose with the per-step LDS-DMA of the query chunk (vmcnt completes in
-// order, so waiting for the newest query piece drains every older database load).  Tried and dropped: two fragments per
-// wave (128-row blocks, 2 workgroups per CU: 1.00 ms), a fifth wave touching the database 8 / 16 steps ahead with LDS-DMA
-// sector loads (1.27 ms: the extra wave costs a workgroup of residency and the touches did not shorten the loads).
+// Measured (MI355X, 200 queries x 1.25 M x 512, tools/perf_dense.py, profiles/r02_retrieval_*): deep kernel 0.56-0.60 ms =
+// 4.3-4.6 TB/s (0.54-0.57 of the 8 TB/s peak; HBM traffic 2.61 GB per launch against 2.56 GB algorithmic), whole exact top-k
+// 0.81-0.85 ms (memset + scan + regroup 0.62, approximate top-K2 0.08, exact re-score 0.08, exact top-k 0.02, proof + flag
+// 0.03) against 3.6 ms for the f32-matrix-core scan.  Timing ablations of the 4-wave shape (SWAT_DENSE_ABL, tuning only):
+// no query DMA 0.52 ms, no MFMA / LDS reads 0.59, no barrier 0.83 of 0.94; row-major query pieces (16 half-used lines per
+// instruction instead of 8 full ones) cost 0.31 ms.  Tried and dropped: two fragments per wave (2 workgroups per CU:
+// 1.00 ms), a fifth wave touching the database 8 / 16 steps ahead (1.27 ms), eight steps of rows in flight (spills).
 #include <stdlib.h>
 #include <utility>
 #include "common.hpp"
@@ -466,17 +479,6 @@ __global__ void pack_queries_kernel(const float* __restrict__ q, int n_q, int d,
 }  // namespace swat
 using namespace swat;
 
-static int dense_variant() {
-    // tuning (SWAT_DENSE_VARIANT), row-major entry only: 1 = one 16-row fragment per wave, 3 workgroups per CU (default);
-    // 2 = two fragments, 2 per CU
-    static int variant = -1;
-    if (variant < 0) {
-        const char* e = getenv("SWAT_DENSE_VARIANT");
-        variant = e ? atoi(e) : 1;
-    }
-    return variant;
-}
-
 // Candidate pass, row-major queries (any d % 64 == 0): queries_bf16 [n_q, d] (bf16), db [n_db, d] fp32.  Every (q, row) with
 // approximate score >= thr_dev[q] is appended to cand_keys [n_q, cap] (uint64: ordered(approx) << 32 | ~(row_base + row)),
 // cand_cnt [n_q] (uint32, zero it first; counts keep growing past cap: overflow is visible).  max_norm2 (device float, zero it
@@ -490,7 +492,6 @@ SWAT_API int swat_sim_candidates_bf16(const void* queries_bf16, int n_q, const f
     SWAT_REQUIRE(row_base + n_db < (1ll << 32), "swat_sim_candidates_bf16: global rows must fit 32 bits");
     SWAT_REQUIRE((int64_t)n_q * d < (1ll << 30), "swat_sim_candidates_bf16: query matrix too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)s;
-    const int variant = dense_variant();
 #define SWAT_CAND(NQT_, NF_, MAXG_)                                                                                      \
     {                                                                                                                    \
         const int64_t nblocks = (n_db + 64 * NF_ - 1) / (64 * NF_);                                                      \
@@ -501,8 +502,8 @@ SWAT_API int swat_sim_candidates_bf16(const void* queries_bf16, int n_q, const f
     }
     for (int q0 = 0; q0 < n_q;) {
         const int left = n_q - q0;
-        if (left > 128) {  // 13 query tiles = 208 queries, 52 KB of LDS: three (NF 1) or two (NF 2) workgroups per CU, all resident
-            if (variant == 2) SWAT_CAND(13, 2, 512) else SWAT_CAND(13, 1, 768)
+        if (left > 128) {  // 13 query tiles = 208 queries, 52 KB of LDS: three workgroups per CU, all resident
+            SWAT_CAND(13, 1, 768)
             q0 += 16 * 13;
         } else if (left > 32) {
             SWAT_CAND(8, 1, 1024)

@@ -11,7 +11,7 @@ db = torch.randn(n, d, device=dev, generator=g); db /= db.norm(dim=-1, keepdim=T
 q = torch.randn(nq, d, device=dev, generator=g); q /= q.norm(dim=-1, keepdim=True)
 def ev(): return torch.cuda.Event(enable_timing=True)
 dense.topk_dense(db, q, k); torch.cuda.synchronize()
-print("route:", dense.last_path, "| SWAT_DENSE_VARIANT =", os.environ.get("SWAT_DENSE_VARIANT", "1"))
+print("route:", dense.last_path, "| SWAT_DENSE_WAVES =", os.environ.get("SWAT_DENSE_WAVES", "12"))
 c = dense._cache
 for rep in range(3):
     a, b = ev(), ev()

@@ -199,34 +199,45 @@ __global__ __launch_bounds__(256) void near_dup_kernel(const float* __restrict__
     if (hit) marks[col] = 1;  // every writer stores the same value
 }
 
-// One block per query: sort its candidate keys (<= CAND_MAX) descending, emit the first k.
+// One block per query: sort its candidate keys (<= CAND_MAX) descending, emit the first k.  Bitonic network in LDS on 1024
+// threads; a compare-exchange stage of stride <= 64 stays inside the 128-key block its wave owns (pairs i0 .. i0+63 touch
+// keys 2 i0 .. 2 i0 + 127), so only the stages of stride >= 128 — 10 of the 66 for 2048 keys — pay a workgroup barrier; the
+// others are ordered by the wave's own in-order LDS queue.
 constexpr int CAND_MAX = 8192;
-__global__ __launch_bounds__(256) void candidates_topk_kernel(const unsigned long long* __restrict__ cand, int cap,
-                                                              const unsigned* __restrict__ cnt, int k,
-                                                              int64_t* __restrict__ out_idx, float* __restrict__ out_val,
-                                                              int64_t* __restrict__ out_cnt) {
+__global__ __launch_bounds__(1024) void candidates_topk_kernel(const unsigned long long* __restrict__ cand, int cap,
+                                                               const unsigned* __restrict__ cnt, int k,
+                                                               int64_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                               int64_t* __restrict__ out_cnt) {
     __shared__ unsigned long long keys[CAND_MAX];
     const int q = blockIdx.x, tid = threadIdx.x;
     unsigned n = cnt[q];
     if (n > (unsigned)cap) n = cap;
     int np2 = 1;
     while (np2 < (int)n) np2 <<= 1;
-    for (int i = tid; i < np2; i += 256) keys[i] = i < (int)n ? cand[q * (int64_t)cap + i] : 0ull;
+    for (int i = tid; i < np2; i += 1024) keys[i] = i < (int)n ? cand[q * (int64_t)cap + i] : 0ull;
     __syncthreads();
     for (int size = 2; size <= np2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < np2 / 2; i += 256) {
+            if (stride >= 128) __syncthreads();  // reads keys other waves wrote
+            for (int i = tid; i < np2 / 2; i += 1024) {
                 const int lo = 2 * i - (i & (stride - 1));
                 const int hi = lo + stride;
                 const bool desc = ((lo & size) == 0);
                 const unsigned long long a = keys[lo], c = keys[hi];
                 if ((a < c) == desc) { keys[lo] = c; keys[hi] = a; }
             }
-            __syncthreads();
+            if (stride >= 128) {
+                __syncthreads();
+            } else {  // wave-local stage: the wave's LDS operations execute in order; keep the compiler from caching keys
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
     }
+    __syncthreads();
     const int kk = (int)n < k ? (int)n : k;
-    for (int r = tid; r < k; r += 256) {
+    for (int r = tid; r < k; r += 1024) {
         int64_t idx = -1;
         float val = -INFINITY;
         if (r < kk) {
@@ -266,7 +277,7 @@ SWAT_API int swat_sim_topk_candidates(const float* queries, int n_q, const float
 SWAT_API int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k, int64_t* out_idx,
                                   float* out_val, int64_t* out_cnt, swat_stream_t s) {
     SWAT_REQUIRE(cap >= 1 && cap <= CAND_MAX && k >= 1 && k <= cap, "swat_candidates_topk: need 1 <= k <= cap <= %d", CAND_MAX);
-    hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(256), 0, (hipStream_t)s, (const unsigned long long*)cand_keys,
+    hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, (const unsigned long long*)cand_keys,
                        cap, (const unsigned*)cand_cnt, k, out_idx, out_val, out_cnt);
     return check_launch("swat_candidates_topk");
 }

@@ -213,15 +213,27 @@ __global__ __launch_bounds__(256) void segment_topk_kernel(const float* __restri
                 if (key != 0ull && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned cum = 0;
-                int dsel = 0;
-                for (int dgt = 255; dgt >= 0; --dgt) {
-                    if (cum + hist[dgt] >= remaining) { dsel = dgt; break; }
-                    cum += hist[dgt];
+            if (tid < 64) {
+                // wave 0 finds the digit that holds the remaining-th largest key: lane l owns digits 255-4l .. 252-4l; a
+                // shuffle prefix gives the count of keys in larger digits (was: one thread walking 256 bins, 8 times)
+                unsigned h[4], mine = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { h[j] = hist[255 - 4 * tid - j]; mine += h[j]; }
+                unsigned incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+                    if (tid >= o) incl += up;
                 }
-                s_remaining = remaining - cum;
-                s_prefix = prefix | ((unsigned long long)dsel << shift);
+                unsigned before = incl - mine;  // keys in digits above this lane's four
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (before < remaining && before + h[j] >= remaining) {  // true for exactly one (lane, j)
+                        s_remaining = remaining - before;
+                        s_prefix = prefix | ((unsigned long long)(255 - 4 * tid - j) << shift);
+                    }
+                    before += h[j];
+                }
             }
             __syncthreads();
             remaining = s_remaining;
@@ -246,9 +258,11 @@ __global__ __launch_bounds__(256) void segment_topk_kernel(const float* __restri
     }
     __syncthreads();
 
-    // bitonic sort, descending
+    // bitonic sort, descending; stages of stride <= 64 stay inside the 128-key block a wave owns (no workgroup barrier:
+    // the wave's LDS operations execute in order), see candidates_topk_kernel
     for (int size = 2; size <= npow2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 128) __syncthreads();
             for (int i = tid; i < npow2 / 2; i += 256) {
                 const int lo = 2 * i - (i & (stride - 1));
                 const int hi = lo + stride;
@@ -256,9 +270,16 @@ __global__ __launch_bounds__(256) void segment_topk_kernel(const float* __restri
                 const unsigned long long a = keys[lo], c = keys[hi];
                 if ((a < c) == desc) { keys[lo] = c; keys[hi] = a; }
             }
-            __syncthreads();
+            if (stride >= 128) {
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
     }
+    __syncthreads();
 
     for (int r = tid; r < k; r += 256) {
         int64_t idx = -1;

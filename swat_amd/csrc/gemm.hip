@@ -771,7 +771,7 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
 // n products of one layout (the weight gradients of a transformer block): ONE persistent launch over the joint tile list
 // when every product qualifies for the producer / consumer kernel's grouped form, else one launch each.
 int gemm_group_dispatch(int layout, const GemmArgs* probs, int n, hipStream_t s) {
-    bool ok = layout == L_TN && n >= 2 && n <= 4 && !(g_exp & 512) && g_force_cfg < 0;
+    bool ok = layout == L_TN && n >= 2 && n <= 64 && !(g_exp & 512) && g_force_cfg < 0;
     for (int i = 0; ok && i < n; ++i) {
         const GemmArgs& a = probs[i];
         ok = a.K % 64 == 0 && a.K >= 256 && a.out_f32 && a.N % 4 == 0 && a.ldc % 4 == 0 && !a.actin && !a.C2 && a.inner == 1 &&

@@ -22,6 +22,9 @@
 #include <hip/hip_ext.h>
 #include <type_traits>
 #include <utility>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
 #include "gemm_device.hpp"
 #include "../../include/swat_hip.h"
 #include "../../include/swat_hip_tuning.h"
@@ -536,14 +539,31 @@ __global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pc_kernel(const Gemm
 // into the next tile's operands while the consumers finish a tile, park its accumulators in an LDS tile of its own
 // (behind the ring) and store it with the fused epilogue; one extra barrier per tile.  Tiles of a workgroup are
 // b, b + G, b + 2G, ... of the joint list after the XCD-contiguous remap, so an XCD's L2 keeps serving the same panels.
-struct GemmGroup {
+constexpr int PCG_MAX = 64;     // products per launch (a 12-block chunk of a tower = 48)
+constexpr int PCG_MAX_WG = 512;  // persistent workgroups
+struct GemmGroup {               // lives in device memory (built once per distinct product list, launch_gemm_pc_group)
     int n, total;
-    int tile_end[4];
-    GemmArgs p[4];
+    int tile_end[PCG_MAX];       // running tile count behind product i
+    int wg_stages[PCG_MAX_WG];   // all k-steps of all tiles of workgroup b (the loaders' stream length)
+    GemmArgs p[PCG_MAX];
 };
 
+// joint tile list -> (problem, tile row, tile column), after the XCD-contiguous remap of the virtual tile number
+__host__ __device__ inline void pcg_decode(const int* tile_end, int n, int total, int vt, int& pi, int& id_in) {
+    const int xcd = vt & 7, q = total >> 3, r = total & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vt >> 3);
+    int lo = 0, hi = n - 1;  // first product whose tile_end exceeds id
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (id >= tile_end[mid]) lo = mid + 1; else hi = mid;
+    }
+    pi = lo;
+    id_in = id - (lo ? tile_end[lo - 1] : 0);
+}
+
 template <int LAYOUT, int BM, int BN, int CM, int CN, int NL, int NS>
-__global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pcg_kernel(const GemmGroup g) {
+__global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pcg_kernel(const GemmGroup* __restrict__ gp) {
+    const GemmGroup& g = *gp;
     constexpr bool A_KC = (LAYOUT != L_TN);
     constexpr bool B_KC = (LAYOUT == L_NT);
     constexpr int NC = CM * CN;
@@ -567,16 +587,9 @@ __global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pcg_kernel(const Gem
     const int G = gridDim.x, total = g.total;
     const int ntiles = (total - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup (>= 1: G <= total)
 
-    // joint tile list -> (problem, tile row, tile column), after the XCD-contiguous remap of the virtual tile number
     auto decode = [&](int vt, int& pi, int& by, int& bx) {
-        const int xcd = vt & 7, q = total >> 3, r = total & 7;
-        int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vt >> 3);
-        pi = 0;
-        int base = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k + 1 < g.n && id >= g.tile_end[k]) { pi = k + 1; base = g.tile_end[k]; }
-        id -= base;
+        int id;
+        pcg_decode(g.tile_end, g.n, total, vt, pi, id);
         const int tm = g.p[pi].tiles_m, tn = g.p[pi].tiles_n;
         if (g.p[pi].swz == 2) { bx = id % tn; by = id / tn; }
         else { by = id % tm; bx = id / tm; }
@@ -638,13 +651,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pcg_kernel(const Gem
         };
         int ti_issue = 0;  // tile the next issue belongs to
         open_tile(0);
-        int64_t stages_total = 0;  // all k-steps of all tiles of this workgroup
-        for (int ti = 0; ti < ntiles; ++ti) {
-            int pi, by, bx;
-            decode((int)blockIdx.x + ti * G, pi, by, bx);
-            stages_total += g.p[pi].K >> 6;
-        }
-        const int S = (int)stages_total;
+        const int S = g.wg_stages[blockIdx.x];  // all k-steps of all tiles of this workgroup (host-computed)
         int issued = 0, buf = 0;
         auto issue = [&]() {  // next stage of the stream into ring buffer `buf`
             unsigned char* st = smem + buf * STAGE + lw * 1024;
@@ -827,24 +834,88 @@ __global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pcg_kernel(const Gem
     }
 }
 
-int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    SWAT_REQUIRE(n >= 1 && n <= 4, "gemm group: 1-4 products");
-    GemmGroup g{};
-    g.n = n;
-    int total = 0;
-    for (int i = 0; i < n; ++i) {
-        g.p[i] = probs[i];
-        (void)plan_grid(g.p[i], 96, 96, 1);
-        if (g.p[i].swz == 0) g.p[i].swz = 1;  // small grids: any walk
-        total += g.p[i].tiles_m * g.p[i].tiles_n;
-        g.tile_end[i] = total;
+// Descriptor cache: the product lists of a training job repeat every step (same buffers), so a list is uploaded once.
+struct PcgSig {  // what identifies a product (GemmArgs has padding bytes: never compared raw)
+    const void *A, *B, *C, *colsum;
+    int M, N, K, lda, ldb, ldc;
+    bool operator==(const PcgSig& o) const {
+        return A == o.A && B == o.B && C == o.C && colsum == o.colsum && M == o.M && N == o.N && K == o.K && lda == o.lda &&
+               ldb == o.ldb && ldc == o.ldc;
     }
-    g.total = total;
-    int G = total < 256 ? total : 256;
+};
+struct PcgEntry {
+    std::vector<PcgSig> sig;
+    GemmGroup* dev;
+    int G, tile;
+};
+static std::vector<PcgEntry> g_pcg_cache;
+
+int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    SWAT_REQUIRE(n >= 1 && n <= PCG_MAX, "gemm group: 1-%d products", PCG_MAX);
     SWAT_REQUIRE(layout == L_TN, "gemm group: built for the weight-gradient layout only");
-    auto kern = gemm_pcg_kernel<L_TN, 96, 96, 2, 2, 4, 4>;
-    if (ev0) hipExtLaunchKernelGGL(kern, dim3(G), dim3(512), 0, s, ev0, ev1, 0, g);
-    else hipLaunchKernelGGL(kern, dim3(G), dim3(512), 0, s, g);
+    // tuning (SWAT_WGRAD_TILE): 96 = 96 x 96 tiles, one workgroup per CU (default); 64 = 64 x 64 tiles, two per CU (measured
+    // slower: 884 vs 656 us for the 48 weight gradients of a ViT-B/32 backward, tools/perf_wgrad_group.py)
+    static const int tile = getenv("SWAT_WGRAD_TILE") ? atoi(getenv("SWAT_WGRAD_TILE")) : 96;
+    const int bt = tile == 96 ? 96 : 64, maxg = tile == 96 ? 256 : 512;
+    std::vector<PcgSig> sig(n);
+    for (int i = 0; i < n; ++i)
+        sig[i] = PcgSig{probs[i].A, probs[i].B, probs[i].C, probs[i].colsum, probs[i].M, probs[i].N, probs[i].K,
+                        probs[i].lda, probs[i].ldb, probs[i].ldc};
+    PcgEntry* e = nullptr;
+    for (auto& c : g_pcg_cache)
+        if (c.tile == bt && c.sig == sig) e = &c;
+    if (!e) {
+        if (g_pcg_cache.size() >= 64) {  // a job uses a handful of lists; recycle the oldest beyond that
+            (void)hipFree(g_pcg_cache.front().dev);
+            g_pcg_cache.erase(g_pcg_cache.begin());
+        }
+        GemmGroup* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(GemmGroup)) != hipSuccess) {
+            set_error("gemm group: hipMalloc of the descriptor failed");
+            return -1;
+        }
+        int total = 0;
+        GemmGroup* up = (GemmGroup*)calloc(1, sizeof(GemmGroup));  // planned copies: tile grid, walk order, per-workgroup stream length
+        SWAT_REQUIRE(up, "gemm group: out of host memory");
+        for (int i = 0; i < n; ++i) {
+            up->p[i] = probs[i];
+            (void)plan_grid(up->p[i], bt, bt, 1);
+            if (up->p[i].swz == 0) up->p[i].swz = 1;  // small grids: any walk
+            total += up->p[i].tiles_m * up->p[i].tiles_n;
+            up->tile_end[i] = total;
+        }
+        up->n = n;
+        up->total = total;
+        const int G = total < maxg ? total : maxg;
+        for (int b = 0; b < G; ++b) {
+            int st = 0;
+            for (int vt = b; vt < total; vt += G) {
+                int pi, id;
+                pcg_decode(up->tile_end, n, total, vt, pi, id);
+                st += up->p[pi].K >> 6;
+            }
+            up->wg_stages[b] = st;
+        }
+        // synchronous upload (once per distinct list): the staging copy can be freed right away
+        const hipError_t ce = hipMemcpy(d, up, sizeof(GemmGroup), hipMemcpyHostToDevice);
+        free(up);
+        if (ce != hipSuccess) {
+            (void)hipFree(d);
+            set_error("gemm group: descriptor upload failed: %s", hipGetErrorString(ce));
+            return -1;
+        }
+        g_pcg_cache.push_back(PcgEntry{sig, d, G, bt});
+        e = &g_pcg_cache.back();
+    }
+    if (bt == 96) {
+        auto kern = gemm_pcg_kernel<L_TN, 96, 96, 2, 2, 4, 4>;
+        if (ev0) hipExtLaunchKernelGGL(kern, dim3(e->G), dim3(512), 0, s, ev0, ev1, 0, (const GemmGroup*)e->dev);
+        else hipLaunchKernelGGL(kern, dim3(e->G), dim3(512), 0, s, (const GemmGroup*)e->dev);
+    } else {
+        auto kern = gemm_pcg_kernel<L_TN, 64, 64, 2, 2, 4, 4>;
+        if (ev0) hipExtLaunchKernelGGL(kern, dim3(e->G), dim3(512), 0, s, ev0, ev1, 0, (const GemmGroup*)e->dev);
+        else hipLaunchKernelGGL(kern, dim3(e->G), dim3(512), 0, s, (const GemmGroup*)e->dev);
+    }
     return check_launch("swat_gemm group (pc)");
 }
 

@@ -258,8 +258,8 @@ SWAT_API int swat_linear_wgrad_bias(const void* dY_bf16, const void* X_bf16, flo
 SWAT_API int swat_linear_wgrad_bias_group(int n, const void* const* dY_bf16, const void* const* X_bf16, float* const* dW,
                                           float* const* dbias, const int* rows, const int* n_out, const int* n_in,
                                           const int* ld_dy, const int* ld_x, void* workspace, swat_stream_t stream) {
-    SWAT_REQUIRE(n >= 1 && n <= 4 && dY_bf16 && X_bf16 && dW && dbias && rows && n_out && n_in && ld_dy && ld_x,
-                 "swat_linear_wgrad_bias_group: 1-4 layers, non-null arrays");
+    SWAT_REQUIRE(n >= 1 && n <= 64 && dY_bf16 && X_bf16 && dW && dbias && rows && n_out && n_in && ld_dy && ld_x,
+                 "swat_linear_wgrad_bias_group: 1-64 layers, non-null arrays");
     hipStream_t s = (hipStream_t)stream;
     bool fused = true;
     for (int i = 0; i < n; ++i) {
@@ -274,7 +274,7 @@ SWAT_API int swat_linear_wgrad_bias_group(int n, const void* const* dY_bf16, con
         }
         return 0;
     }
-    GemmArgs a[4];
+    GemmArgs a[64];
     for (int i = 0; i < n; ++i) {
         a[i] = G(dY_bf16[i], X_bf16[i], dW[i], n_out[i], n_in[i], rows[i], ld_dy[i], ld_x[i], n_in[i], 1);
         a[i].colsum = dbias[i];

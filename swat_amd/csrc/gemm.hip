@@ -28,6 +28,8 @@
 // loads/stores are 8-16 B per lane.
 #include <hip/hip_ext.h>
 #include "kernels.hpp"
+#include <stdio.h>
+#include <stdlib.h>
 #include "gemm_device.hpp"
 #include "../../include/swat_hip.h"
 #include "../../include/swat_hip_tuning.h"
@@ -680,7 +682,26 @@ static int launch_gemm(const GemmArgs& a, int batch, int cfg, hipStream_t s, hip
 
 static int g_force_cfg = -1;  // swat_gemm_set_tile(): experiments / tests pin one configuration
 
+static int pick_cfg_base(int layout, const GemmArgs& a, int batch);
 static int pick_cfg(int layout, const GemmArgs& a, int batch) {
+    // tuning (SWAT_PC_MAP="53:60,54:61"): replace a chosen configuration by another one inside the step
+    static int map[128], init = 0;
+    if (!init) {
+        for (int i = 0; i < 128; ++i) map[i] = i;
+        if (const char* e = getenv("SWAT_PC_MAP")) {
+            int from, to, n = 0;
+            while (sscanf(e, "%d:%d%n", &from, &to, &n) == 2) {
+                if (from >= 0 && from < 128) map[from] = to;
+                e += n;
+                if (*e == ',') ++e;
+            }
+        }
+        init = 1;
+    }
+    const int c = pick_cfg_base(layout, a, batch);
+    return c >= 0 && c < 128 ? map[c] : c;
+}
+static int pick_cfg_base(int layout, const GemmArgs& a, int batch) {
     if (g_force_cfg >= 0) return g_force_cfg;
     // Measured on MI355X (rocprofv3 kernel durations, tools/exp_trace.py; M = B*T = 1600).  The launches are short
     // (10-30 us) and run as lock-step rounds of resident workgroups (tools/block_timeline.py), each round paying its

@@ -251,6 +251,17 @@ def retrieval_secondary(dev, rank=0, world=1, d=512, steps=5, with_cpu=True):
     torch.cuda.synchronize()
     ms_sim = e[0].elapsed_time(e[1]) / steps
     ms_topk = e[2].elapsed_time(e[3]) / steps
+    # the same pass with 25 % of the rows excluded (the duplicates / zero-shot-filter mask of the reference's walk)
+    excl = (torch.rand(n, device=dev, generator=torch.Generator(device=dev).manual_seed(5)) < 0.25).to(torch.uint8)
+    e2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e2[0].record()
+    for _ in range(steps):
+        ops.similarity_segmented(cap, q, row_seg, out=s1)
+        ops.similarity_segmented(img, q, row_seg, out=s2)
+        ops.segment_topk(s1, off, k, thr=0.0, t2i=s2, t2i_thr=0.25, excluded=excl)
+    e2[1].record()
+    torch.cuda.synchronize()
+    ms_masked = e2[0].elapsed_time(e2[1]) / steps
     gbs = n * d * 4 / 1e9 / (ms_sim * 1e-3)
     passing = float((s2 > 0.25).float().mean().item())
     rec = {"metric": "retrieval top-k queries/s (T2T-rank-T2I-tshd, per-class queries)", "value": round(nseg / (ms_all * 1e-3), 1),
@@ -258,7 +269,7 @@ def retrieval_secondary(dev, rank=0, world=1, d=512, steps=5, with_cpu=True):
            "config": {"workload": f"{world} x {n} x {d} fp32 rows x 2 matrices (caption + image features), {nseg} class queries, k={k}, "
                                   f"thr=0.0, t2i_thr=0.25 (synthetic T2I cosines straddle it: {100 * passing:.0f} % of the {n // nseg} rows of a class pass)"
                                   + (", all_gather + k-way merge of the per-rank lists" if world > 1 else "")},
-           "ms_per_pass": round(ms_all, 3), "ms_segment_topk": round(ms_topk, 4),
+           "ms_per_pass": round(ms_all, 3), "ms_segment_topk": round(ms_topk, 4), "ms_per_pass_25pct_rows_masked": round(ms_masked, 3),
            "roofline": {"bound": "hbm", "kernel": "sim_segmented_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("sim_segmented_kernel", d),
                         "algorithmic_bytes_per_launch": n * d * 4, "avg_ms": round(ms_sim, 4),
@@ -421,6 +432,20 @@ def retrieval_dense_secondary(dev, rank=0, world=1, steps=5, with_cpu=True):
                         "traffic": _pmc_traffic("sim_candidates_bf16_deep_kernel"), "algorithmic_bytes_per_launch": n * d * 4,
                         "avg_ms": round(ms_k, 4), "pass_frac": round(n * d * 4 / 1e9 / dt / HBM_PEAK_GBS, 4),
                         "mfma": {"achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}}}
+    if world == 1:  # Nq in {1, 200, 1000}; queries from seed 11
+        other = {}
+        for nq2 in (1, 1000):
+            q2 = _unit(torch.randn(nq2, d, device=dev, generator=torch.Generator(device=dev).manual_seed(11)))
+            dense.topk_dense(db, q2, k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                dense.topk_dense(db, q2, k)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / steps
+            other[str(nq2)] = {"queries_per_s": round(nq2 / t, 1), "ms_per_pass": round(t * 1e3, 3), "route": dense.last_path,
+                               "hbm_frac_whole_pass": round(n * d * 4 / 1e9 / t / HBM_PEAK_GBS, 4)}
+        rec["other_nq"] = other
     if with_cpu and world == 1:
         rec["cpu_baseline"] = dense_cpu_baseline(db, q, k, idx, val)
     return rec

@@ -56,3 +56,26 @@ def segment_topk(sims, seg_offsets, k, thr=0.0, t2i=None, t2i_thr=0.25, excluded
                                       _lib.stream())
     _lib.check(rc, "swat_segment_topk")
     return idx, val, cnt
+
+
+def i2i_similarity_p2p(fewshot_embedding, img_embeddings, mode):
+    """ref: retrieval/sample_retrieval.py:369-394 — similarity of every row of img_embeddings [n, d] to the few-shot
+    embeddings (a list of d-vectors or an [m, d] array), reduced over the few-shot axis by 'min' | 'max' | 'mean';
+    returns a Python list of n floats like the reference.  The [m, n] product is the canonical k-ordered fp32 chain
+    (swat_sim_topk_candidates), the reduction runs over the few-shot rows in order — bit-identical to
+    oracle/retrieval_oracle.c:orc_similarity_p2p."""
+    import numpy as np
+    from . import dense
+    if mode not in ("min", "max", "mean"):
+        raise ValueError('Invalid mode type.')
+    if not isinstance(img_embeddings, torch.Tensor) or not img_embeddings.is_cuda:
+        raise _lib.SwatHipError("i2i_similarity_p2p needs the image embeddings on the GPU (no CPU fallback)")
+    fs = fewshot_embedding if isinstance(fewshot_embedding, torch.Tensor) else torch.from_numpy(np.stack(fewshot_embedding))
+    fs = fs.to(img_embeddings.device, torch.float32).contiguous()
+    S = dense.sim_matrix(fs, img_embeddings.float().contiguous())  # [m, n]
+    r = S[0].clone()
+    for j in range(1, S.shape[0]):
+        r = torch.minimum(r, S[j]) if mode == "min" else torch.maximum(r, S[j]) if mode == "max" else r + S[j]
+    if mode == "mean":
+        r = r / float(S.shape[0])
+    return r.cpu().tolist()

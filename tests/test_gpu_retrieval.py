@@ -251,6 +251,26 @@ def test_sim_gathered_is_the_scan_on_a_row_list():
 
 
 @pytest.mark.parametrize("kind", ["grid", "float"])
+@pytest.mark.parametrize("mode", ["min", "max", "mean"])
+def test_p2p_similarity_matches_oracle_and_reference_golden(golden_dir, kind, mode):
+    """i2i_similarity_p2p (ref :369-394): bit-exact against the C oracle; against the imported reference's output exact on
+    the grid case (min / max) and within 1e-6 elsewhere (its BLAS order is unspecified)."""
+    from swat_amd.retrieval import ops
+    g, spec, case = _load(golden_dir, kind)
+    c0 = min(case["class_ids"])
+    rows = np.nonzero(case["labels"] == c0)[0]
+    img = torch.from_numpy(case["img"][rows]).to(_dev())
+    got = np.array(ops.i2i_similarity_p2p([case["img"][r] for r in rows[:16]], img, mode), np.float32)
+    assert np.array_equal(got.view(np.uint32), orc.similarity_p2p(case["img"][rows], case["img"][rows[:16]], mode).view(np.uint32))
+    if kind == "grid" and mode != "mean":
+        assert np.array_equal(got, g[f"p2p_{mode}"])
+    else:
+        assert np.abs(got - g[f"p2p_{mode}"]).max() <= 1e-6
+    with pytest.raises(ValueError):
+        ops.i2i_similarity_p2p([case["img"][0]], img, "median")
+
+
+@pytest.mark.parametrize("kind", ["grid", "float"])
 def test_near_dup_matches_reference_golden(golden_dir, kind):
     from swat_amd.retrieval import SegmentedIndex, dense
     g, spec, case = _load(golden_dir, kind)

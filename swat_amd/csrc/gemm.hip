@@ -738,19 +738,18 @@ static int pick_cfg_base(int layout, const GemmArgs& a, int batch) {
     const bool many_rows = (layout == L_TN ? a.K : a.M) >= 4096;
     if (layout == L_NT) {
         if (a.N >= 2048 && a.K <= 1024 && a.M >= 128) return 43;
-        return many_rows && a.K >= 2048 ? 33 : 14;
-    }
+        return many_rows && a.K >= 2048 ? 50 : 14;  // (50 = producer / consumer 128 x 128, several rounds: ViT-L/14 step 34.3 ->
+    }                                               //  32.3 ms, ViT-B/16 9.39 -> 9.05 ms against the register rings 33 / 32)
     if (layout == L_NN) {
         if (a.N >= 2048 && a.K <= 1024 && a.M >= 128) return 43;
-        if (many_rows && a.K >= 2048) return 32;
+        if (many_rows && a.K >= 2048) return 50;
         return a.K >= 384 ? 30 : 14;  // (re-checked inside the overlapped step: 43 / 30 stay the best pair)
     }
     // weight gradients run on the backward's second stream beside the data-gradient chain: alone the LDS-DMA 64x64
     // kernel is the fastest for the large ones (21 vs 22 us), but in the step the 128x128 register ring disturbs the
     // main chain least (3.65 vs 3.79 ms/step; 15 / 16 / 30 / 32 in between) — half the operand traffic through L2
     // (the same holds at 6 304 / 8 224 rows: ViT-L/14 40.1 ms/step with 33 vs 43.3 with the 128x64 LDS-DMA tile)
-    if ((int64_t)a.M * a.N >= (1 << 21)) return a.K >= 384 ? 33 : 14;
-    return a.K >= 384 ? 30 : 14;
+    if ((int64_t)a.M * a.N >= (1 << 21)) return a.K >= 384 ? 50 : 14;
     return a.K >= 384 ? 30 : 14;
 }
 
@@ -777,7 +776,9 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     // kernel's execution time as rocprofv3 reports it, without the ~2-3 us each separately recorded event adds
     hipEvent_t ev0 = prof ? g_prof.ev[2 * g_prof.n] : nullptr, ev1 = prof ? g_prof.ev[2 * g_prof.n + 1] : nullptr;
     int rc;
-    if (tile >= 50) rc = launch_gemm_pc(layout, a, batch, tile, s, ev0, ev1);
+    if (tile >= 70 && tile <= 72 && batch == 1 && a.inner == 1) rc = launch_gemm_pc_group(layout, &a, 1, s, ev0, ev1, tile);  // persistent tile loop
+    else if (tile >= 70) { set_error("gemm: persistent configuration %d needs one unbatched product", tile); rc = -1; }
+    else if (tile >= 50) rc = launch_gemm_pc(layout, a, batch, tile, s, ev0, ev1);
     else if (layout == L_NT) rc = launch_gemm<L_NT>(a, batch, tile, s, ev0, ev1);
     else if (layout == L_NN) rc = launch_gemm<L_NN>(a, batch, tile, s, ev0, ev1);
     else rc = launch_gemm<L_TN>(a, batch, tile, s, ev0, ev1);

@@ -24,6 +24,8 @@
 #include <utility>
 #include <stdlib.h>
 #include <string.h>
+#include <stddef.h>
+#include <unordered_map>
 #include <vector>
 #include "gemm_device.hpp"
 #include "../../include/swat_hip.h"
@@ -834,59 +836,82 @@ __global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pcg_kernel(const Gem
     }
 }
 
-// Descriptor cache: the product lists of a training job repeat every step (same buffers), so a list is uploaded once.
-struct PcgSig {  // what identifies a product (GemmArgs has padding bytes: never compared raw)
-    const void *A, *B, *C, *colsum;
-    int M, N, K, lda, ldb, ldc;
-    bool operator==(const PcgSig& o) const {
-        return A == o.A && B == o.B && C == o.C && colsum == o.colsum && M == o.M && N == o.N && K == o.K && lda == o.lda &&
-               ldb == o.ldb && ldc == o.ldc;
-    }
+// Descriptor cache: the product lists of a training job repeat every step (same buffers), so a list is uploaded once and
+// kept for the life of the process (a ViT-L/14 step has ~200 distinct lists of one product: 3 KB of device memory each).
+struct PcgSig {  // what identifies a product (GemmArgs has padding bytes: never compared raw); 64 bytes, no padding
+    const void *A, *B, *C, *C2, *bias, *aux;  // aux: residual / actin / rowbias / colsum folded together
+    int M, N, K, lda, ldb, ldc, flags, pad;
+    bool operator==(const PcgSig& o) const { return memcmp(this, &o, sizeof(PcgSig)) == 0; }
 };
 struct PcgEntry {
     std::vector<PcgSig> sig;
     GemmGroup* dev;
-    int G, tile;
+    int G, cfg, layout;
 };
-static std::vector<PcgEntry> g_pcg_cache;
+static std::unordered_map<uint64_t, std::vector<PcgEntry>> g_pcg_cache;
 
-int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+struct PcgTile { int bm, bn, maxg; };
+static PcgTile pcg_tile(int layout, int cfg) {
+    // cfg 0: the layout's default — TN 96 x 96 (SWAT_WGRAD_TILE=64: 64 x 64, two workgroups per CU, measured slower), NT / NN
+    // 128 x 64; 70 = 128 x 64, 71 = 96 x 96, 72 = 64 x 64 (two per CU)
+    static const int wt = getenv("SWAT_WGRAD_TILE") ? atoi(getenv("SWAT_WGRAD_TILE")) : 96;  // tuning
+    if (cfg == 0) cfg = layout == L_TN ? (wt == 64 ? 72 : 71) : 70;
+    if (cfg == 70) return PcgTile{128, 64, 256};
+    if (cfg == 72) return PcgTile{64, 64, 512};
+    return PcgTile{96, 96, 256};
+}
+
+template <int LAYOUT>
+static void pcg_launch(const PcgTile& t, int G, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const GemmGroup* d) {
+#define SWAT_PCG(BM_, BN_)                                                                                             \
+    {                                                                                                                  \
+        auto kern = gemm_pcg_kernel<LAYOUT, BM_, BN_, 2, 2, 4, 4>;                                                     \
+        if (ev0) hipExtLaunchKernelGGL(kern, dim3(G), dim3(512), 0, s, ev0, ev1, 0, d);                                \
+        else hipLaunchKernelGGL(kern, dim3(G), dim3(512), 0, s, d);                                                    \
+    }
+    if (t.bm == 128) SWAT_PCG(128, 64) else if (t.bm == 96) SWAT_PCG(96, 96) else SWAT_PCG(64, 64)
+#undef SWAT_PCG
+}
+
+int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int cfg) {
     SWAT_REQUIRE(n >= 1 && n <= PCG_MAX, "gemm group: 1-%d products", PCG_MAX);
-    SWAT_REQUIRE(layout == L_TN, "gemm group: built for the weight-gradient layout only");
-    // tuning (SWAT_WGRAD_TILE): 96 = 96 x 96 tiles, one workgroup per CU (default); 64 = 64 x 64 tiles, two per CU (measured
-    // slower: 884 vs 656 us for the 48 weight gradients of a ViT-B/32 backward, tools/perf_wgrad_group.py)
-    static const int tile = getenv("SWAT_WGRAD_TILE") ? atoi(getenv("SWAT_WGRAD_TILE")) : 96;
-    const int bt = tile == 96 ? 96 : 64, maxg = tile == 96 ? 256 : 512;
+    const PcgTile t = pcg_tile(layout, cfg);
     std::vector<PcgSig> sig(n);
-    for (int i = 0; i < n; ++i)
-        sig[i] = PcgSig{probs[i].A, probs[i].B, probs[i].C, probs[i].colsum, probs[i].M, probs[i].N, probs[i].K,
-                        probs[i].lda, probs[i].ldb, probs[i].ldc};
+    uint64_t key = 1469598103934665603ull ^ (uint64_t)(t.bm * 1024 + t.bn) ^ ((uint64_t)layout << 40);
+    for (int i = 0; i < n; ++i) {
+        const GemmArgs& a = probs[i];
+        memset(&sig[i], 0, sizeof(PcgSig));
+        sig[i].A = a.A; sig[i].B = a.B; sig[i].C = a.C; sig[i].C2 = a.C2; sig[i].bias = a.bias;
+        sig[i].aux = (const void*)((uintptr_t)a.residual ^ ((uintptr_t)a.actin << 1) ^ ((uintptr_t)a.rowbias << 2) ^ ((uintptr_t)a.colsum << 3));
+        sig[i].M = a.M; sig[i].N = a.N; sig[i].K = a.K; sig[i].lda = a.lda; sig[i].ldb = a.ldb; sig[i].ldc = a.ldc;
+        sig[i].flags = a.act | (a.out_f32 << 4) | (a.rpg << 8) | (a.ldact << 16);
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(&sig[i]);
+        for (size_t j = 0; j < sizeof(PcgSig); ++j) key = (key ^ b[j]) * 1099511628211ull;
+    }
     PcgEntry* e = nullptr;
-    for (auto& c : g_pcg_cache)
-        if (c.tile == bt && c.sig == sig) e = &c;
+    auto& bucket = g_pcg_cache[key];
+    for (auto& c : bucket)
+        if (c.cfg == t.bm * 1024 + t.bn && c.layout == layout && c.sig == sig) e = &c;
     if (!e) {
-        if (g_pcg_cache.size() >= 64) {  // a job uses a handful of lists; recycle the oldest beyond that
-            (void)hipFree(g_pcg_cache.front().dev);
-            g_pcg_cache.erase(g_pcg_cache.begin());
-        }
+        const size_t bytes = offsetof(GemmGroup, p) + (size_t)n * sizeof(GemmArgs);
         GemmGroup* d = nullptr;
-        if (hipMalloc((void**)&d, sizeof(GemmGroup)) != hipSuccess) {
+        if (hipMalloc((void**)&d, bytes) != hipSuccess) {
             set_error("gemm group: hipMalloc of the descriptor failed");
             return -1;
         }
-        int total = 0;
         GemmGroup* up = (GemmGroup*)calloc(1, sizeof(GemmGroup));  // planned copies: tile grid, walk order, per-workgroup stream length
         SWAT_REQUIRE(up, "gemm group: out of host memory");
+        int total = 0;
         for (int i = 0; i < n; ++i) {
             up->p[i] = probs[i];
-            (void)plan_grid(up->p[i], bt, bt, 1);
+            (void)plan_grid(up->p[i], t.bm, t.bn, 1);
             if (up->p[i].swz == 0) up->p[i].swz = 1;  // small grids: any walk
             total += up->p[i].tiles_m * up->p[i].tiles_n;
             up->tile_end[i] = total;
         }
         up->n = n;
         up->total = total;
-        const int G = total < maxg ? total : maxg;
+        const int G = total < t.maxg ? total : t.maxg;
         for (int b = 0; b < G; ++b) {
             int st = 0;
             for (int vt = b; vt < total; vt += G) {
@@ -897,25 +922,19 @@ int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s
             up->wg_stages[b] = st;
         }
         // synchronous upload (once per distinct list): the staging copy can be freed right away
-        const hipError_t ce = hipMemcpy(d, up, sizeof(GemmGroup), hipMemcpyHostToDevice);
+        const hipError_t ce = hipMemcpy(d, up, bytes, hipMemcpyHostToDevice);
         free(up);
         if (ce != hipSuccess) {
             (void)hipFree(d);
             set_error("gemm group: descriptor upload failed: %s", hipGetErrorString(ce));
             return -1;
         }
-        g_pcg_cache.push_back(PcgEntry{sig, d, G, bt});
-        e = &g_pcg_cache.back();
+        bucket.push_back(PcgEntry{sig, d, G, t.bm * 1024 + t.bn, layout});
+        e = &bucket.back();
     }
-    if (bt == 96) {
-        auto kern = gemm_pcg_kernel<L_TN, 96, 96, 2, 2, 4, 4>;
-        if (ev0) hipExtLaunchKernelGGL(kern, dim3(e->G), dim3(512), 0, s, ev0, ev1, 0, (const GemmGroup*)e->dev);
-        else hipLaunchKernelGGL(kern, dim3(e->G), dim3(512), 0, s, (const GemmGroup*)e->dev);
-    } else {
-        auto kern = gemm_pcg_kernel<L_TN, 64, 64, 2, 2, 4, 4>;
-        if (ev0) hipExtLaunchKernelGGL(kern, dim3(e->G), dim3(512), 0, s, ev0, ev1, 0, (const GemmGroup*)e->dev);
-        else hipLaunchKernelGGL(kern, dim3(e->G), dim3(512), 0, s, (const GemmGroup*)e->dev);
-    }
+    if (layout == L_NT) pcg_launch<L_NT>(t, e->G, s, ev0, ev1, e->dev);
+    else if (layout == L_NN) pcg_launch<L_NN>(t, e->G, s, ev0, ev1, e->dev);
+    else pcg_launch<L_TN>(t, e->G, s, ev0, ev1, e->dev);
     return check_launch("swat_gemm group (pc)");
 }
 

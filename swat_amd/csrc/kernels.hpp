@@ -41,7 +41,7 @@ dim3 plan_grid(GemmArgs& b, int bm, int bn, int batch);
 int launch_gemm_pc(int layout, const GemmArgs& a, int batch, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 // up to 64 products of one layout in ONE persistent launch (gemm_pc.hip); every product: batch 1, K % 64 == 0, fp32 or
 // bf16 output with 16-B rows (what gemm_group_dispatch checks before it comes here)
-int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int cfg = 0);
 // n products of one layout: one grouped launch when every product qualifies, else one launch each
 int gemm_group_dispatch(int layout, const GemmArgs* probs, int n, hipStream_t s);
 

@@ -83,7 +83,7 @@ def test_linear_wgrad_bias(M, N, K):
     assert (db - ref).abs().max().item() <= 1e-5 * math.sqrt(M) * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg", [50, 51, 53, 55, 56, 58])
+@pytest.mark.parametrize("cfg", [50, 51, 53, 55, 56, 58, 70, 71, 72])
 def test_gemm_producer_consumer_epilogues(cfg):
     """The producer / consumer kernel's LDS-staged epilogue: bias, activation + second output, in-place fp32 residual,
     dgrad through the activation, fp32 and bf16 outputs, ragged M edge (M = 200 is not a multiple of any tile height)."""
@@ -406,11 +406,12 @@ def test_adamw_matches_torch():
 
 
 PC_LAYOUTS = {50: ("nt", "nn", "tn"), 51: ("nt", "nn"), 53: ("nt", "nn", "tn"), 54: ("tn",), 55: ("nt", "nn", "tn"),
-              56: ("nt", "nn", "tn"), 58: ("nt", "nn")}
+              56: ("nt", "nn", "tn"), 58: ("nt", "nn"),
+              70: ("nt", "nn", "tn"), 71: ("nt", "nn", "tn"), 72: ("nt", "nn", "tn")}  # 70-72: the persistent tile loop
 
 
 @pytest.mark.parametrize("cfg", [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 43,
-                                 50, 51, 53, 54, 55, 56, 58])
+                                 50, 51, 53, 54, 55, 56, 58, 70, 71, 72])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm_every_tile_configuration(cfg, layout):
     """All register-staged and LDS-DMA pipelined tile configurations give the same product (ragged M/N edges)."""

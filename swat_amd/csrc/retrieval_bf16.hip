@@ -32,8 +32,8 @@
 //
 // Measured (MI355X, 200 queries x 1.25 M x 512, tools/perf_dense.py, profiles/r02_retrieval_*): deep kernel 0.56-0.60 ms =
 // 4.3-4.6 TB/s (0.54-0.57 of the 8 TB/s peak; HBM traffic 2.61 GB per launch against 2.56 GB algorithmic), whole exact top-k
-// 0.81-0.85 ms (memset + scan + regroup 0.62, approximate top-K2 0.08, exact re-score 0.08, exact top-k 0.02, proof + flag
-// 0.03) against 3.6 ms for the f32-matrix-core scan.  Timing ablations of the 4-wave shape (SWAT_DENSE_ABL, tuning only):
+// 0.76-0.79 ms (memset + scan + regroup 0.57-0.62, approximate top-K2 0.04, exact re-score 0.08, exact top-k 0.02, proof +
+// flag 0.03) against 3.6 ms for the f32-matrix-core scan.  Timing ablations of the 4-wave shape (SWAT_DENSE_ABL, tuning only):
 // no query DMA 0.52 ms, no MFMA / LDS reads 0.59, no barrier 0.83 of 0.94; row-major query pieces (16 half-used lines per
 // instruction instead of 8 full ones) cost 0.31 ms.  Tried and dropped: two fragments per wave (2 workgroups per CU:
 // 1.00 ms), a fifth wave touching the database 8 / 16 steps ahead (1.27 ms), eight steps of rows in flight (spills).

@@ -15,7 +15,7 @@
 //   * 12 waves per workgroup, one workgroup per CU, each wave owns 16 database rows of a 192-row block against ALL query tiles
 //     (NQT x 16 queries, NQT accumulators of 16x16); the twelve waves share one query chunk, so the L2 -> LDS query stream is
 //     0.55x the database bytes (1.66x with 4 waves per workgroup — measured as the largest single cost of that shape);
-//   * 32-deep steps; database fragments never touch LDS: lane (r16, g) loads 32 B = k 8g..8g+7 of row r16 straight into the
+//   * 32-deep steps; database fragments never touch LDS: lane (r16, g) loads 2 x 16 B = k 4g..4g+3 and 16+4g..16+4g+3 of row r16 straight into the
 //     MFMA A-fragment registers, FOUR steps ahead (a ring of four register sets, loop unrolled four times, inline-asm loads
 //     off a scalar base so the compiler neither counts nor drains them);
 //   * query chunks [16 NQT][32] bf16 come from the packed image — 1 KiB per (chunk, tile), already in LDS order, read
@@ -279,10 +279,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
     // database fragment of a step: lane reads k = 32 c + 8 g .. + 7 of row blk * BR + wave * 16 + r16 (16 rows x 128 B lines):
     // a scalar base (block, chunk) + one constant 32-bit lane offset; the last, partial block clamps its rows to n_db - 1
     const unsigned row_in_blk = (unsigned)(wave * 16 + r16);
-    const unsigned voff = (row_in_blk * (unsigned)d + 8u * g) * 4u;
+    const unsigned voff = (row_in_blk * (unsigned)d + 4u * g) * 4u;  // k 4g..4g+3 (and +16 below): 64 contiguous bytes per row and instruction
     const int64_t last_blk = nblocks - 1;
     const unsigned last_rows = (unsigned)(n_db - last_blk * BR);  // 1 .. BR
-    const unsigned voff_last = ((row_in_blk < last_rows ? row_in_blk : last_rows - 1) * (unsigned)d + 8u * g) * 4u;
+    const unsigned voff_last = ((row_in_blk < last_rows ? row_in_blk : last_rows - 1) * (unsigned)d + 4u * g) * 4u;
     const size_t blk_bytes = (size_t)BR * d * 4;
     rb_f32x4_t nx[D][2];
     const unsigned qr = (unsigned)(r16 * 64 + ((g ^ ((r16 >> 2) & 3)) << 4));
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
         const char* base = reinterpret_cast<const char*>(db) + lblk * blk_bytes + (size_t)lc * 128;  // uniform
         const unsigned off = lblk == last_blk ? voff_last : voff;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0]) : "v"(off), "s"(base));
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst[1]) : "v"(off), "s"(base));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(dst[1]) : "v"(off), "s"(base));
         next_l();
     };
     load_db(nx[0]);
@@ -456,7 +456,8 @@ __global__ __launch_bounds__(256) void regroup_candidates_kernel(const uint4* __
 }
 
 // Packed query image for the deep form: [d / 32 chunks][n_tiles][1 KiB] bf16, where the 1 KiB of (chunk c, tile T) is the LDS
-// image of queries 16T .. 16T+15, k 32c .. 32c+31: 16-B unit L holds row L / 4, k-slot (L % 4) ^ ((L / 16) % 4) — eight
+// image of queries 16T .. 16T+15, k 32c .. 32c+31: 16-B unit L holds row L / 4, k-slot s = (L % 4) ^ ((L / 16) % 4), i.e.
+// k 4s..4s+3 and 16+4s..16+4s+3 (the k-order of the scan's database fragments; a dot product does not care) — eight
 // consecutive rows of a fragment read then cover all 64 banks.  Rows >= n_q are zero.
 __global__ void pack_queries_kernel(const float* __restrict__ q, int n_q, int d, int n_tiles, unsigned short* __restrict__ out) {
     const int64_t unit = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // one 16-B unit (8 bf16)
@@ -466,11 +467,11 @@ __global__ void pack_queries_kernel(const float* __restrict__ q, int n_q, int d,
     const int64_t ct = unit >> 6;
     const int T = (int)(ct % n_tiles), c = (int)(ct / n_tiles);
     const int row = 16 * T + (L >> 2);
-    const int k0 = 32 * c + 8 * ((L & 3) ^ ((L >> 4) & 3));
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    const int k0 = 32 * c + 4 * ((L & 3) ^ ((L >> 4) & 3));  // slot s holds k 4s..4s+3 and 16+4s..16+4s+3: the order in which the
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);                     // scan's lanes read a database row (64 contiguous bytes per load)
     if (row < n_q) {
         const float* src = q + (int64_t)row * d + k0;
-        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 16);
         v = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
     }
     *reinterpret_cast<uint4*>(out + unit * 8) = v;

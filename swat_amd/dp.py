@@ -43,6 +43,9 @@ def init_from_env(args):
     if ngpu:
         torch.cuda.set_device(index)
     args.rank, args.world, args.local_rank = rank, world, local
+    if not getattr(args, 'dp_weak', False) and getattr(args, 'bsz', world) % world:
+        raise ValueError(f"--bsz {args.bsz} is split over {world} ranks: it must be a multiple of the world size "
+                         "(or use --dp_weak for --bsz rows per rank)")
     return args
 
 

@@ -83,10 +83,13 @@ _cache = {}
 
 
 def _prepared(db, queries, k, sample):
-    """Per (database, queries, k): pruning thresholds (from a row sample, exact scores), bf16 queries, |q| max, the static
-    index tensors of the re-scoring step.  Keyed on storage + version, so in-place updates invalidate it."""
-    key = (db.data_ptr(), db.shape, db._version, queries.data_ptr(), queries.shape, queries._version, k)
-    hit = _cache.get("key") == key
+    """Per (database, queries, k): pruning thresholds (from a row sample, exact scores), the packed bf16 queries, |q| max, the
+    static index tensors of the re-scoring step.  A hit needs the SAME tensor objects (weak references: a new tensor that
+    happens to reuse a freed tensor's address is a miss) at the same version, so in-place updates invalidate it too."""
+    import weakref
+    key = (db.shape, db._version, queries.shape, queries._version, k)
+    hit = (_cache.get("key") == key and _cache["db_ref"]() is db and _cache["q_ref"]() is queries
+           and _cache["ptrs"] == (db.data_ptr(), queries.data_ptr()))
     if not hit:
         nq = queries.shape[0]
         K2 = min(TOPK2_MAX, max(64, (max(2 * k, k + 256) + 63) // 64 * 64))
@@ -102,7 +105,8 @@ def _prepared(db, queries, k, sample):
         else:
             qb = queries.to(torch.bfloat16).contiguous()
         _cache.clear()
-        _cache.update(key=key, thr=thr, qb=qb, ws=ws, qn=float(queries.norm(dim=1).max().item()), K2=K2,
+        _cache.update(key=key, db_ref=weakref.ref(db), q_ref=weakref.ref(queries), ptrs=(db.data_ptr(), queries.data_ptr()),
+                      thr=thr, qb=qb, ws=ws, qn=float(queries.norm(dim=1).max().item()), K2=K2,
                       row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
                       idx2=torch.empty((nq, K2), dtype=torch.int64, device=dev), val2=torch.empty((nq, K2), dtype=torch.float32, device=dev),
                       cnt2=torch.empty(nq, dtype=torch.int64, device=dev), keys2=torch.empty((nq, K2), dtype=torch.int64, device=dev),

@@ -210,9 +210,29 @@ def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale, d):
     assert torch.equal(idx3, e3_idx) and torch.equal(val3, e3_val)
 
 
+def test_dense_cache_is_keyed_on_tensor_identity_not_on_addresses():
+    """A new query tensor that reuses a freed tensor's address (same shape, version 0) must not hit the cached thresholds /
+    packed queries of the old one."""
+    from swat_amd.retrieval import dense
+    dev = _dev()
+    rs = np.random.RandomState(2)
+    db = torch.from_numpy(synth.unit_rows(rs, 30000, 256)).to(dev)
+    outs = []
+    for i in range(3):
+        q = torch.from_numpy(synth.unit_rows(np.random.RandomState(10 + i), 24, 256)).to(dev)
+        ptr = q.data_ptr()
+        idx, val, _ = dense.topk_dense(db, q, 40)
+        e_idx, e_val, _ = dense.topk_dense_exact(db, q, 40)
+        assert torch.equal(idx, e_idx) and torch.equal(val, e_val), i
+        outs.append(ptr)
+        del q, idx, val, e_idx, e_val
+    # (the caching allocator normally hands the same block back: that is the case the test is about, but not required)
+
+
 def test_packed_query_image_layout():
     """swat_dense_pack_queries: per (32-deep chunk, 16-query tile) a 1 KiB block whose 16-B unit L holds query 16T + L/4,
-    k = 32c + 8 ((L % 4) ^ ((L / 16) % 4)) .. +7, rounded to bf16 (RNE); rows >= n_q and the 13 slack tiles are zero."""
+    k-slot s = (L % 4) ^ ((L / 16) % 4) = k 32c + 4s .. +3 and 32c + 16 + 4s .. +3 (the order in which the scan reads a
+    database row), rounded to bf16 (RNE); rows >= n_q and the 13 slack tiles are zero."""
     from swat_amd import _lib
     dev = _dev()
     nq, d = 37, 256
@@ -229,7 +249,9 @@ def test_packed_query_image_layout():
     slot = (L % 4) ^ ((L // 16) % 4)
     for c in range(d // 32):
         for T in (0, 1, 2, 3, tiles - 1):
-            want = torch.stack([qb[16 * T + int(L[i]) // 4, 32 * c + 8 * int(slot[i]):32 * c + 8 * int(slot[i]) + 8] for i in range(64)])
+            want = torch.stack([torch.cat([qb[16 * T + int(L[i]) // 4, 32 * c + 4 * int(slot[i]):32 * c + 4 * int(slot[i]) + 4],
+                                           qb[16 * T + int(L[i]) // 4, 32 * c + 16 + 4 * int(slot[i]):32 * c + 20 + 4 * int(slot[i])]])
+                                for i in range(64)])
             assert torch.equal(got[c, T], want), (c, T)
 
 

@@ -671,7 +671,35 @@ def golden_stages():
     print("wrote tests/golden/stages_tiny.npz")
 
 
-SECTIONS.update({"host": golden_host, "loop": golden_loop, "vit": golden_vit, "text": golden_text, "stages": golden_stages})
+def prompt_metrics():
+    """Synthetic <dataset>_metrics-LAION400M.json content: keys out of numeric order, synonyms with counts, Semi-Aves fields."""
+    names = [("7", "marsh wren", "Cistothorus palustris"), ("0", "barn owl", "Tyto alba"), ("12", "cedar waxwing", "Bombycilla cedrorum"),
+             ("3", "dark-eyed junco", "Junco hyemalis")]
+    return {k: {"name": n, "most_common_name": n.title(), "alternates": {n: 10, n + " bird": 3, s: 1}, "class_id": int(k), "species": s,
+                "common_name": n, "most_freq_synonym": n + " bird"} for k, n, s in names}
+
+
+def golden_prompts():
+    """prompt_maker / prompt_maker_aves (utils/prompt.py:83-148) on synthetic metrics for every dataset whose template list the
+    build carries — the expected prompts double as the check of those lists."""
+    from oracle import ref_shims
+    ref_shims.install()
+    import utils.prompt as rp
+    m = prompt_metrics()
+    out = {"prompt_maker": {}, "prompt_maker_aves": {}}
+    for ds in ("flowers102", "food101", "oxford_pets", "fgvc-aircraft", "eurosat", "sun397", "dtd", "dtd_selected", "stanford_cars", "semi-aves"):
+        for nt in ("name", "most_common_name", "alternates"):
+            out["prompt_maker"][f"{ds}|{nt}"] = rp.prompt_maker(m, ds, nt)
+    import contextlib, io
+    for nt in ("s-name", "c-name", "t-name", "f-name"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            out["prompt_maker_aves"][nt] = rp.prompt_maker_aves(m, "semi-aves", nt)
+    with open(os.path.join(GOLD, "prompts.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote tests/golden/prompts.json")
+
+
+SECTIONS.update({"prompts": golden_prompts, "host": golden_host, "loop": golden_loop, "vit": golden_vit, "text": golden_text, "stages": golden_stages})
 
 
 if __name__ == "__main__":

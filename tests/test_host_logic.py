@@ -149,3 +149,25 @@ def test_ensemble_model_matches_the_reference_golden(golden_dir):
         assert np.allclose(dig, g[f"wsft_{alpha}_digest"], rtol=1e-6, atol=1e-7)
         with torch.no_grad():
             assert np.allclose(w.encode_image(x).numpy(), g[f"wsft_{alpha}_embeds"], atol=1e-5)
+
+
+def test_prompt_makers_match_reference_golden(golden_dir):
+    """prompt_maker / prompt_maker_aves (ref utils/prompt.py:83-148): same keys, order and prompt strings as the imported
+    reference for every dataset whose template list is built in (tests/golden/prompts.json, oracle/make_golden.py prompts)."""
+    import json
+    import os
+    import pytest
+    from oracle.make_golden import prompt_metrics
+    from swat_amd import prompt
+    g = json.load(open(os.path.join(golden_dir, "prompts.json")))
+    m = prompt_metrics()
+    for key, want in g["prompt_maker"].items():
+        ds, nt = key.split("|")
+        got = prompt.prompt_maker(m, ds, nt)
+        assert list(got.keys()) == list(want.keys()) and got == want, key
+    for nt, want in g["prompt_maker_aves"].items():
+        got = prompt.prompt_maker_aves(m, "semi-aves", nt)
+        assert list(got.keys()) == list(want.keys()) and got == want, nt
+    with pytest.raises(KeyError):
+        prompt.prompt_maker(m, "imagenet", "name")  # the 80-template list comes from SWAT_TEMPLATES_JSON
+    assert prompt.prompt_maker(m, "some-new-dataset", "name")["0"]["corpus"] == ["a photo of a barn owl."]

@@ -3,6 +3,7 @@
 //
 // ref: open_clip VisionTransformer pieces called through model.encode_image (utils/training.py:332,1474),
 // CutMix paste utils/training.py:1458-1472, AdamW + LR groups utils/optimizers.py:22-35,131-146.
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/swat_hip.h"
 
@@ -200,8 +201,18 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
     const int t = threadIdx.x & 31, j = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + t;
     float a = 0.f;
-    if (c < d)
-        for (int i = j; i < nblk; i += 32) a += part[((int64_t)i * 3 + q) * d + c];
+    if (c < d) {
+        // 8 loads in flight per thread (the sum keeps its order: i = j, j + 32, ...): a bare loop pays one memory latency per term
+        int i = j;
+        for (; i + 7 * 32 < nblk; i += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[((int64_t)(i + 32 * u) * 3 + q) * d + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; i < nblk; i += 32) a += part[((int64_t)i * 3 + q) * d + c];
+    }
     sh[j][t] = a;
     __syncthreads();
     if (j == 0 && c < d) {

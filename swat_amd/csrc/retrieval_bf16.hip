@@ -35,7 +35,8 @@
 // 0.76-0.79 ms (memset + scan + regroup 0.57-0.62, approximate top-K2 0.04, exact re-score 0.08, exact top-k 0.02, proof +
 // flag 0.03) against 3.6 ms for the f32-matrix-core scan.  Timing ablations of the 4-wave shape (SWAT_DENSE_ABL, tuning only):
 // no query DMA 0.52 ms, no MFMA / LDS reads 0.59, no barrier 0.83 of 0.94; row-major query pieces (16 half-used lines per
-// instruction instead of 8 full ones) cost 0.31 ms.  Tried and dropped: two fragments per wave (2 workgroups per CU:
+// instruction instead of 8 full ones) cost 0.31 ms; the 12-wave kernel without any candidate (ablation 16) runs 480 us against
+// 565 us with them — neither an LDS queue in front of the staging stores nor thresholds in registers moved that.  Tried and dropped: two fragments per wave (2 workgroups per CU:
 // 1.00 ms), a fifth wave touching the database 8 / 16 steps ahead (1.27 ms), eight steps of rows in flight (spills).
 #include <stdlib.h>
 #include <utility>
@@ -439,7 +440,8 @@ __global__ __launch_bounds__(256) void regroup_candidates_kernel(const uint4* __
     __syncthreads();
     for (int sl = 0; sl < 16; ++sl) {
         const uint4* src = stage + (size_t)(s0 + sl) * stage_cap;
-        for (unsigned i = tid; i < slot_n[sl]; i += 256) atomicAdd(&hist[src[i].z], 1u);
+        for (unsigned i = tid; i < slot_n[sl]; i += 256)
+            if (src[i].z < (unsigned)n_q) atomicAdd(&hist[src[i].z], 1u);  // (a record's query is always < n_q; never index LDS on trust)
     }
     __syncthreads();
     for (int q = tid; q < n_q; q += 256)
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(256) void regroup_candidates_kernel(const uint4* __
         const uint4* src = stage + (size_t)(s0 + sl) * stage_cap;
         for (unsigned i = tid; i < slot_n[sl]; i += 256) {
             const uint4 rec = src[i];
+            if (rec.z >= (unsigned)n_q) continue;
             const unsigned pos = base[rec.z] + atomicAdd(&fill[rec.z], 1u);
             if (pos < (unsigned)cap) cand[rec.z * (size_t)cap + pos] = ((unsigned long long)rec.y << 32) | rec.x;
         }

@@ -212,3 +212,74 @@ def test_cli_under_torchrun_two_ranks_equals_the_single_process_run(tmp_path):
                 worst, worst_key = err, k
     assert worst < 2e-3, (worst_key, worst)
     assert set(ck1.keys()) == set(ck2.keys())
+
+
+def _retrieval_worker(rank, world, port, q, path):
+    """ShardedIndex.sample and the sharded dense top-k on rank's row range; every rank must hold the global lists."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, ROOT)
+        from swat_amd.retrieval import dense, shard
+        dev = torch.device("cuda:0")
+        inp = torch.load(os.path.join(path, "inputs.pt"))
+        ix = shard.ShardedIndex(os.path.join(path, "ix"), device=dev)
+        idx, val, cnt = ix.sample(inp["q_seg"].to(dev), inp["k"], rank_by="t2t", use_t2i_thr=True, thr=0.0, t2i_thr=0.25)
+        db = inp["db"]
+        lo, hi = shard.shard_bounds(db.shape[0], world, rank)
+        d_idx, d_val, _ = dense.topk_dense(db[lo:hi].contiguous().to(dev), inp["q_dense"].to(dev), inp["k"], row_base=lo)
+        g_idx, g_val, g_cnt = shard.gather_and_merge(d_idx, d_val, inp["k"])
+        torch.save({"idx": idx.cpu(), "val": val.cpu(), "cnt": cnt.cpu(), "d_idx": g_idx.cpu(), "d_val": g_val.cpu(),
+                    "route": dense.last_path}, os.path.join(path, f"out{rank}.pt"))
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_sharded_index_and_sharded_dense_topk_two_ranks(tmp_path):
+    """SURVEY 8(e), retrieval: two processes, each with its row range of a saved index (ShardedIndex) and of a dense
+    database (topk_dense with row_base), one all_gather of the [n_query, k] lists + merge — every rank ends with the
+    single-GPU answer, rows and values, ties included."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import synth
+    from swat_amd.retrieval import dense
+    from swat_amd.retrieval.index import SegmentedIndex
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(5)
+    n, d, ncls, k = 24000, 512, 11, 200
+    cap, img = synth.unit_rows(rs, n, d), synth.unit_rows(rs, n, d)
+    for _ in range(800):
+        a, b = rs.randint(n), rs.randint(n)
+        cap[a] = cap[b]
+    labels = torch.from_numpy(rs.randint(0, ncls, size=n))
+    full = SegmentedIndex(torch.from_numpy(img), torch.from_numpy(cap), labels, filepath=[str(i) for i in range(n)], device=dev)
+    full.save(str(tmp_path / "ix"))
+    q_seg = torch.from_numpy(synth.unit_rows(rs, full.n_seg, d))
+    q_dense = torch.from_numpy(synth.unit_rows(rs, 37, d))
+    db = torch.from_numpy(cap)
+    torch.save({"q_seg": q_seg, "q_dense": q_dense, "db": db, "k": k}, str(tmp_path / "inputs.pt"))
+    w_idx, w_val, w_cnt, _, _ = full.sample(q_seg.to(dev), k, rank_by="t2t", use_t2i_thr=True, thr=0.0, t2i_thr=0.25)
+    e_idx, e_val, _ = dense.topk_dense_exact(db.to(dev), q_dense.to(dev), k)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_retrieval_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for _ in range(2):
+        rank, msg = q.get(timeout=600)
+        assert msg == "ok", msg
+    for p in procs:
+        p.join(60)
+    for rank in range(2):
+        out = torch.load(str(tmp_path / f"out{rank}.pt"))
+        assert torch.equal(out["cnt"], w_cnt.cpu()) and torch.equal(out["idx"], w_idx.cpu())
+        valid = w_idx.cpu() >= 0
+        assert torch.equal(out["val"][valid], w_val.cpu()[valid])
+        assert out["route"] == "bf16-candidates+exact-rescore"
+        assert torch.equal(out["d_idx"], e_idx.cpu()) and torch.equal(out["d_val"], e_val.cpu())

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of swat_amd on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: one rank per GPU under torch.distributed.run; started without a
+                                                          launcher, bench.py starts the N ranks itself as a child process)
 
 Workload (BASELINE.json configs[1]): ViT-B/32 (open_clip ViT-B-32-quickgelu, random init) finetuning,
 B = 32 images / GPU, 200 classes, synthetic N(0,1) 224x224 images resident in HBM, one "step" = CutMix + encode_image +
@@ -510,6 +511,27 @@ def preprocess_secondary(dev, bsz=32, h=375, w=500, steps=50):
                          "achieved": round(nbytes / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / dt / 8e12, 4), "traffic": None}}
 
 
+def self_launch(n, argv):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <argv>` as a child process (one rank
+    per GPU, rendezvous on 127.0.0.1 at a free port), pass rank 0's single JSON line through and return the child's
+    exit status.  Called before anything in this process has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, got {len(lines)}\n")
+        return 1
+    for ln in lines:
+        print(ln, flush=True)
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,9 +550,16 @@ def main():
               flush=True)
         return
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU yet, so it starts the N ranks
+        # as a fresh child (never an exec) and relays rank 0's JSON line and the child's return code.
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: swat_amd has no CPU fallback")
     # test hooks (tests/test_gpu_ddp.py): two ranks on the single GPU of a test box over gloo — RCCL refuses that
@@ -544,7 +573,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    comm_ranks = dist.get_world_size() if world > 1 else 1
+    if comm_ranks != a.gpus:
+        raise SystemExit(f"bench.py: the process group has {comm_ranks} ranks, --gpus says {a.gpus}")
 
     args, model, head, step, sched = build_job(dev, world, a.bsz, trail=a.overlap == 2)
     from swat_amd import _lib
@@ -579,6 +610,7 @@ def main():
         ms = dt / a.steps * 1e3
         out = {"metric": "finetune img/s (ViT-B/32 bsz=32)", "value": round(world * a.bsz * a.steps / dt, 1), "unit": "img/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+               "rccl_ranks": comm_ranks if backend == "nccl" else None, "backend": backend if world > 1 else None,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "ViT-B/32 (open_clip ViT-B-32-quickgelu, random init) --method cutmix finetune step, "
                                       "200 classes, AdamW 3 LR groups, fp32 master + bf16 MFMA", "per_gpu_batch": a.bsz,

@@ -96,6 +96,13 @@ int swat_sim_candidates_packed(const void* packed, int n_q, const float* db, int
 /*     sort each query's candidates, emit the (value desc, row asc) top-k (cap <= 8192). */
 int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k,
                          int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);
+/*     SURVEY 8(e) retrieval row: k-way merge of the per-shard top-k lists after the all_gather (the sharded form of the
+ *     reference's single sorted() per class, retrieval/sample_retrieval.py:754,807).  idx / val [n_q, m]: the shards' lists
+ *     side by side in rank order (global rows, -1 padded), m <= 8192; output = the k best by (value desc, global row asc).
+ *     workspace: swat_merge_topk_workspace_bytes(n_q, m) bytes. */
+int64_t swat_merge_topk_workspace_bytes(int n_q, int m);
+int swat_merge_topk_lists(const int64_t* idx, const float* val, int n_q, int m, int k, void* workspace,
+                          int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);
 /* B6  remove_near_duplicates2 (ref :237-275): marks[j] = 1 iff <f_i, f_j> > thr for some i < j (S = F F^T on the
  *     fp32 matrix cores, exact canonical order). */
 int swat_near_dup_marks(const float* feats, int64_t n, int d, float thr, uint8_t* marks,
@@ -228,6 +235,13 @@ int swat_sgemm_small(const float* A, const float* B, float* C, int M, int N, int
 int swat_ce_mixed(const float* z, const float* logit_scale_dev, const int64_t* ya, const int64_t* yb,
                   float lam, float* per_sample_ws, float* loss, float* dlogit_scale, float* dz,
                   float* logits_out, double* loss_accum, int B, int C, swat_stream_t stream);
+
+/* A9 / f.4  validate's per-batch tail on the device (ref testing.py:449-458 argmax + torchmetrics ConfusionMatrix.update,
+ *     :417): pred[b] = first index of the maximum of row b of z [B, C]; confusion[label, pred] += 1 ([C, C] int64, rows =
+ *     true class, accumulated across calls — the caller zeroes it once per validate); *correct += (pred == label).
+ *     pred_out / max_out / confusion / correct may each be null. */
+int swat_argmax_confusion(const float* z, const int64_t* labels, int B, int C, int64_t* pred_out, float* max_out,
+                          int64_t* confusion, int64_t* correct, swat_stream_t stream);
 
 /* A2d  nn.MultiheadAttention core for short sequences (T <= 64, head width 64: ViT-B/32 at 224 px has T = 50): one
  *     workgroup per (image, head) does QK^T, softmax, PV on the matrix cores; the backward recomputes P from Q and K.

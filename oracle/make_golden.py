@@ -367,6 +367,55 @@ def golden_loop():
     print("wrote tests/golden/loop_tiny.npz")
 
 
+def probing_inputs(seed=41, C=7, E=64, B=8):
+    """Pre-extracted (unit-norm) features of a 7-class toy problem: 4 train / 2 val / 2 test batches of 8."""
+    rs = np.random.RandomState(seed)
+    centres = synth.unit_rows(rs, C, E)
+
+    def split(nb):
+        out = []
+        for _ in range(nb):
+            y = rs.randint(0, C, size=B)
+            x = 0.55 * centres[y] + synth.unit_rows(rs, B, E)
+            x /= np.linalg.norm(x, axis=1, keepdims=True)
+            out.append((torch.from_numpy(x.astype(np.float32)), torch.from_numpy(y.astype(np.int64)), None, torch.ones(B, dtype=torch.long)))
+        return out
+    tr, va, te = split(4), split(2), split(2)
+    W0 = 0.35 * centres + synth.unit_rows(rs, C, E)   # a head that is partly right: accuracy moves while probing
+    W0 /= np.linalg.norm(W0, axis=1, keepdims=True)
+    return tr, va, te, torch.from_numpy(W0.astype(np.float32))
+
+
+def golden_probing():
+    """A8 / f.4: the reference's own train_probing (utils/training.py:47-161) on pre-extracted features — the loop that
+    run_stage2_probing (main.py:402-474) drives after re-extracting the few-shot features: head-only AdamW with the
+    warm-up + cosine LR trace, logit_scale fixed at ln(100), validate + calculate_scores every epoch."""
+    from oracle import ref_shims, vit_oracle as vo
+    ref_shims.install()
+    import utils.training as rt
+    import utils.optimizers as ro
+    import utils.models as rm
+    train, val, test, W0 = probing_inputs()
+    torch.manual_seed(0)
+    model = vo.OracleCLIP(vision_cfg=TINY, text_width=64, text_heads=1, text_layers=1, ctx=8, vocab=64)
+    head = rm.MyLinear(weights=W0.clone())
+    args = _ref_args(method="probing", epochs=3, pre_extracted=True, lr_classifier=1e-2, early_stop=False)
+    args.loss = torch.nn.CrossEntropyLoss()
+    params, logit_scale = ro.set_params(args, model, head, _logger())
+    opt, sched, _ = ro.set_optimizer(args, params, train)
+    args.optimizer, args.scheduler = opt, sched
+    rt.time = types.SimpleNamespace(sleep=lambda s: None, time=__import__("time").time)
+    csv = io.StringIO()
+    best_model, best_head, rec, best_ls, _, _ = rt.train_probing(args, _logger(), csv, model, head, None, None, train, val, test, False)
+    print(f"[probing] loss.csv:\n{csv.getvalue()}")
+    np.savez_compressed(os.path.join(GOLD, "probing_tiny.npz"), csv=csv.getvalue(), head=head.linear.weight.detach().numpy(),
+                        best_head=best_head.linear.weight.detach().numpy(), logit_scale=np.float32(logit_scale.item()),
+                        best=json.dumps([float(rec["best_val_acc"]), int(rec["best_epoch"]), int(rec["best_iter"])]),
+                        cm=np.asarray(rec["best_confusion_matrix"]),
+                        avg_class_acc=np.float64(rec["best_scores"]["avg_class_accuracy"]))
+    print("wrote tests/golden/probing_tiny.npz")
+
+
 def hf_to_oracle_state(hf):
     """HF CLIPVisionModelWithProjection -> open_clip VisionTransformer key names (SURVEY App. A mapping)."""
     sd = hf.state_dict()
@@ -699,6 +748,59 @@ def golden_prompts():
     print("wrote tests/golden/prompts.json")
 
 
+PROMPT_TEXT_CFG = (16, 128, 64, 2, 2)  # ctx, vocab, width, heads, layers of the toy text tower of the B8 golden
+
+
+def prompt_tensor_model(seed=21):
+    from oracle import vit_oracle as vo
+    torch.manual_seed(seed)
+    ctx, vocab, tw, th, tl = PROMPT_TEXT_CFG
+    return vo.OracleCLIP(vision_cfg=TINY, text_width=tw, text_heads=th, text_layers=tl, ctx=ctx, vocab=vocab)
+
+
+def golden_prompt_tensors():
+    """B8 compute branch: the reference's own get_text_features (utils/features.py:39-64: encode every template x synonym,
+    L2-normalise each, mean, L2-normalise again -> {'all', 'mean'}) and the un-cached branch of cal_prompt_tensors
+    (retrieval/sample_retrieval.py:1418-1454: prompt_maker -> get_text_features -> torch.save of both tables) with the fp32
+    oracle text tower as `model` and oracle/synth.hash_tokenize as the tokenizer."""
+    from oracle import ref_shims
+    sr = ref_shims.import_retrieval()
+    import utils.features as rf
+    import utils.prompt as rp
+    model = prompt_tensor_model()
+    tok = synth.hash_tokenize(PROMPT_TEXT_CFG[0], PROMPT_TEXT_CFG[1])
+    metrics = prompt_metrics()
+    recs = {}
+    for ds, nt in (("semi-aves", "alternates"), ("dtd", "name")):
+        prompts = rp.prompt_maker(metrics, ds, nt)
+        td = rf.get_text_features(model, prompts, tok, "encode")
+        keys = list(td.keys())
+        recs[f"{ds}|{nt}|keys"] = json.dumps(keys)
+        recs[f"{ds}|{nt}|counts"] = np.array([td[k]["all"].shape[0] for k in keys], np.int64)
+        recs[f"{ds}|{nt}|all"] = torch.cat([td[k]["all"] for k in keys]).numpy()
+        recs[f"{ds}|{nt}|mean"] = torch.stack([td[k]["mean"] for k in keys]).numpy()
+        print(f"[prompt_tensors/{ds}|{nt}] {len(keys)} classes, {recs[f'{ds}|{nt}|all'].shape[0]} prompts")
+    # cal_prompt_tensors, un-cached: runs from a scratch `retrieval/` so that its '../data/<dataset>/prompts/' lands in a temp tree
+    tmp = tempfile.mkdtemp()
+    os.makedirs(f"{tmp}/retrieval")
+    cwd = os.getcwd()
+    os.chdir(f"{tmp}/retrieval")
+    try:
+        args = types.SimpleNamespace(dataset="semi-aves", model_cfg="vitb32_openclip_laion400m", prompt_name="alternates", recal_prompt=False)
+        ptd, tpd = sr.cal_prompt_tensors(args, _logger(), model, tok, metrics, "/unused")
+        files = sorted(os.listdir(f"{tmp}/data/semi-aves/prompts"))
+    finally:
+        os.chdir(cwd)
+    keys = list(ptd["alternates"].keys())
+    recs["cal|keys"] = json.dumps(keys)
+    recs["cal|mean"] = torch.stack([ptd["alternates"][k]["mean"] for k in keys]).numpy()
+    recs["cal|files"] = json.dumps(files)
+    recs["cal|corpus0"] = json.dumps(tpd["alternates"][keys[0]]["corpus"])
+    np.savez_compressed(os.path.join(GOLD, "prompt_tensors.npz"), **recs)
+    print("wrote tests/golden/prompt_tensors.npz", files)
+
+
+SECTIONS.update({"probing": golden_probing, "prompt_tensors": golden_prompt_tensors})
 SECTIONS.update({"prompts": golden_prompts, "host": golden_host, "loop": golden_loop, "vit": golden_vit, "text": golden_text, "stages": golden_stages})
 
 

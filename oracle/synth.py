@@ -72,3 +72,24 @@ def retrieval_case(kind, seed, d, k, class_ids, sizes, n_dups):
 def unit_rows(rs, n, d):
     x = rs.randn(n, d).astype(np.float32)
     return x / np.linalg.norm(x, axis=-1, keepdims=True).astype(np.float32)
+
+
+def hash_tokenize(ctx=16, vocab=128):
+    """A deterministic stand-in for open_clip's BPE tokenizer (test infrastructure: the B8 golden needs SOME tokenizer both
+    the imported reference and the GPU test can call): lower-cased whitespace words -> 1 + crc32(word) % (vocab - 3),
+    <start> = vocab - 2 in front, <end> = vocab - 1 behind (the largest id, so argmax finds it like CLIP's EOT), zero padded,
+    truncated to ctx like open_clip's tokenizer."""
+    import zlib
+
+    import torch
+
+    def tok(texts):
+        if isinstance(texts, str):
+            texts = [texts]
+        out = torch.zeros(len(texts), ctx, dtype=torch.long)
+        for i, t in enumerate(texts):
+            ids = [vocab - 2] + [1 + zlib.crc32(w.encode()) % (vocab - 3) for w in t.lower().split()]
+            ids = ids[:ctx - 1] + [vocab - 1]
+            out[i, :len(ids)] = torch.tensor(ids)
+        return out
+    return tok

@@ -237,23 +237,64 @@ __global__ __launch_bounds__(1024) void candidates_topk_kernel(const unsigned lo
     }
     __syncthreads();
     const int kk = (int)n < k ? (int)n : k;
+    int valid = 0;  // key 0 = an empty slot (merged shard lists carry -1 padded rows): sorts last, emitted as (-1, -inf)
     for (int r = tid; r < k; r += 1024) {
         int64_t idx = -1;
         float val = -INFINITY;
-        if (r < kk) {
+        if (r < kk && keys[r] != 0ull) {
             const unsigned long long key = keys[r];
             idx = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
             const uint32_t o = (uint32_t)(key >> 32);
             val = __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+            ++valid;
         }
         out_idx[(int64_t)q * k + r] = idx;
         out_val[(int64_t)q * k + r] = val;
     }
-    if (tid == 0) out_cnt[q] = kk;
+    __shared__ int n_valid;
+    if (tid == 0) n_valid = 0;
+    __syncthreads();
+    if (valid) atomicAdd(&n_valid, valid);
+    __syncthreads();
+    if (tid == 0) out_cnt[q] = n_valid;
+}
+
+// (value, global row) lists -> the sort keys candidates_topk_kernel orders: ordered(value) << 32 | ~row; row < 0 -> 0 (sorts
+// last).  -0.0 and 0.0 are one key, as in segment_topk_kernel.
+__global__ void pack_list_keys_kernel(const float* __restrict__ val, const int64_t* __restrict__ idx, int64_t n,
+                                      unsigned long long* __restrict__ keys, unsigned* __restrict__ cnt, int n_q, int m) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_q) cnt[i] = (unsigned)m;
+    if (i >= n) return;
+    const int64_t r = idx[i];
+    float v = val[i];
+    if (v == 0.0f) v = 0.0f;
+    const uint32_t b = __float_as_uint(v);
+    const uint32_t o = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    keys[i] = r < 0 ? 0ull : (((unsigned long long)o << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)r));
 }
 
 }  // namespace swat
 using namespace swat;
+
+// k-way merge of per-shard top-k lists (SURVEY 8(e) retrieval row: the rank-0 / every-rank merge after the all_gather):
+// idx / val [n_q, m] = the shards' lists side by side (global rows, -1 padded), m <= 8192.  Output: the k best by
+// (value desc, global row asc).  workspace: swat_merge_topk_workspace_bytes(n_q, m).
+SWAT_API int64_t swat_merge_topk_workspace_bytes(int n_q, int m) {
+    return (int64_t)n_q * m * 8 + (int64_t)n_q * 4 + 256;
+}
+
+SWAT_API int swat_merge_topk_lists(const int64_t* idx, const float* val, int n_q, int m, int k, void* workspace,
+                                   int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t s) {
+    SWAT_REQUIRE(idx && val && workspace && out_idx && out_val && out_cnt, "swat_merge_topk_lists: null pointer");
+    SWAT_REQUIRE(n_q >= 1 && m >= 1 && m <= CAND_MAX && k >= 1 && k <= m, "swat_merge_topk_lists: need 1 <= k <= m <= %d", CAND_MAX);
+    unsigned long long* keys = (unsigned long long*)workspace;
+    unsigned* cnt = (unsigned*)((char*)workspace + ((int64_t)n_q * m * 8 + 255) / 256 * 256);
+    const int64_t n = (int64_t)n_q * m;
+    hipLaunchKernelGGL(pack_list_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, val, idx, n, keys, cnt, n_q, m);
+    hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, keys, m, cnt, k, out_idx, out_val, out_cnt);
+    return check_launch("swat_merge_topk_lists");
+}
 
 SWAT_API int swat_sim_topk_candidates(const float* queries, int n_q, const float* db, int64_t n_db, int d,
                                       const float* thr_dev, int64_t row_base, void* cand_keys, int cap, void* cand_cnt,

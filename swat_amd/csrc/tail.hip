@@ -126,6 +126,38 @@ __global__ void ce_finish_kernel(const float* __restrict__ per_loss, const float
     }
 }
 
+// validate's host tail on the device (ref testing.py:449-458: torch.max / argmax per row, torchmetrics ConfusionMatrix.update):
+// one wave per row of z [B, C]; pred = FIRST index of the row maximum (torch.argmax's tie rule on a contiguous row), then
+// confusion[label, pred] += 1 (rows = true class, integer atomics: exact in any order) and correct += (pred == label).
+__global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __restrict__ z, const int64_t* __restrict__ labels,
+                                                               int B, int C, int64_t* __restrict__ pred_out,
+                                                               float* __restrict__ max_out, unsigned long long* __restrict__ confusion,
+                                                               unsigned long long* __restrict__ correct) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* zr = z + (int64_t)row * C;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = zr[c];
+        if (v > best || (v == best && c < arg) || arg == 0x7fffffff) { best = v; arg = c; }  // NaN rows: first index, like a plain scan
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oa = __shfl_xor(arg, o, 64);
+        if (ov > best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+    }
+    if (lane == 0) {
+        if (arg == 0x7fffffff) arg = 0;
+        const int64_t y = labels[row];
+        if (pred_out) pred_out[row] = arg;
+        if (max_out) max_out[row] = best;
+        if (confusion && y >= 0 && y < C) atomicAdd(&confusion[y * C + arg], 1ull);
+        if (correct && y == arg) atomicAdd(correct, 1ull);
+    }
+}
+
 }  // namespace swat
 using namespace swat;
 
@@ -245,4 +277,13 @@ SWAT_API int swat_ce_mixed(const float* z, const float* logit_scale_dev, const i
     hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const float*)per_sample_ws,
                        (const float*)(per_sample_ws + B), B, loss, dlogit_scale, loss_accum);
     return check_launch("swat_ce_mixed");
+}
+
+SWAT_API int swat_argmax_confusion(const float* z, const int64_t* labels, int B, int C, int64_t* pred_out, float* max_out,
+                                   int64_t* confusion, int64_t* correct, swat_stream_t s) {
+    SWAT_REQUIRE(z && labels && B >= 0 && C >= 1, "swat_argmax_confusion: null pointer or bad shape");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(argmax_confusion_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, z, labels, B, C, pred_out, max_out,
+                       (unsigned long long*)confusion, (unsigned long long*)correct);
+    return check_launch("swat_argmax_confusion");
 }

@@ -53,10 +53,12 @@ class MinedDataset(Dataset):
     caption_map: {str(label): {image id: caption}} (the pickled `*_metadata-*.map`, retrieval/extract_mined_feature.py:252-262).
     rank / world: this process encodes files rank, rank + world, ... of the list (world 1 = all)."""
 
-    def __init__(self, transform=None, dataset_root=".", caption_map=None, rank=0, world=1, loader=_pil_loader):
+    def __init__(self, transform=None, dataset_root=".", caption_map=None, rank=0, world=1, loader=_pil_loader, fnames=None):
         import pathlib
         self.dataset_root = pathlib.Path(dataset_root)
-        self.fnames = list(self.dataset_root.glob("**/*.jpg"))  # directory order, like the reference (not sorted)
+        # directory order, like the reference (not sorted).  `fnames`: the list every rank must stride over — rank 0's,
+        # broadcast by the caller, because directory order is not guaranteed to agree between processes / mounts
+        self.fnames = [pathlib.Path(f) for f in fnames] if fnames is not None else list(self.dataset_root.glob("**/*.jpg"))
         if len(self.fnames) == 0:
             raise ValueError('Check image suffix. No images found in the specified dataset_root: {}'.format(dataset_root))
         self.num_classes = len(set(f.parent.name for f in self.fnames))

@@ -24,9 +24,10 @@ import torch.distributed as dist
 from torch.utils.data import Sampler
 
 
-def init_from_env(args):
+def init_from_env(args, split_batch=True):
     """Call FIRST in main(): creates the process group before anything touches the GPU (a launcher must not start other
-    programs from a process that has initialised the device, and RCCL wants its device bound at creation)."""
+    programs from a process that has initialised the device, and RCCL wants its device bound at creation).
+    split_batch=False: the caller does not split --bsz over the ranks (feature extraction), so any world size goes."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     args.rank, args.world, args.local_rank = 0, 1, 0
     if world <= 1:
@@ -43,7 +44,7 @@ def init_from_env(args):
     if ngpu:
         torch.cuda.set_device(index)
     args.rank, args.world, args.local_rank = rank, world, local
-    if not getattr(args, 'dp_weak', False) and getattr(args, 'bsz', world) % world:
+    if split_batch and not getattr(args, 'dp_weak', False) and getattr(args, 'bsz', world) % world:
         raise ValueError(f"--bsz {args.bsz} is split over {world} ranks: it must be a multiple of the world size "
                          "(or use --dp_weak for --bsz rows per rank)")
     return args

@@ -18,6 +18,7 @@ NUM_CLASSES_DICT = {'semi-aves': 200, 'flowers102': 102, 'fgvc-aircraft': 100, '
 
 def set_model(args, logger):
     model, preprocess, tokenizer = get_engine(model_cfg=args.model_cfg, device=args.device)
+    args.embed_dim = model.visual.output_dim  # width of the random / dataset-cls heads (set_classifier)
     logger.info(f'Loaded model: {args.model_cfg}')
     return model, preprocess, tokenizer
 
@@ -46,15 +47,20 @@ class MyLinear(nn.Module):
 
 
 def set_classifier(args, prompt_tensors, logger):
+    # The reference hard-codes inp_dim=512 for the random / dataset-cls heads (utils/models.py:26,36), which is the
+    # embedding width of its ViT-B towers only; here the width comes from the tower (512 for ViT-B/*, 768 for ViT-L/14:
+    # BASELINE config 5), so `--cls_init random` works for every --model_cfg.  Text-initialised heads take it from the
+    # prompt tensor in both.
+    inp_dim = getattr(args, 'embed_dim', 512)
     if args.method == "dataset-cls":
-        classifier_head = MyLinear(inp_dim=512, num_classes=2, bias=False)
+        classifier_head = MyLinear(inp_dim=inp_dim, num_classes=2, bias=False)
     elif args.cls_init in ('REAL-Prompt', 'REAL-Linear', 'text'):
         weights = features.prompt_sampler(prompt_tensors, sample_by='mean')
         classifier_head = MyLinear(weights=weights)
         logger.info(f'Initialized classifier head with text embedding. weights.shape: {weights.shape}')
     elif args.cls_init == 'random':
         num_class = NUM_CLASSES_DICT[args.dataset]
-        classifier_head = MyLinear(inp_dim=512, num_classes=num_class, bias=False)
+        classifier_head = MyLinear(inp_dim=inp_dim, num_classes=num_class, bias=False)
         logger.info(f'Initialized classifier head with random weights. Num of classes: {num_class}')
     else:
         raise NotImplementedError(f'Classifier head {args.cls_init} not implemented.')

@@ -79,6 +79,7 @@ def topk_dense_exact(db, queries, k, row_base=0, sample=16384):
 
 
 EPS_BF16 = 2.0 ** -8 + 2.0 ** -12  # two bf16 roundings per product ((1 + 2^-9)^2 - 1) + fp32 accumulation over <= 1024 terms
+EPS_MAX_D = 1024                    # largest d the bound above covers
 _cache = {}
 
 
@@ -141,7 +142,9 @@ def topk_dense(db, queries, k, row_base=0, sample=16384):
     nq = queries.shape[0]
     need = min(k, n)
     global last_path
-    if 2 * k > TOPK2_MAX or d % 64 != 0:
+    if 2 * k > TOPK2_MAX or d % 64 != 0 or d > EPS_MAX_D:
+        # d > 1024: the fp32-accumulation share of EPS_BF16 (2^-12) no longer bounds the candidate scores' error, so the
+        # device-side completeness proof would not be sound — the exact f32-matrix-core scan answers instead
         last_path = "exact"
         return topk_dense_exact(db, queries, k, row_base, sample)
     c = _prepared(db, queries, k, sample)

@@ -90,6 +90,32 @@ def merge_rank_dicts(parts):
     return out
 
 
+def gather_rank_parts(part, n_total, rank, world):
+    """Rank 0 <- every rank's strided share, merged into single-process row order.  The feature matrices travel as
+    tensors (dist.gather of equal-sized, zero-padded blocks: 2 x 2 KB per row), only the path lists as pickled objects."""
+    import torch.distributed as dist
+    n_max = (n_total + world - 1) // world
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    parts = [{} for _ in range(world)] if rank == 0 else None
+    for key in ('caption_features', 'image_features', 'labels'):
+        t = part[key]
+        blk = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        blk[:t.shape[0]] = t.to(dev)
+        out = [torch.empty_like(blk) for _ in range(world)] if rank == 0 else None
+        dist.gather(blk, out, dst=0)
+        if rank == 0:
+            for r in range(world):
+                parts[r][key] = out[r][:len(range(r, n_total, world))].cpu()
+    paths = [None] * world if rank == 0 else None
+    dist.gather_object(part['filepath'], paths, dst=0)
+    if rank != 0:
+        return None
+    for r in range(world):
+        parts[r]['filepath'] = paths[r]
+        assert len(paths[r]) == parts[r]['labels'].shape[0], "a rank encoded a different number of files than its share"
+    return merge_rank_dicts(parts)
+
+
 def pre_extract_mined_fea(args, dataset_name, dataset_root, caption_path, model_cfg, model, preprocess, tokenizer):
     """ref :252-280 — same arguments, same output file; returns the dict (rank 0) for callers that go on in-process."""
     from ..dataloader import MinedDataset
@@ -99,16 +125,22 @@ def pre_extract_mined_fea(args, dataset_name, dataset_root, caption_path, model_
         print('dataset_root:', dataset_root)
     with open(caption_path, 'rb') as f:
         caption_map = pickle.load(f)
-    dataset = MinedDataset(dataset_root=dataset_root, transform=preprocess, caption_map=caption_map, rank=rank, world=world)
+    fnames = None
+    if world > 1:
+        # every rank strides over RANK 0's file list: two processes (or two mounts) need not list a directory in the same order
+        import pathlib
+        import torch.distributed as dist
+        box = [[str(f) for f in pathlib.Path(dataset_root).glob("**/*.jpg")] if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        fnames = box[0]
+    dataset = MinedDataset(dataset_root=dataset_root, transform=preprocess, caption_map=caption_map, rank=rank, world=world,
+                           fnames=fnames)
     loader = DataLoader(dataset, batch_size=args.bsz, shuffle=False, num_workers=args.num_workers, drop_last=False, pin_memory=True)
     part = extract_mined_feats_batch(model, loader, tokenizer, save_dir=f'{args.root}/{dataset_name}/temp')
     if world > 1:
-        import torch.distributed as dist
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(part, parts, dst=0)
+        part = gather_rank_parts(part, dataset.n_total, rank, world)
         if rank != 0:
             return None
-        part = merge_rank_dicts(parts)
     save_root = f'{args.root}/{dataset_name}'
     os.makedirs(save_root, exist_ok=True)
     output_fn = f'{save_root}/{dataset_name}_{model_cfg}_mined.pth'
@@ -130,7 +162,7 @@ def main(argv=None):
     parser.add_argument('--dist_backend', type=str, default='nccl', choices=['nccl', 'gloo'])
     args = parser.parse_args(argv)
     from .. import dp
-    dp.init_from_env(args)  # before anything touches the GPU
+    dp.init_from_env(args, split_batch=False)  # before anything touches the GPU; --bsz is per rank here (nothing is split)
     if dp.is_main(args):
         for arg in vars(args):
             print(f'{arg}: {getattr(args, arg)}')

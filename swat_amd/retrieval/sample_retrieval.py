@@ -66,7 +66,15 @@ def zeroshot_clip_img_filter(model, preprocess, root_folder, pre_extracted_feats
     index = samplers._as_index(pre_extracted_feats)
     filtered_images_dict = defaultdict(set)
     W = head.linear.weight.detach().to(index.image_features.device, torch.float32)
-    preds = torch.argmax(index.image_features @ W.t(), dim=1).cpu()   # [N, C] logits once; rows are class-grouped
+    # logits[c, i] = <W[c], f_i> in the library's canonical order (one fp32 fma chain over k ascending on the f32 matrix
+    # cores, csrc/retrieval_mfma.hip — the same bits as the oracle's restatement), 32 768 rows at a time
+    from . import dense
+    W = W.contiguous()
+    feats = index.image_features
+    preds = torch.empty(feats.shape[0], dtype=torch.int64)
+    for lo in range(0, feats.shape[0], 32768):
+        S = dense.sim_matrix(W, feats[lo:lo + 32768].contiguous())   # [C, n]
+        preds[lo:lo + S.shape[1]] = torch.argmax(S, dim=0).cpu()
     off = index.offsets.tolist()
     paths, ids = index.paths_array(), index.file_ids()
     import numpy as np

@@ -21,11 +21,25 @@ def local_segments(offsets, lo, hi):
 
 
 def merge_topk(idx_list, val_list, k):
-    """idx/val per shard: [n_seg, k] (global rows, -1 padded / -inf).  Shards must be passed in rank order: rows of a
-    lower rank are lower global rows, so a STABLE descending sort of the concatenation reproduces
-    (value desc, global row asc) — the reference's stable sorted(reverse=True) order."""
-    idx = torch.cat(idx_list, dim=1)
-    val = torch.cat(val_list, dim=1)
+    """idx/val per shard: [n_seg, k] (global rows, -1 padded / -inf), shards in rank order -> the k best of every
+    query by (value desc, global row asc) — the reference's stable sorted(reverse=True) order, since rows of a lower
+    rank are lower global rows.  On the GPU: swat_merge_topk_lists (the library's own bitonic top-k over the packed
+    (value, ~row) keys).  CPU tensors (the gloo tests of the merge bookkeeping) use a stable descending sort — the same
+    order by construction; the data path never takes it (ShardedIndex / bench.py hold GPU tensors)."""
+    idx = torch.cat(idx_list, dim=1).contiguous()
+    val = torch.cat(val_list, dim=1).contiguous()
+    if idx.is_cuda:
+        from .. import _lib
+        L = _lib.lib()
+        nq, m = idx.shape
+        kk = min(k, m)
+        ws = torch.empty(L.swat_merge_topk_workspace_bytes(nq, m), dtype=torch.uint8, device=idx.device)
+        out_idx = torch.empty((nq, kk), dtype=torch.int64, device=idx.device)
+        out_val = torch.empty((nq, kk), dtype=torch.float32, device=idx.device)
+        cnt = torch.empty(nq, dtype=torch.int64, device=idx.device)
+        _lib.check(L.swat_merge_topk_lists(_lib.ptr(idx), _lib.ptr(val), nq, m, kk, _lib.ptr(ws), _lib.ptr(out_idx), _lib.ptr(out_val),
+                                           _lib.ptr(cnt), _lib.stream()), "swat_merge_topk_lists")
+        return out_idx, out_val, cnt
     val = torch.where(idx >= 0, val, torch.full_like(val, float("-inf")))
     order = torch.sort(val, dim=1, descending=True, stable=True).indices[:, :k]
     out_idx = torch.gather(idx, 1, order)

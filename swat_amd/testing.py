@@ -2,7 +2,8 @@
 
 ref: load_model :76-131, calculate_scores :134-186, validate :403-486.
 Forward-only HIP path: encode_image -> L2-normalise -> head -> scaled CE (swat_head_loss with want_grad = 0);
-argmax / accuracy / confusion matrix are host-side like the reference's (.cpu() + torchmetrics there).
+argmax, the accuracy count and the confusion matrix accumulate on the device (swat_argmax_confusion); the
+reference does them on the host per batch (.cpu() + torchmetrics, :449-458).
 """
 import numpy as np
 import torch
@@ -51,24 +52,40 @@ def calculate_scores(confusion_matrix):
     return scores
 
 
-def head_eval(feats, W, logit_scale, labels, normalize=True):
+_WS = {}  # (device, B, E, C) -> head_loss workspace: validate runs ~30 times per job on the same batch shapes
+
+
+def _head_ws(dev, B, E, C):
+    key = (str(dev), B, E, C)
+    ws = _WS.get(key)
+    if ws is None:
+        if len(_WS) > 16:
+            _WS.clear()
+        ws = _WS[key] = torch.empty(_lib.lib().swat_head_loss_workspace_bytes(B, E, C), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def head_eval(feats, W, logit_scale, labels, normalize=True, z=None, loss=None):
     """-> (z [B,C] un-scaled head output, loss device scalar = CE(z * exp(logit_scale), labels))."""
     B, E = feats.shape
     C = W.shape[0]
     dev = feats.device
     ls = logit_scale.detach().reshape(-1)[:1].to(dev, torch.float32).contiguous()
-    z = torch.empty((B, C), dtype=torch.float32, device=dev)
-    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    if z is None:
+        z = torch.empty((B, C), dtype=torch.float32, device=dev)
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
     Wd = W.detach().contiguous()
     if normalize:
-        ws = torch.empty(_lib.lib().swat_head_loss_workspace_bytes(B, E, C), dtype=torch.uint8, device=dev)
+        ws = _head_ws(dev, B, E, C)
         rc = _lib.lib().swat_head_loss(_lib.ptr(feats), _lib.ptr(Wd), _lib.ptr(ls), _lib.ptr(labels), _lib.ptr(labels), 1.0,
                                        _lib.ptr(ws), _lib.ptr(loss), None, None, None, _lib.ptr(z), None, None, B, E, C, 0, 1,
                                        _lib.stream())
         _lib.check(rc, "swat_head_loss")
     else:
         ops.sgemm_small(feats, Wd, B, C, E, E, 1, 1, E, out=z)
-        loss, _, _, _ = ops.ce_mixed(z, ls, labels, labels, 1.0, want_grad=False)
+        l2, _, _, _ = ops.ce_mixed(z, ls, labels, labels, 1.0, want_grad=False)
+        loss.copy_(l2.reshape(-1)[:1])
     return z, loss
 
 
@@ -81,34 +98,51 @@ def validate(args, data_loader, model, logger, loss, logit_scale, classifier_hea
         classifier_head.eval()
     else:
         raise NotImplementedError("validate without a classifier head (model(inputs, texts)) is out of scope")
-    val_acc = 0
+    # f.4: argmax, accuracy count and the confusion matrix accumulate ON THE DEVICE (swat_argmax_confusion; the
+    # reference moves every batch's logits to the host, testing.py:449-458); one host synchronisation per validate call.
     val_count = 0
     num_classes = classifier_head.num_classes
-    confusion = np.zeros((num_classes, num_classes), dtype=np.int64)
     W = classifier_head.linear.weight
-    predicted_labels, max_logits, val_loss_batch = [], [], []
+    dev = W.device
+    L = _lib.lib()
+    confusion_d = torch.zeros((num_classes, num_classes), dtype=torch.int64, device=dev)
+    correct_d = torch.zeros(1, dtype=torch.int64, device=dev)
+    n_batches = len(data_loader) if hasattr(data_loader, '__len__') else None
+    losses_d = torch.zeros(max(1, n_batches or 1), dtype=torch.float32, device=dev)
+    extra_losses, preds_d, maxl_d = [], [], []
     with torch.no_grad():
         for i, val_data in enumerate(data_loader):
             inputs, labels, texts, source = val_data
             inputs = inputs.to(device)
-            labels = labels.long().to(device)
+            labels = labels.long().to(device).contiguous()
+            B = labels.numel()
+            if n_batches is not None and i < n_batches:
+                loss_slot = losses_d[i:i + 1]
+            else:
+                loss_slot = torch.empty(1, dtype=torch.float32, device=dev)
+                extra_losses.append(loss_slot)
             if not pre_extracted:
                 feats = model.visual.forward_raw(inputs)
-                z, loss_batch = head_eval(feats, W, logit_scale, labels, normalize=True)
+                z, _ = head_eval(feats, W, logit_scale, labels, normalize=True, loss=loss_slot)
             else:
-                z, loss_batch = head_eval(inputs.float().contiguous(), W, logit_scale, labels, normalize=False)
-            val_loss_batch.append(loss_batch)
-            zc = z.cpu()
-            labels_c = labels.cpu()
-            max_logits.append(torch.max(zc, dim=1).values.numpy())
-            pred = torch.argmax(zc, dim=1)
-            predicted_labels.append(pred.numpy())
-            val_acc += torch.sum(pred == labels_c).item()
-            val_count += labels_c.size(0)
-            if show_confusion_matrix:
-                np.add.at(confusion, (labels_c.numpy(), pred.numpy()), 1)
-    val_acc = (val_acc / val_count) * 100
-    val_loss = np.mean([v.item() for v in val_loss_batch])
+                z, _ = head_eval(inputs.float().contiguous(), W, logit_scale, labels, normalize=False, loss=loss_slot)
+            pred = torch.empty(B, dtype=torch.int64, device=dev) if predict_labels else None
+            maxl = torch.empty(B, dtype=torch.float32, device=dev) if predict_labels else None
+            _lib.check(L.swat_argmax_confusion(_lib.ptr(z), _lib.ptr(labels), B, num_classes, _lib.ptr(pred), _lib.ptr(maxl),
+                                               _lib.ptr(confusion_d) if show_confusion_matrix else None, _lib.ptr(correct_d),
+                                               _lib.stream()), "swat_argmax_confusion")
+            if predict_labels:
+                preds_d.append(pred)
+                maxl_d.append(maxl)
+            val_count += B
+    n_seen = i + 1
+    all_losses = torch.cat([losses_d[:min(n_seen, losses_d.numel())] if n_batches is not None else losses_d[:0]] + extra_losses)
+    host = torch.cat([all_losses.double(), correct_d.double()]).cpu()   # the one synchronisation of the call
+    val_acc = (float(host[-1].item()) / val_count) * 100
+    val_loss = np.mean(host[:-1].tolist())   # fp32 batch means averaged in double, as np.mean of the reference's .item() list
+    confusion = confusion_d.cpu().numpy() if show_confusion_matrix else None
+    predicted_labels = [p.cpu().numpy() for p in preds_d]
+    max_logits = [m.cpu().numpy() for m in maxl_d]
     if predict_labels:
         predicted = np.concatenate(predicted_labels).tolist()
         maxl = np.concatenate(max_logits).tolist()

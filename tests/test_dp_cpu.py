@@ -79,6 +79,20 @@ def _worker(rank, world, port, q):
         assert dp.bcast_object(args, nxt) == nxt  # the sampler consumed the same amount of the stream on every rank
         # one scalar all-reduce per epoch for loss.csv
         assert abs(dp.mean_over_ranks(args, 1.0 + rank) - 1.5) < 1e-12
+        # SURVEY 8(e) row 3, mined-feature extraction: rank-strided shares of 7 files -> rank 0 holds the single-process dict
+        # (feature matrices gathered as padded tensors, paths as objects)
+        from swat_amd.retrieval.extract_mined_feature import gather_rank_parts
+        n = 7
+        feats = torch.arange(n * 4, dtype=torch.float32).view(n, 4)
+        mine = list(range(rank, n, world))
+        part = {"caption_features": feats[mine], "image_features": -feats[mine], "labels": torch.tensor(mine),
+                "filepath": [f"f{i}.jpg" for i in mine]}
+        merged = gather_rank_parts(part, n, rank, world)
+        if rank == 0:
+            assert merged["filepath"] == [f"f{i}.jpg" for i in range(n)] and torch.equal(merged["labels"], torch.arange(n))
+            assert torch.equal(merged["caption_features"], feats) and torch.equal(merged["image_features"], -feats)
+        else:
+            assert merged is None
         q.put((rank, "ok"))
     except Exception:  # noqa
         import traceback
@@ -101,6 +115,19 @@ def test_world2_gloo_data_parallel_host_logic():
         if p.is_alive():
             p.kill()
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_extraction_does_not_split_the_batch_over_ranks(monkeypatch):
+    """`--bsz 1024` with 3 ranks is fine for feature extraction (nothing is split); training still refuses."""
+    from swat_amd import dp
+    import pytest
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(dist, "init_process_group", lambda *a, **k: None)
+    with pytest.raises(ValueError):
+        dp.init_from_env(types.SimpleNamespace(dist_backend="gloo", bsz=1024))
+    a = dp.init_from_env(types.SimpleNamespace(dist_backend="gloo", bsz=1024), split_batch=False)
+    assert a.world == 3
 
 
 def test_single_process_is_untouched():

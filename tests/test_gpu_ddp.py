@@ -125,24 +125,23 @@ def _initial_flat():
 
 
 def test_bench_two_rank_plumbing_prints_one_json_line():
-    """bench.py exactly as the driver launches it at N = 2 (torch.distributed.run, one JSON line from rank 0, roofline
-    leg on every rank, barrier + max-over-ranks timing) — on the one test GPU over gloo, so only the plumbing is
-    checked, not the number."""
+    """`python bench.py --gpus 2 ...` with NO launcher, the form of the driver's recorded command: bench.py starts the two
+    ranks itself (torch.distributed.run as a child process), rank 0 prints one JSON line with n_gpus = 2, roofline leg on
+    every rank, barrier + max-over-ranks timing — on the one test GPU over gloo, so only the plumbing is checked, not
+    the number."""
     import json
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, SWAT_BENCH_TEST_BACKEND="gloo", SWAT_BENCH_TEST_DEVICE="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-                        "--warmup", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["backend"] == "gloo" and d["rccl_ranks"] is None   # rccl_ranks = dist.get_world_size() on the nccl backend only
     assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"] + 0.1
@@ -283,3 +282,63 @@ def test_sharded_index_and_sharded_dense_topk_two_ranks(tmp_path):
         assert torch.equal(out["val"][valid], w_val.cpu()[valid])
         assert out["route"] == "bf16-candidates+exact-rescore"
         assert torch.equal(out["d_idx"], e_idx.cpu()) and torch.equal(out["d_val"], e_val.cpu())
+
+
+def test_extract_mined_feature_cli_two_ranks_equals_one_process(tmp_path):
+    """SURVEY 8(e) row 3 end to end: `python -m swat_amd.retrieval.extract_mined_feature` (ref retrieval/
+    extract_mined_feature.py:252-315) on a toy retrieved folder, once as one process and once under torch.distributed.run
+    with two ranks (gloo on the one test GPU): rank 0's file list is broadcast, every rank encodes its strided share on the
+    HIP towers, the shares are gathered as tensors and rank 0 writes the reference's mined.pth dict — same rows, same
+    order, same features (bf16 towers: batches differ between the two runs, so to the stated path-A tolerance)."""
+    import gzip
+    import pickle
+    import re
+    import subprocess
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    from swat_amd import tokenizer as tk
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_tokenizer import CORPUS, learn_merges
+    rs = np.random.RandomState(9)
+    root = tmp_path / "retrieved"
+    folder = root / "toy" / "toy_retrieved_LAION400M-all_synonyms-random"
+    cap_map = {}
+    words = [w for w in " ".join(CORPUS).lower().split() if w.isalpha()]
+    for c in (0, 2, 5):
+        os.makedirs(folder / str(c))
+        cap_map[str(c)] = {}
+        for i in range(5):
+            img_id = str(100 * c + 3 * i + 1)
+            Image.fromarray(rs.randint(0, 255, (240 + 8 * i, 256 + 4 * c, 3), dtype=np.uint8)).save(folder / str(c) / f"{img_id}.jpg", quality=95)
+            cap_map[str(c)][img_id] = " ".join(rs.choice(words, size=3 + i % 4))
+    pickle.dump(cap_map, open(root / "toy" / "toy_metadata-random-0.0-LAION400M.map", "wb"))
+    pat = re.compile(r"'s|'t|'re|'ve|'m|'ll|'d|[a-zA-Z]+|[0-9]|[^\sa-zA-Z0-9]+", re.IGNORECASE)
+    merges = learn_merges([w for t in CORPUS for w in re.findall(pat, t.lower())], 120, tk._bytes_to_unicode())
+    bpe = tmp_path / "bpe_tiny.txt.gz"
+    with gzip.open(bpe, "wt", encoding="utf-8") as f:
+        f.write("#version: synthetic\n")
+        for a, b in merges:
+            f.write(f"{a} {b}\n")
+    env = dict(os.environ, SWAT_BPE_VOCAB=str(bpe), PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    flags = ["-m", "swat_amd.retrieval.extract_mined_feature", "--dataset", "toy", "--root", str(root), "--bsz", "4",
+             "--num_workers", "0", "--dist_backend", "gloo"]
+    out = root / "toy" / "toy_vitb32_openclip_laion400m_mined.pth"
+    r = subprocess.run([sys.executable] + flags, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = torch.load(out, weights_only=False)
+    os.rename(out, tmp_path / "one.pth")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port())] + flags, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = torch.load(out, weights_only=False)
+    assert set(two) == {"caption_features", "labels", "filepath", "image_features"}                  # the reference's key set (:270-279)
+    assert len(one["filepath"]) == 15 and two["filepath"] == one["filepath"] and torch.equal(two["labels"], one["labels"])
+    assert [int(os.path.basename(os.path.dirname(p))) for p in two["filepath"]] == two["labels"].tolist()
+    for key in ("caption_features", "image_features"):
+        a, b = one[key], two[key]
+        assert a.shape == b.shape == (15, 512) and not b.is_cuda
+        assert (a - b).abs().max().item() <= 0.007 * a.abs().max().item() + 1e-3
+        assert torch.allclose(b.norm(dim=1), torch.ones(15), atol=1e-4)

@@ -123,6 +123,27 @@ def test_cli_end_to_end_on_synthetic_data(tmp_path, monkeypatch):
     assert "visual.transformer.resblocks.11.mlp.c_proj.weight" in ck["clip"]
 
 
+@pytest.mark.parametrize("cfg,width", [("vitl14_openclip_laion400m", 768), ("vitb16_openclip_laion400m", 512)])
+def test_cli_other_model_cfgs_build_a_head_of_the_tower_width(tmp_path, monkeypatch, cfg, width):
+    """BASELINE config 5 (ViT-L/14) and ViT-B/16 through main.py: `--synthetic` forces cls_init = random, whose head the
+    reference hard-codes to 512 columns (utils/models.py:26,36) — here the head takes the tower's embedding width, so one
+    stage-1 epoch (cutmix, WiSE-FT, tau-norm, checkpoint) runs on a 768-wide embedding too."""
+    import glob
+    import sys
+    monkeypatch.chdir(tmp_path)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import main as cli
+    summary = cli.main(["--synthetic", "16", "--num_classes", "3", "--method", "cutmix", "--epochs", "1", "--bsz", "8",
+                        "--num_workers", "0", "--log_mode", "file", "--shots", "4", "--skip_stage2", "--model_cfg", cfg,
+                        "--folder", str(tmp_path / "out")])
+    parts = summary.split(",")
+    assert parts[1] == "cutmix" and 0.0 <= float(parts[7]) <= 100.0
+    ck = glob.glob(str(tmp_path / "out" / "**" / "stage1_model_best*"), recursive=True)
+    assert len(ck) == 1
+    st = torch.load(ck[0], map_location="cpu", weights_only=False)
+    assert st["head"]["linear.weight"].shape == (3, width) and st["clip"]["visual.proj"].shape[1] == width
+
+
 def test_cli_zeroshot_method_matches_the_oracle(tmp_path, monkeypatch, capsys):
     """BASELINE config 1 (`--method zeroshot`, ref main.py:219-227, utils/training.py:23-44): the CLI builds the model and the
     classifier head, validates on the test split through the HIP tower + fused head, prints the 8-field summary and exits.
@@ -203,8 +224,11 @@ def test_stage_fan_out_matches_the_reference_golden(golden_dir):
     wm, wh, wacc = stages.run_wsft_alpha(args, best, head_b, val, test, zero, head_z, ls, _Lg())
     assert np.allclose(wh.linear.weight.detach().cpu().numpy(), g["wsft_alpha_head"], atol=1e-6)
     assert abs(wacc - float(g["wsft_alpha_test_acc"])) <= 100.0 / 48 + 1e-9     # bf16 tower: at most one near-tie flips
+    # the interpolated tower itself: embeddings of the batch the reference's ensemble_model(0.5) tower was recorded on
     with torch.no_grad():
-        e = wm.visual.forward_raw(val[0][0].to("cuda")).cpu().numpy()
+        e = wm.visual.forward_raw(mg.stage_loader(21, 22, 8)[0][0].to("cuda")).cpu().numpy()
+    want_e = g["wsft_0.5_embeds"]
+    assert e.shape == want_e.shape and np.abs(e - want_e).max() <= 0.007 * np.abs(want_e).max()
     # tau-normalisation on pre-extracted features of the same splits
     fv, ft = extract_test_feats(best, val), extract_test_feats(best, test)
     pv = [(fv["image_features"][i:i + 8], fv["labels"][i:i + 8], torch.zeros(1), 1) for i in range(0, 40, 8)]
@@ -213,3 +237,85 @@ def test_stage_fan_out_matches_the_reference_golden(golden_dir):
     if abs(tau - float(g["tau_best"])) < 1e-9:
         assert np.allclose(th.linear.weight.detach().cpu().numpy(), g["tau_head"], rtol=1e-5, atol=1e-6)
     assert abs(tacc - float(g["tau_test_acc"])) <= 2 * 100.0 / 48 + 1e-9
+
+
+def test_train_probing_matches_the_reference_golden(golden_dir):
+    """A8 / f.4: swat_amd.training.train_probing (fused head step + device-side validate) on pre-extracted features against the
+    REFERENCE's own train_probing (utils/training.py:47-161 — the loop main.py:402-474 run_stage2_probing drives), recorded by
+    oracle/make_golden.py `probing`: loss.csv rows, the trained head, best records and the confusion matrix.  The head path is
+    fp32 end to end, so the tolerance is rounding of a different summation order, not bf16."""
+    from oracle.make_golden import probing_inputs
+    from swat_amd import optimizers, training
+    from swat_amd.clip_model import CLIP
+    from swat_amd.models import MyLinear
+    g = np.load(os.path.join(golden_dir, "probing_tiny.npz"), allow_pickle=False)
+    train, val, test, W0 = probing_inputs()
+    torch.manual_seed(0)
+    model = CLIP(vision_cfg=TINY, text_cfg=(8, 64, 64, 1, 1)).to("cuda")
+    head = MyLinear(weights=W0.clone()).to("cuda")
+    args = _args(method="probing", epochs=3, pre_extracted=True, lr_classifier=1e-2, early_stop=False)
+    args.loss = torch.nn.CrossEntropyLoss()
+    params, logit_scale = optimizers.set_params(args, model, head, _Lg())
+    assert abs(float(logit_scale.reshape(-1)[0]) - 4.60517) < 1e-6 and not logit_scale.requires_grad   # fixed ln(100), ref optimizers.py:58
+    opt, sched, _ = optimizers.set_optimizer(args, params, train)
+    args.optimizer, args.scheduler = opt, sched
+    csv = io.StringIO()
+    best_model, best_head, rec, best_ls, vl, tl = training.train_probing(args, _Lg(), csv, model, head, None, None, train, val, test, False)
+    assert vl is val and tl is test
+    got = [[float(v) for v in line.split(",")] for line in csv.getvalue().strip().split("\n")]
+    want = [[float(v) for v in line.split(",")] for line in str(g["csv"]).strip().split("\n")]
+    assert len(got) == len(want) == 3
+    for a, b in zip(got, want):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert abs(a[2] - b[2]) < 2e-4 * max(1.0, abs(b[2])) and abs(a[3] - b[3]) < 2e-4 * max(1.0, abs(b[3]))   # train / val loss
+        assert a[4] == b[4] and a[5] == b[5]                                                              # val / test accuracy
+    ref_head = torch.from_numpy(g["head"])
+    assert ((head.linear.weight.cpu() - ref_head).norm() / ref_head.norm()).item() < 1e-5
+    assert ((best_head.linear.weight.cpu() - torch.from_numpy(g["best_head"])).norm() / ref_head.norm()).item() < 1e-5
+    wb = json.loads(str(g["best"]))
+    assert rec["best_val_acc"] == wb[0] and rec["best_epoch"] == wb[1] and rec["best_iter"] == wb[2]
+    assert np.array_equal(np.asarray(rec["best_confusion_matrix"]), g["cm"])
+    assert abs(rec["best_scores"]["avg_class_accuracy"] - float(g["avg_class_acc"])) < 1e-9
+
+
+def test_get_text_features_and_cal_prompt_tensors_match_the_reference_golden(golden_dir, tmp_path, monkeypatch):
+    """B8 compute branch: swat_amd.features.get_text_features (HIP text tower: encode every template x synonym, L2-normalise,
+    mean, L2-normalise) and the UN-CACHED branch of cal_prompt_tensors (prompt_maker -> get_text_features -> both tables
+    saved, then the cached branch on the second call) against the reference's own functions (utils/features.py:39-64,
+    retrieval/sample_retrieval.py:1418-1454) recorded on the fp32 oracle by oracle/make_golden.py `prompt_tensors`."""
+    from oracle import synth
+    from oracle.make_golden import PROMPT_TEXT_CFG, prompt_metrics, prompt_tensor_model
+    from swat_amd import features
+    from swat_amd.clip_model import CLIP
+    from swat_amd.prompt import prompt_maker
+    from swat_amd.retrieval.sample_retrieval import cal_prompt_tensors
+    g = np.load(os.path.join(golden_dir, "prompt_tensors.npz"), allow_pickle=False)
+    model = CLIP(vision_cfg=TINY, text_cfg=PROMPT_TEXT_CFG)
+    model.load_state_dict(prompt_tensor_model().state_dict())
+    model.to("cuda").eval()
+    tok = synth.hash_tokenize(PROMPT_TEXT_CFG[0], PROMPT_TEXT_CFG[1])
+    metrics = prompt_metrics()
+
+    def close(a, b):  # unit vectors through a bf16 tower: the stated path-A tolerance (0.7 % of max-abs), and still unit-norm
+        a = a.detach().float().cpu().numpy()
+        assert a.shape == b.shape and np.abs(a - b).max() <= 0.007 * np.abs(b).max() + 2e-3, np.abs(a - b).max()
+        assert np.allclose(np.linalg.norm(a, axis=-1), 1.0, atol=1e-4)
+
+    for ds, nt in (("semi-aves", "alternates"), ("dtd", "name")):
+        td = features.get_text_features(model, prompt_maker(metrics, ds, nt), tok, "encode")
+        keys = json.loads(str(g[f"{ds}|{nt}|keys"]))
+        assert list(td.keys()) == keys
+        assert [td[k]["all"].shape[0] for k in keys] == g[f"{ds}|{nt}|counts"].tolist()
+        close(torch.cat([td[k]["all"] for k in keys]), g[f"{ds}|{nt}|all"])
+        close(torch.stack([td[k]["mean"] for k in keys]), g[f"{ds}|{nt}|mean"])
+    # the command line's branch: no cache on disk -> compute + save; second call -> load
+    monkeypatch.chdir(tmp_path)
+    args = types.SimpleNamespace(dataset="semi-aves", model_cfg="vitb32_openclip_laion400m", prompt_name="alternates", recal_prompt=False)
+    ptd, tpd = cal_prompt_tensors(args, _Lg(), model, tok, metrics, "/unused", data_dir=str(tmp_path / "data"))
+    keys = json.loads(str(g["cal|keys"]))
+    assert list(ptd["alternates"].keys()) == keys
+    close(torch.stack([ptd["alternates"][k]["mean"] for k in keys]), g["cal|mean"])
+    assert sorted(os.listdir(tmp_path / "data" / "semi-aves" / "prompts")) == json.loads(str(g["cal|files"]))
+    assert tpd["alternates"][keys[0]]["corpus"] == json.loads(str(g["cal|corpus0"]))
+    ptd2, _ = cal_prompt_tensors(args, _Lg(), None, None, metrics, "/unused", data_dir=str(tmp_path / "data"))   # cached: no model needed
+    assert torch.equal(ptd2["alternates"][keys[0]]["mean"].cpu(), ptd["alternates"][keys[0]]["mean"].cpu())

@@ -2,6 +2,7 @@
 (tests/golden/host_logic.json, loop_tiny.npz — oracle/make_golden.py `host` / `loop`)."""
 import json
 import os
+import sys
 import types
 
 import numpy as np
@@ -171,3 +172,37 @@ def test_prompt_makers_match_reference_golden(golden_dir):
     with pytest.raises(KeyError):
         prompt.prompt_maker(m, "imagenet", "name")  # the 80-template list comes from SWAT_TEMPLATES_JSON
     assert prompt.prompt_maker(m, "some-new-dataset", "name")["0"]["corpus"] == ["a photo of a barn owl."]
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """`bench.py --gpus 8` inside a 1-rank (or 2-rank) environment is a hard error, never a silent 1-GPU number
+    (VERDICT r02 missing #1 / ADVICE medium); without WORLD_SIZE it launches the ranks itself."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bench_self_launch_starts_one_rank_per_gpu(monkeypatch):
+    import importlib.util
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        return subprocess.CompletedProcess(cmd, 0, stdout='noise\n{"n_gpus": 4}\n', stderr="")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    assert bench.self_launch(4, ["--gpus", "4", "--steps", "3"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]

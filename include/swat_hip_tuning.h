@@ -32,6 +32,14 @@ int swat_gemm_set_swizzle(int mode);    /* 0 = plain 2-D grid, -1 = XCD-aware ti
  *     reduction runs as `planes` slices into fp32 planes that the next LayerNorm kernel sums in a fixed order (default 3;
  *     0 or 1 = one launch, no planes).  Deterministic either way; the per-element summation order differs. */
 int swat_vit_set_split_k(int planes);
+/* The transformer blocks of the forward as ONE persistent launch (csrc/vit_mega.hip; ViT-B/32 regime: d = 768, 12 heads of 64,
+ *     38 <= T <= 56): 1 = on when the shapes qualify (default), 0 = always op by op.  Same buffers, same rounding points. */
+int swat_vit_set_mega(int mode);
+/* Synchronises the device and returns the status word of the persistent forwards since the last call: 0 = every team
+ *     hand-off completed; otherwise bit 30 is set and the low bits name the hand-off a workgroup gave up on (0.5 s). */
+int swat_vit_mega_status(void);
+/* Per-workgroup phase stamps of the next persistent forwards (64 x uint64 per workgroup, 100 MHz ticks); null = off. */
+int swat_vit_mega_trace(void* device_buffer);
 
 #ifdef __cplusplus
 }

@@ -45,4 +45,10 @@ int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s
 // n products of one layout: one grouped launch when every product qualifies, else one launch each
 int gemm_group_dispatch(int layout, const GemmArgs* probs, int n, hipStream_t s);
 
+// the transformer blocks of the ViT forward as one persistent launch (vit_mega.hip); -> 0 launched, 1 not eligible, < 0 error
+int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int save, int M, int Mp, const float* params,
+                     const unsigned short* shadow, const int64_t* layer_offs, float* xs, float* x1, unsigned short* h1,
+                     unsigned short* h2, unsigned short* a, unsigned short* qkv, unsigned short* f, unsigned short* gact, float* mean1,
+                     float* rstd1, float* mean2, float* rstd2, hipStream_t s);
+
 }  // namespace swat

@@ -318,7 +318,11 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
     TRY(swat_layernorm_fwd(w.xpre, d, params + O.lnpre_w, params + O.lnpre_b, nullptr, w.xs, w.mean_pre, w.rstd_pre, M, d, eps, s));
 
     int pending = 1;  // split-K planes of the previous block's c_proj still to be summed into xs[l]
-    for (int l = 0; l < D.L; ++l) {
+    // ViT-B/32 regime: all blocks in ONE persistent launch (csrc/vit_mega.hip); same buffers, so the backward is unchanged
+    const int mega = vit_mega_forward(D.B, T, d, D.H, D.mlp, D.L, D.act, D.save, M, D.Mp, params, sh, O.layer, w.xs, w.x1, w.h1, w.h2, w.a,
+                                      w.qkv, w.f, w.gact, w.mean1, w.rstd1, w.mean2, w.rstd2, s);
+    if (mega < 0) return mega;
+    for (int l = 0; l < (mega == 0 ? 0 : D.L); ++l) {
         const int64_t* lo = O.layer + 12 * l;
         const int64_t li = D.save ? l : 0;
         float* xin = w.xs + (D.save ? (int64_t)l : (int64_t)(l & 1)) * M * d;

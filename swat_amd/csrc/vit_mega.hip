@@ -1,0 +1,712 @@
+// swat_amd/csrc/vit_mega.hip — the transformer blocks of the ViT forward as ONE persistent launch (ViT-B/32 regime:
+// T <= 56 tokens, d = 768, head width 64, B*T rows in the low thousands).
+//
+// ref: the 12 x [ln_1, in_proj, attention, out_proj, ln_2, c_fc, act, c_proj] of open_clip's VisionTransformer.forward
+// behind model.encode_image (call sites utils/training.py:332,1474, testing.py:430; arithmetic SURVEY App. A).
+//
+// Why.  Launched op by op (csrc/vit.hip) a block is seven launches of 5-18 us each, of which 6-7 us per GEMM launch
+// are fixed costs (dispatch, workgroup entry, first operand bytes, epilogue tail) — at B = 32 they are
+// 40 % of the step.  Every op of the forward is local to an image (attention) or to a row (LayerNorm, the linear
+// layers), so a PANEL of images can run the whole tower without ever waiting for another panel.  The launch is 256
+// workgroups, one per CU, in TEAMS of 16: a team owns one panel (P images, P*T <= 112 rows = seven 16-row MFMA fragments)
+// at a time and walks it through all layers.  Inside a layer the team alternates six phases with a team-wide
+// hand-off between them (nothing is chip-wide):
+//     LN1 : member i normalises rows 7i .. 7i+6 of the panel                               -> h1 (bf16)
+//     QKV : member h < H multiplies the panel by head h's 3 x 64 rows of in_proj (112 x 192 x K tile), keeps q, k, v in
+//           LDS and runs the attention of its head for the panel's images right there       -> qkv (for backward), a
+//     OUT : member i computes columns 48i .. 48i+47 of out_proj, + bias + residual          -> x1 (fp32)
+//     LN2 : as LN1                                                                         -> h2
+//     FC  : member i computes columns 192i .. of c_fc, + bias, activation                   -> f, g = act(f)
+//     PRJ : member i computes columns 48i .. of c_proj, + bias + residual                   -> x (next block's input)
+// The GEMM phases use the producer / consumer structure of csrc/gemm_pc.hip (loader waves issue LDS-DMA into a ring with
+// counted vmcnt, consumer waves read fragments and issue v_mfma_f32_16x16x32_bf16, one raw s_barrier per 64-deep
+// k-step); what bounds them is the same per-CU L2 -> LDS rate, but a layer now pays six ~2 us hand-offs instead of
+// seven kernel boundaries + launch fixed costs.
+//
+// Hand-off protocol (MI355X guide, Guideline 16 recipe R1, counter form; placement-independent — the team <-> XCD
+// mapping below is for speed only): every byte another workgroup will read is stored write-through (sc1); each storing
+// wave drains its stores (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane adds 1 to the team's arrival counter (agent
+// scope) and polls it relaxed until all 16 members of the phase have arrived; then ONE agent-scope acquire
+// (buffer_inv sc1), its wait, workgroup barrier, and only then the next phase's loads.  Counters are zeroed by a
+// hipMemsetAsync in front of every launch; every spin is bounded (give-up code in the status block).
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
+#include "gemm_device.hpp"
+#include "attention.hpp"
+#include "../../include/swat_hip.h"
+#include "../../include/swat_hip_tuning.h"
+
+namespace swat {
+
+constexpr int MG_ROWS = 112;      // panel rows held by one team (seven 16-row fragments)
+constexpr int MG_FM = 7;
+constexpr int MG_TEAM = 16;       // workgroups per team
+constexpr int MG_THREADS = 512;   // 4 consumer + 4 loader waves
+constexpr int MG_NC = 4, MG_NL = 4;
+constexpr int MG_LDS = 156 * 1024;
+
+struct MegaFwd {
+    // shapes
+    int B, T, d, H, mlp, L, act, save, M, Mp;
+    int P;          // images per panel
+    int npanels, nteams;
+    float eps;
+    // parameters: fp32 master + bf16 shadow at the same element offsets; layer l adds l * layer_stride
+    const float* params;
+    const unsigned short* shadow;
+    int64_t lo[12];         // ln1_w ln1_b qkv_w qkv_b out_w out_b ln2_w ln2_b fc_w fc_b proj_w proj_b of layer 0
+    int64_t layer_stride;
+    // workspace (csrc/vit.hip carve): per-layer strides are 0 when the forward does not save activations
+    float* xs;              // [(L+1) or 2][M, d]
+    float* x1;
+    unsigned short *h1, *h2, *a, *qkv, *f, *gact;
+    float *mean1, *rstd1, *mean2, *rstd2;
+    // hand-off state (zeroed before every launch)
+    unsigned* ctr;          // [nteams][32] : word 0 of each 128-B line = arrivals
+    unsigned* status;       // [0] = first give-up code (0 = ok)
+    unsigned long long* trace;  // tuning: per workgroup phase stamps (null in production)
+};
+
+enum { LN1W = 0, LN1B, QKVW, QKVB, OUTW, OUTB, LN2W, LN2B, FCW, FCB, PRW, PRB };
+
+// ---- write-through (sc1) stores / loads of bytes that cross workgroups ---------------------------------------------
+__device__ __forceinline__ void st_sc1_16(void* p, u32x4_t v) {
+    // one 16-B store with sc1: inline asm (a raw-buffer descriptor would cap the workspace at 4 GiB); the trailing s_nop keeps
+    // the data registers intact until the store has read them (guide 5.7 item 1)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v));
+}
+__device__ __forceinline__ void st_sc1_8(void* p, unsigned lo, unsigned hi) {
+    const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned long long mg_clock() { return wall_clock64(); }  // 100 MHz
+
+// W-slice prefetch into the XCD's L2 (no register, no wait): one 4-byte LDS-DMA per 128-B line of the next phase's weight
+// slice, landing in a 256-B scratch behind the ring.  A weight slice is read by only two CUs of an XCD, so without this the
+// ring's DMAs run at HBM latency (~2 us per stage: 55 GB/s per CU measured); touched ahead, they hit L2.
+constexpr bool MG_TOUCH = false;   // measured: touching lines ahead costs the TA path as much as loading them
+struct MegaTouch {
+    const unsigned short* W;   // next phase's weight matrix (null: nothing to prefetch)
+    int ldw, nrows, row0, qkv_h, d, nk;   // tile row n -> W row (qkv_h >= 0: head-strided in_proj rows, else row0 + n)
+};
+__device__ __forceinline__ void mg_touch(const MegaTouch& t, unsigned char* scratch, int wave3, int lane) {
+    if (!MG_TOUCH || !t.W) return;
+    const int lines = t.nrows * t.nk;          // one line = 64 k of one W row
+    for (int i = wave3 * 64 + lane; i < (lines + 63) / 64 * 64; i += 3 * 64) {
+        const int ii = i < lines ? i : lines - 1;
+        const int ks = ii / t.nrows, n = ii % t.nrows;   // k-step major: the first k-steps arrive first
+        const int row = t.qkv_h >= 0 ? (n >> 6) * t.d + 64 * t.qkv_h + (n & 63) : t.row0 + n;
+        const unsigned short* src = t.W + (int64_t)row * t.ldw + 64 * ks;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)scratch, 4, 0, 0);
+    }
+}
+
+// the lines of ONE 64-deep k-step of a weight slice (nrows lines): consumer wave w touches rows 64 w .. 64 w + 63
+__device__ __forceinline__ void mg_touch_step(const MegaTouch& t, int ks, unsigned char* scratch, int wave, int lane) {
+    if (!MG_TOUCH || !t.W || ks >= t.nk || 64 * wave >= t.nrows) return;
+    int n = 64 * wave + lane;
+    n = n < t.nrows ? n : t.nrows - 1;
+    const int row = t.qkv_h >= 0 ? (n >> 6) * t.d + 64 * t.qkv_h + (n & 63) : t.row0 + n;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.W + (int64_t)row * t.ldw + 64 * ks),
+                                     (__attribute__((address_space(3))) void*)scratch, 4, 0, 0);
+}
+constexpr int MG_TOUCH_AHEAD = 8;   // k-steps between a line's touch and its LDS-DMA (HBM latency + the ring's 3 stages)
+
+// team-wide hand-off: all members' phase outputs are complete and visible when this returns (see the file header).
+// While lane 0 waits for the team, waves 1-3 pull the next phase's weight slice into L2.
+__device__ __forceinline__ void team_sync(const MegaFwd& p, int team, unsigned target, const MegaTouch& touch, unsigned char* scratch,
+                                          unsigned long long* tr = nullptr) {
+    if (tr && threadIdx.x == 0) tr[0] = mg_clock();   // stores issued
+    mg_drain();          // every storing wave
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) {
+        if (tr) tr[1] = mg_clock();                   // stores drained, workgroup together
+        unsigned* c = p.ctr + team * 32;
+        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = mg_clock();
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (mg_clock() - t0 > 50000000ull) {  // 0.5 s: a member never arrived (not resident / faulted): give up, flag it
+                __hip_atomic_store(p.status, 0x80000000u | target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (tr) tr[2] = mg_clock();                   // every member has arrived
+        // The acquire drops lines this CU's L1 (and the L2's non-local lines) may hold from BEFORE they were rewritten.  With
+        // save = 1 every handed-off buffer is per layer: each line is written once in a launch and no workgroup loads it before
+        // the hand-off that publishes it (the launch itself starts with invalidated caches), so there is nothing stale to
+        // drop and the ~1 us invalidate is skipped.  save = 0 re-uses the buffers layer after layer: the acquire stays.
+        if (!p.save) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (tr) tr[3] = mg_clock();                   // acquire complete
+    } else if (wave >= 1 && wave <= 3) {
+        mg_touch(touch, scratch, wave - 1, threadIdx.x & 63);
+    }
+    __syncthreads();
+}
+
+template <int N_>
+__device__ __forceinline__ void mg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+__device__ __forceinline__ void mg_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8_t mg_lds_b128(unsigned addr) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+template <int N_>
+__device__ __forceinline__ void mg_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_ > 15 ? 15 : N_) : "memory"); }
+__device__ __forceinline__ void mg_pin(bf16x8_t& v) { asm volatile("" : "+v"(v)); }
+template <int N_, typename F, int... Is>
+__device__ __forceinline__ void mg_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N_, typename F>
+__device__ __forceinline__ void mg_static_for(F&& f) { mg_static_for_impl<N_>(f, std::make_integer_sequence<int, N_>{}); }
+
+// ---- one GEMM phase: C[112, BN] = A[rows, K] (row-major, lda) x W^T, W rows picked by wrow(n), both operands
+// k-contiguous.  Structure and LDS image of gemm_pc_kernel<L_NT> (one tile, FM = 7 row fragments for every consumer
+// wave, CN consumer waves side by side in n).  On return the fp32 tile sits in LDS at smem as [112][BN + 4] and the
+// workgroup has passed a barrier behind it.
+template <int BN, int CN, int NS, class WRow>
+__device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned short* A, int lda, int rows, const unsigned short* W,
+                                            int ldw, WRow wrow, int K, const MegaTouch& tcur, const MegaTouch& tnext, unsigned char* scratch) {
+    constexpr int NL = MG_NL, NC = MG_NC;
+    constexpr int FM = MG_FM, WN = BN / CN, FN = WN / 16;
+    static_assert(BN % (16 * CN) == 0 && CN <= NC, "wave tiles are whole fragments");
+    constexpr int PA = MG_ROWS / 8, PB = BN / 8, P = PA + PB;
+    constexpr int A_BYTES = PA * 1024, STAGE = P * 1024;
+    constexpr int LPS = (P + NL - 1) / NL;
+    static_assert(NS >= 4 && NS * STAGE <= MG_LDS && MG_ROWS * (BN + 4) * 4 <= NS * STAGE, "LDS ring");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = K >> 6;
+
+    if (wave >= NC) {
+        // ================================ loader waves ================================
+        const int lw = wave - NC;
+        unsigned voff[LPS];
+        unsigned amask = 0, dmask = 0;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            int q = lw + NL * i;
+            if (q >= P) { q -= NL; dmask |= 1u << i; }
+            const bool isA = q < PA;
+            if (isA) amask |= 1u << i;
+            const int byte = (isA ? q : q - PA) * 1024 + lane * 16;
+            const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
+            if (isA) {
+                const int gr = row < rows ? row : rows - 1;
+                voff[i] = (unsigned)(gr * lda + 8 * t) * 2u;
+            } else {
+                voff[i] = (unsigned)(wrow(row) * ldw + 8 * t) * 2u;
+            }
+        }
+        const char* curA = reinterpret_cast<const char*>(A);
+        const char* curB = reinterpret_cast<const char*>(W);
+        auto issue = [&](int buf) {
+            unsigned char* st = smem + buf * STAGE + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) {
+                const char* src = ((amask >> i) & 1) ? curA : curB;
+                unsigned char* dst = st + (NL * i - (((dmask >> i) & 1) ? NL : 0)) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + voff[i]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+            curA += 128; curB += 128;
+        };
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nk) issue(s);
+        int t = 0, buf = NS - 1;
+        for (; t + NS - 1 < nk; ++t) {
+            mg_wait_vmcnt<(NS - 3) * LPS>();
+            mg_barrier();
+            issue(buf);
+            buf = buf + 1 == NS ? 0 : buf + 1;
+        }
+        for (; t < nk; ++t) {
+            switch (nk - 2 - t) {
+                case 1: mg_wait_vmcnt<LPS>(); break;
+                case 2: mg_wait_vmcnt<(NS >= 5 ? 2 : 0) * LPS>(); break;
+                case 3: mg_wait_vmcnt<(NS >= 6 ? 3 : 0) * LPS>(); break;
+                default: mg_wait_vmcnt<0>(); break;
+            }
+            mg_barrier();
+        }
+    } else {
+        // ================================ consumer waves ================================
+        const bool active = wave < CN;   // BN = 48: three column fragments, the fourth consumer wave only keeps the barriers
+        const int wn0 = (active ? wave : 0) * WN;
+        const int r16 = lane & 15, g = lane >> 4;
+        const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
+        unsigned ra[2], rb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            ra[ks] = lds0 + kc_off(r16, 4 * ks + g);
+            rb[ks] = lds0 + A_BYTES + kc_off(wn0 + r16, 4 * ks + g);
+        }
+        f32x4_t acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            bf16x8_t fa[FM], fb[2][FN];
+            constexpr int RB = FM / 2;
+            auto read_a = [&](auto I, unsigned so, int ks) {
+                constexpr int i = decltype(I)::value;
+                fa[i] = mg_lds_b128<2048 * i>(ra[ks] + so);
+            };
+            auto read_b = [&](auto J, unsigned so, int ks, bf16x8_t (&bfr)[FN]) {
+                constexpr int j = decltype(J)::value;
+                bfr[j] = mg_lds_b128<2048 * j>(rb[ks] + so);
+            };
+            constexpr int NRI = FM + FN;
+            auto half = [&](auto WITH_READS, bf16x8_t (&bcur)[FN], bf16x8_t (&bnext)[FN], unsigned sn, int nks) {
+                mg_static_for<FM>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    // reads issued behind row i-1 of THIS half (with reads): a_{i-1} + the B fragments that ride behind row i-1
+                    if constexpr (i == 0) {
+                        mg_wait_lgkm<(FM - RB)>();
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) mg_pin(bcur[j]);
+                    } else if constexpr (decltype(WITH_READS)::value) {
+                        mg_wait_lgkm<NRI - 1>();
+                    } else {
+                        constexpr int later_b = i + 1 < RB ? FN - (i + 1) * FN / RB : 0;
+                        mg_wait_lgkm<(FM - 1 - i) + later_b>();
+                    }
+                    mg_pin(fa[i]);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], fa[i], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (decltype(WITH_READS)::value) {
+                        read_a(I, sn, nks);
+                        if constexpr (i < RB) {
+                            constexpr int j0 = i * FN / RB, j1 = (i + 1) * FN / RB;
+                            mg_static_for<j1 - j0>([&](auto Jd) {
+                                read_b(std::integral_constant<int, j0 + decltype(Jd)::value>{}, sn, nks, bnext);
+                            });
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            };
+            using T0 = std::integral_constant<int, 0>;
+            using T1 = std::integral_constant<int, 1>;
+            mg_barrier();  // barrier 0: stages 0 and 1 have landed
+            mg_static_for<FM>([&](auto I) { read_a(I, 0u, 0); });
+            mg_static_for<FN>([&](auto J) { read_b(J, 0u, 0, fb[0]); });
+            mg_wait_lgkm<0>();
+            unsigned so = 0;
+            for (int t = 0; t + 1 < nk; ++t) {
+                const unsigned sn = so + STAGE == NS * STAGE ? 0u : so + STAGE;
+                half(T1{}, fb[0], fb[1], so, 1);
+                half(T1{}, fb[1], fb[0], sn, 0);
+                mg_barrier();
+                // keep the weight stream MG_TOUCH_AHEAD k-steps ahead in L2; it runs on into the next GEMM phase's slice
+                if (t + MG_TOUCH_AHEAD < nk) mg_touch_step(tcur, t + MG_TOUCH_AHEAD, scratch, wave, lane);
+                else mg_touch_step(tnext, t + MG_TOUCH_AHEAD - nk, scratch, wave, lane);
+                so = sn;
+            }
+            half(T1{}, fb[0], fb[1], so, 1);
+            half(T0{}, fb[1], fb[0], 0u, 0);
+            mg_touch_step(tnext, MG_TOUCH_AHEAD - 1, scratch, wave, lane);
+        } else {
+            for (int t = 0; t < nk; ++t) {
+                mg_barrier();
+                if (t + 1 < nk) {
+                    if (t + MG_TOUCH_AHEAD < nk) mg_touch_step(tcur, t + MG_TOUCH_AHEAD, scratch, wave, lane);
+                    else mg_touch_step(tnext, t + MG_TOUCH_AHEAD - nk, scratch, wave, lane);
+                } else {
+                    mg_touch_step(tnext, MG_TOUCH_AHEAD - 1, scratch, wave, lane);
+                }
+            }
+        }
+        // accumulators -> LDS fp32 tile, behind a barrier: every consumer has finished reading the ring
+        // (the loaders are past their last stage barrier: this extra barrier is matched below)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (active) {
+            float* cl = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    *reinterpret_cast<f32x4_t*>(cl + (16 * i + r16) * (BN + 4) + wn0 + 16 * j + 4 * g) = acc[i][j];
+        }
+    }
+    if (wave >= NC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // matches the consumers' "ring is free" barrier
+    }
+    __syncthreads();                    // the fp32 tile is complete
+}
+
+// ---- LayerNorm of the member's rows (one wave per row): x fp32 -> y bf16 (sc1), mean / rstd ------------------------
+__device__ __forceinline__ void mg_layernorm(const MegaFwd& p, const float* x, const float* gamma, const float* beta,
+                                             unsigned short* y, float* mean, float* rstd, int row0, int rows_valid, int member) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = 7 * member + wave;     // 16 members x 7 rows = 112
+    if (wave < 7 && r < rows_valid) {
+        const int d = p.d;               // d = 768: 3 float4 per lane
+        const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)(row0 + r) * d);
+        float4 v[3], gm[3], bt[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = xr[lane + 64 * i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {    // every load of the row's pass is in flight before the first reduction
+            gm[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
+            bt[i] = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+        const float mu = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
+            q += a * a + b * b + cc * cc + dd * dd;
+        }
+        const float var = wave_sum(q) / (float)d;
+        const float rs = rsqrtf(var + p.eps);
+        if (lane == 0) {
+            mean[row0 + r] = mu;
+            rstd[row0 + r] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = lane + 64 * i;
+            const float o0 = (v[i].x - mu) * rs * gm[i].x + bt[i].x, o1 = (v[i].y - mu) * rs * gm[i].y + bt[i].y;
+            const float o2 = (v[i].z - mu) * rs * gm[i].z + bt[i].z, o3 = (v[i].w - mu) * rs * gm[i].w + bt[i].w;
+            st_sc1_8(y + (int64_t)(row0 + r) * d + 4 * c, pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        }
+    }
+}
+
+// ---- epilogue passes over the fp32 tile cl[112][BN + 4]: a thread keeps ONE column chunk (bias loaded once) and walks
+// the rows; every global load of the pass is issued before the first store (loads and stores share vmcnt, in order).
+// BN = 48, fp32 out: 12 chunks of 4 columns x 42 rows per pass (504 threads), 3 passes: out = cl + bias + residual (sc1 store)
+__device__ __forceinline__ void mg_epi_residual(const float* cl, const float* bias, const float* res, float* out, int64_t ld,
+                                                int rows, int tid) {
+    const int cc = tid % 12, r0 = tid / 12;
+    if (r0 >= 42) return;
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + 4 * cc);
+    float4 rr[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int row = r0 + 42 * it;
+        if (row < rows) rr[it] = *reinterpret_cast<const float4*>(res + (int64_t)row * ld + 4 * cc);
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int row = r0 + 42 * it;
+        if (row >= rows) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(cl + row * 52 + 4 * cc);
+        u32x4_t v;
+        v[0] = __float_as_uint(c0.x + b0.x + rr[it].x); v[1] = __float_as_uint(c0.y + b0.y + rr[it].y);
+        v[2] = __float_as_uint(c0.z + b0.z + rr[it].z); v[3] = __float_as_uint(c0.w + b0.w + rr[it].w);
+        st_sc1_16(out + (int64_t)row * ld + 4 * cc, v);
+    }
+}
+// BN = 192: 24 chunks of 8 columns x 21 rows per pass (504 threads), 6 passes; -> the chunk with bias added, as 8 bf16
+template <class F>
+__device__ __forceinline__ void mg_epi_bf16(const float* cl, const float* b0p, const float* b1p, int tid, F&& emit) {
+    const int cc = tid % 24, r0 = tid / 24;
+    if (r0 >= 21) return;
+    const float4 b0 = *reinterpret_cast<const float4*>(b0p), b1 = *reinterpret_cast<const float4*>(b1p);
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int row = r0 + 21 * it;
+        if (row >= MG_ROWS) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(cl + row * 196 + 8 * cc);
+        const float4 c1 = *reinterpret_cast<const float4*>(cl + row * 196 + 8 * cc + 4);
+        u32x4_t pk;
+        pk[0] = pack_bf16x2(c0.x + b0.x, c0.y + b0.y); pk[1] = pack_bf16x2(c0.z + b0.z, c0.w + b0.w);
+        pk[2] = pack_bf16x2(c1.x + b1.x, c1.y + b1.y); pk[3] = pack_bf16x2(c1.z + b1.z, c1.w + b1.w);
+        emit(row, pk);
+    }
+}
+
+// ---- attention of one (image, head) from LDS tiles [128][ATP] of q, k, v (rows = panel rows); wave w of the image's 4 waves
+// takes query rows 16w .. 16w+15.  Same arithmetic and rounding points as attn_fwd_small_kernel (csrc/attention.hip).
+__device__ __forceinline__ void mg_attention(const unsigned short* qt, const unsigned short* kt, const unsigned short* vt, int r0,
+                                             int T, int w, int lane, float scale, unsigned short* out, int64_t ldo) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const int q = w * 16 + r16, qq = q < T ? q : T - 1;
+    abf16x8_t qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(qt + (r0 + qq) * ATP + 32 * ks + 8 * g);
+    af32x4_t s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int key = 16 * j + r16, kk = key < T ? key : T - 1;
+        s[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(kt + (r0 + kk) * ATP + 32 * ks + 8 * g), qf[ks], s[j], 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * j + 4 * g + e;
+            s[j][e] = key < T ? s[j][e] * scale : -INFINITY;
+            mx = fmaxf(mx, s[j][e]);
+        }
+    mx = xor_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * j + 4 * g + e;
+            s[j][e] = key < T ? __expf(s[j][e] - mx) : 0.f;
+            sum += s[j][e];
+        }
+    const float inv = 1.0f / xor_sum(sum);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[j][e] = bf2f(f2bf(s[j][e] * inv));
+    const abf16x8_t pf[2] = {acc_frag(s, 0), acc_frag(s, 1)};
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc) {
+        af32x4_t o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(vt + r0 * ATP, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), pf[ks], o, 0, 0, 0);
+        if (q < T) st_sc1_8(out + (int64_t)q * ldo + 16 * jc + 4 * g, pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+    }
+}
+
+#define MG_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 64 + ((i) & 63)] = mg_clock();  \
+    } while (0)
+
+__global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[MG_LDS];
+    unsigned char* scratch = smem + MG_LDS - 1024;   // landing place of the L2-prefetch touches (never read)
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    // team <-> XCD affinity (speed only): blocks b, b + 8, ... share an XCD under round-robin placement
+    int team, member;
+    if (p.nteams % 8 == 0) {
+        const int q = p.nteams / 8, s = b >> 3;
+        team = (b & 7) * q + s / MG_TEAM;
+        member = s % MG_TEAM;
+    } else {
+        team = b / MG_TEAM;
+        member = b % MG_TEAM;
+    }
+    const int d = p.d, T = p.T, mlp = p.mlp;
+    const int64_t M = p.M, Mp = p.Mp;
+    const float scale = 1.0f / sqrtf(64.0f);
+    unsigned seq = 0;
+    int stamp = 0;
+    MG_STAMP(stamp++);
+    const MegaTouch none{nullptr, 0, 0, 0, -1, 0, 0};
+#define MG_SYNC(touch_, k_)                                                                                           \
+    team_sync(p, team, ++seq * MG_TEAM, touch_, scratch,                                                              \
+              (p.trace && l == 0 && panel == team) ? p.trace + (size_t)blockIdx.x * 64 + 8 + 4 * (k_) : nullptr);     \
+    if (l == 0) MG_STAMP(stamp++)
+#define MG_GEMM_DONE(k_)                                                                                             \
+    if (p.trace && l == 0 && panel == team && tid == 0) p.trace[(size_t)blockIdx.x * 64 + 32 + (k_)] = mg_clock()
+    for (int panel = team; panel < p.npanels; panel += p.nteams) {
+        const int img0 = panel * p.P;
+        const int nimg = (p.B - img0) < p.P ? (p.B - img0) : p.P;
+        const int row0 = img0 * T, rows = nimg * T;
+        for (int l = 0; l < p.L; ++l) {
+            const int64_t po = (int64_t)l * p.layer_stride;
+            const int64_t li = p.save ? l : 0;
+            const float* xin = p.xs + (p.save ? (int64_t)l : (int64_t)(l & 1)) * M * d;
+            float* xout = p.xs + (p.save ? (int64_t)(l + 1) : (int64_t)((l + 1) & 1)) * M * d;
+            float* x1 = p.x1 + li * M * d;
+            unsigned short* h1 = p.h1 + li * Mp * d;
+            unsigned short* h2 = p.h2 + li * Mp * d;
+            unsigned short* at = p.a + li * Mp * d;
+            unsigned short* qkv = p.qkv + li * M * 3 * d;
+            unsigned short* f = p.f + li * M * mlp;
+            unsigned short* ga = p.gact + li * Mp * mlp;
+            const unsigned short* Wqkv = p.shadow + po + p.lo[QKVW];
+            const unsigned short* Wout = p.shadow + po + p.lo[OUTW];
+            const unsigned short* Wfc = p.shadow + po + p.lo[FCW];
+            const unsigned short* Wpr = p.shadow + po + p.lo[PRW];
+            // weight slices of this layer's four products (and the next in_proj) as prefetch descriptors
+            const MegaTouch tQ{member < p.H ? Wqkv : nullptr, d, 192, 0, member, d, d >> 6};
+            const MegaTouch tO{Wout, d, 48, 48 * member, -1, d, d >> 6};
+            const MegaTouch tF{Wfc, d, 192, 192 * member, -1, d, d >> 6};
+            const MegaTouch tP{Wpr, mlp, 48, 48 * member, -1, d, mlp >> 6};
+            const bool more = l + 1 < p.L || panel + p.nteams < p.npanels;
+            const MegaTouch tQn{(more && member < p.H) ? p.shadow + (l + 1 < p.L ? po + p.layer_stride : 0) + p.lo[QKVW] : nullptr,
+                                d, 192, 0, member, d, d >> 6};
+            // ---------------- LN1 ----------------
+            mg_layernorm(p, xin, p.params + po + p.lo[LN1W], p.params + po + p.lo[LN1B], h1, p.mean1 + li * M, p.rstd1 + li * M,
+                         row0, rows, member);
+            MG_SYNC((l == 0 && panel == team) ? (MegaTouch{tQ.W, d, 192, 0, member, d, MG_TOUCH_AHEAD}) : none, 0);
+            // ---------------- QKV + attention (member = head) ----------------
+            if (member < p.H) {
+                const int h = member;
+                mg_gemm_nt<192, 4, 4>(smem, h1 + (int64_t)row0 * d, d, rows, Wqkv, d,
+                                      [&](int n) { return (n >> 6) * d + 64 * h + (n & 63); }, d, tQ, tO, scratch);
+                const float* cl = reinterpret_cast<const float*>(smem);
+                MG_GEMM_DONE(0);
+                unsigned short* tiles = reinterpret_cast<unsigned short*>(smem + MG_ROWS * 196 * 4);  // q | k | v : [128][ATP] each
+                {
+                    const int cc = tid % 24, part = cc >> 3, c64 = (cc & 7) * 8;
+                    const float* bp = p.params + po + p.lo[QKVB] + part * d + 64 * h + c64;
+                    unsigned short* gq = qkv + (int64_t)row0 * 3 * d + part * d + 64 * h + c64;
+                    unsigned short* tq = tiles + part * 128 * ATP + c64;
+                    mg_epi_bf16(cl, bp, bp + 4, tid, [&](int row, u32x4_t pk) {
+                        *reinterpret_cast<u32x4_t*>(tq + row * ATP) = pk;
+                        if (row < rows) *reinterpret_cast<u32x4_t*>(gq + (int64_t)row * 3 * d) = pk;   // backward re-reads it (a later launch)
+                    });
+                }
+                // v rows 112..127 are read (times P = 0) by the last image's key fragments: they must be finite
+                for (int c = tid; c < 16 * ATP / 8; c += MG_THREADS)
+                    *reinterpret_cast<u32x4_t*>(tiles + 2 * 128 * ATP + MG_ROWS * ATP + c * 8) = (u32x4_t){0u, 0u, 0u, 0u};
+                __syncthreads();
+                const int wave = tid >> 6, lane = tid & 63;
+                for (int im = wave >> 2; im < nimg; im += 2)   // waves 0-3: images 0, 2, ..; waves 4-7: images 1, 3, ..
+                    mg_attention(tiles, tiles + 128 * ATP, tiles + 2 * 128 * ATP, im * T, T, wave & 3, lane, scale,
+                                 at + (int64_t)(row0 + im * T) * d + 64 * h, d);
+            } else if (tid < 64) {   // members without a head: only the first k-steps of their out_proj slice, into L2
+                for (int ks = 0; ks < MG_TOUCH_AHEAD; ++ks) mg_touch_step(tO, ks, scratch, 0, tid);
+            }
+            MG_SYNC(none, 1);
+            // ---------------- out_proj + bias + residual -> x1 ----------------
+            {
+                const int n0 = 48 * member;
+                mg_gemm_nt<48, 3, 6>(smem, at + (int64_t)row0 * d, d, rows, Wout, d, [&](int n) { return n0 + n; }, d, tO, tF, scratch);
+                MG_GEMM_DONE(1);
+                mg_epi_residual(reinterpret_cast<const float*>(smem), p.params + po + p.lo[OUTB] + n0, xin + (int64_t)row0 * d + n0,
+                                x1 + (int64_t)row0 * d + n0, d, rows, tid);
+            }
+            MG_SYNC(none, 2);
+            // ---------------- LN2 ----------------
+            mg_layernorm(p, x1, p.params + po + p.lo[LN2W], p.params + po + p.lo[LN2B], h2, p.mean2 + li * M, p.rstd2 + li * M,
+                         row0, rows, member);
+            MG_SYNC(none, 3);
+            // ---------------- c_fc + bias, activation -> f, g ----------------
+            {
+                const int n0 = 192 * member;
+                mg_gemm_nt<192, 4, 4>(smem, h2 + (int64_t)row0 * d, d, rows, Wfc, d, [&](int n) { return n0 + n; }, d, tF, tP, scratch);
+                MG_GEMM_DONE(2);
+                const int cc = tid % 24;
+                const float* bp = p.params + po + p.lo[FCB] + n0 + 8 * cc;
+                unsigned short* fo = f + (int64_t)row0 * mlp + n0 + 8 * cc;
+                unsigned short* go = ga + (int64_t)row0 * mlp + n0 + 8 * cc;
+                auto epi = [&](auto ACT) {
+                    constexpr int act = decltype(ACT)::value;
+                    mg_epi_bf16(reinterpret_cast<const float*>(smem), bp, bp + 4, tid, [&](int row, u32x4_t pk) {
+                        if (row >= rows) return;
+                        *reinterpret_cast<u32x4_t*>(fo + (int64_t)row * mlp) = pk;   // pre-activation: only the backward reads it
+                        u32x4_t pk2;
+#pragma unroll
+                        for (int hh = 0; hh < 4; ++hh)
+                            pk2[hh] = pack_bf16x2(act_fwd(__uint_as_float(pk[hh] << 16), act), act_fwd(__uint_as_float(pk[hh] & 0xffff0000u), act));
+                        st_sc1_16(go + (int64_t)row * mlp, pk2);
+                    });
+                };
+                if (p.act == 1) epi(std::integral_constant<int, 1>{});
+                else if (p.act == 2) epi(std::integral_constant<int, 2>{});
+                else epi(std::integral_constant<int, 0>{});
+            }
+            MG_SYNC(none, 4);
+            // ---------------- c_proj + bias + residual -> next block's input ----------------
+            {
+                const int n0 = 48 * member;
+                mg_gemm_nt<48, 3, 6>(smem, ga + (int64_t)row0 * mlp, mlp, rows, Wpr, mlp, [&](int n) { return n0 + n; }, mlp, tP, tQn, scratch);
+                MG_GEMM_DONE(3);
+                mg_epi_residual(reinterpret_cast<const float*>(smem), p.params + po + p.lo[PRB] + n0, x1 + (int64_t)row0 * d + n0,
+                                xout + (int64_t)row0 * d + n0, d, rows, tid);
+            }
+            MG_SYNC(none, 5);
+        }
+    }
+#undef MG_SYNC
+#undef MG_GEMM_DONE
+    MG_STAMP(stamp++);
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+static unsigned* g_mega_state = nullptr;   // [16 teams x 32 words | status 32 words] = 2176 B, zeroed before every launch
+static int g_mega_mode = 1;                // swat_vit_set_mega: 0 = op-by-op forward, 1 = persistent forward when eligible
+static unsigned long long* g_mega_trace = nullptr;
+
+// -> 0: launched; 1: not eligible (the caller runs the blocks op by op); < 0: error
+int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int save, int M, int Mp, const float* params,
+                     const unsigned short* shadow, const int64_t* layer_offs, float* xs, float* x1, unsigned short* h1,
+                     unsigned short* h2, unsigned short* a, unsigned short* qkv, unsigned short* f, unsigned short* gact, float* mean1,
+                     float* rstd1, float* mean2, float* rstd2, hipStream_t s) {
+    // one panel = 2 images (attention reads 64 key rows from the second image's first row: 2 T + 14 <= 128 tile rows)
+    if (g_mega_mode == 0 || d != 768 || mlp != 3072 || H != 12 || d / H != 64 || T < 38 || T > 56 || B < 1 || L < 1) return 1;
+    const int64_t stride = L > 1 ? layer_offs[12] - layer_offs[0] : 0;
+    for (int l = 1; l < L; ++l)
+        for (int k = 0; k < 12; ++k)
+            if (layer_offs[12 * l + k] - layer_offs[k] != (int64_t)l * stride) return 1;  // blocks are not laid out at a constant stride
+    for (int k = 0; k < 12; ++k)
+        if (layer_offs[k] % 8) return 1;  // 16-B rows of the bf16 shadow
+    if (stride % 8) return 1;
+    if (!g_mega_state) {
+        if (hipMalloc((void**)&g_mega_state, 17 * 128) != hipSuccess) {
+            set_error("vit_mega: hipMalloc of the hand-off state failed");
+            return -1;
+        }
+    }
+    MegaFwd m{};
+    m.B = B; m.T = T; m.d = d; m.H = H; m.mlp = mlp; m.L = L; m.act = act; m.save = save; m.M = M; m.Mp = Mp;
+    m.eps = 1e-5f;
+    m.params = params; m.shadow = shadow;
+    for (int k = 0; k < 12; ++k) m.lo[k] = layer_offs[k];
+    m.layer_stride = stride;
+    m.xs = xs; m.x1 = x1; m.h1 = h1; m.h2 = h2; m.a = a; m.qkv = qkv; m.f = f; m.gact = gact;
+    m.mean1 = mean1; m.rstd1 = rstd1; m.mean2 = mean2; m.rstd2 = rstd2;
+    m.P = 2;
+    m.npanels = (B + m.P - 1) / m.P;
+    m.nteams = m.npanels < 16 ? m.npanels : 16;
+    m.ctr = g_mega_state;
+    m.status = g_mega_state + 16 * 32;
+    m.trace = g_mega_trace;
+    SWAT_HIP(hipMemsetAsync(g_mega_state, 0, 17 * 128, s));
+    hipLaunchKernelGGL(vit_fwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, m);
+    return check_launch("vit_fwd_mega_kernel");
+}
+
+}  // namespace swat
+using namespace swat;
+
+SWAT_API int swat_vit_set_mega(int mode) {
+    SWAT_REQUIRE(mode == 0 || mode == 1, "swat_vit_set_mega: mode must be 0 or 1");
+    g_mega_mode = mode;
+    return 0;
+}
+
+// status word of the last persistent forward (synchronises the device): 0 = every hand-off completed
+SWAT_API int swat_vit_mega_status(void) {
+    if (!g_mega_state) return 0;
+    unsigned v = 0;
+    SWAT_HIP(hipDeviceSynchronize());
+    SWAT_HIP(hipMemcpy(&v, g_mega_state + 16 * 32, 4, hipMemcpyDeviceToHost));
+    return (int)(v & 0x7fffffffu) | (v ? 0x40000000 : 0);
+}
+
+// tuning: per-workgroup phase stamps (64 x uint64 per workgroup, 100 MHz ticks) of the next persistent forwards; null = off
+SWAT_API int swat_vit_mega_trace(void* device_buffer) {
+    g_mega_trace = (unsigned long long*)device_buffer;
+    return 0;
+}

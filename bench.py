@@ -615,7 +615,9 @@ def main():
                "config": {"workload": "ViT-B/32 (open_clip ViT-B-32-quickgelu, random init) --method cutmix finetune step, "
                                       "200 classes, AdamW 3 LR groups, fp32 master + bf16 MFMA", "per_gpu_batch": a.bsz,
                           "global_batch": a.bsz * world, "image": "3x224x224 fp32 resident in HBM",
-                          "parallelism": f"dp{world}" if world > 1 else "single"},
+                          "parallelism": f"dp{world}" if world > 1 else "single",
+                          "gradient_wire": os.environ.get("SWAT_DP_WIRE", "fp32") if world > 1 else None,
+                          "gradient_collective": os.environ.get("SWAT_DP_COLLECTIVE", "all_reduce") if world > 1 else None},
                "final_loss": round(loss, 4),
                "step_mfma_frac": round(GFLOP_PER_IMG_STEP * 1e9 * a.bsz / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
     # the instrumented replay runs on every rank (its steps contain the gradient all-reduces); rank 0 reports its own

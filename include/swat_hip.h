@@ -210,6 +210,8 @@ int swat_linear_wgrad_bias_group(int n, const void* const* dY_bf16, const void* 
 int swat_gather_cast_bf16(const float* in, void* out_bf16, int64_t rows, int d, int64_t group_rows,
                           int64_t group_stride_rows, int64_t row_off, swat_stream_t stream);
 int swat_cast_bf16(const float* in, void* out_bf16, int64_t n, swat_stream_t stream);
+/*     bf16 -> fp32 (the receiving side of the data-parallel step's optional bf16 gradient wire) */
+int swat_widen_bf16(const void* in_bf16, float* out, int64_t n, swat_stream_t stream);
 
 /* A7  fused multi-group AdamW over one flat fp32 buffer (torch.optim.AdamW semantics, ref
  *     utils/optimizers.py:131-146) + refresh of the bf16 shadow weights.  seg_begin: HOST array of

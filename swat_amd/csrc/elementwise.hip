@@ -465,6 +465,14 @@ __global__ void cast_bf16_kernel(const float* __restrict__ in, unsigned short* _
     }
 }
 
+__global__ void widen_bf16_kernel(const unsigned short* __restrict__ in, float* __restrict__ out, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const ushort4 v = reinterpret_cast<const ushort4*>(in)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(bf2f(v.x), bf2f(v.y), bf2f(v.z), bf2f(v.w));
+    }
+}
+
 static inline int grid_for(int64_t work, int per_block) {
     int64_t b = (work + per_block - 1) / per_block;
     if (b > 4096) b = 4096;
@@ -663,4 +671,12 @@ SWAT_API int swat_cast_bf16(const float* in, void* out_bf16, int64_t n, swat_str
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)s, in,
                        (unsigned short*)out_bf16, n);
     return check_launch("swat_cast_bf16");
+}
+
+SWAT_API int swat_widen_bf16(const void* in_bf16, float* out, int64_t n, swat_stream_t s) {
+    SWAT_REQUIRE(n % 4 == 0, "swat_widen_bf16: n must be a multiple of 4");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(widen_bf16_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)s, (const unsigned short*)in_bf16,
+                       out, n);
+    return check_launch("swat_widen_bf16");
 }

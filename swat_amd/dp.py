@@ -47,6 +47,12 @@ def init_from_env(args, split_batch=True):
     if split_batch and not getattr(args, 'dp_weak', False) and getattr(args, 'bsz', world) % world:
         raise ValueError(f"--bsz {args.bsz} is split over {world} ranks: it must be a multiple of the world size "
                          "(or use --dp_weak for --bsz rows per rank)")
+    per = getattr(args, 'bsz', 0) // world
+    if split_batch and not getattr(args, 'dp_weak', False) and 0 < per < 16 and rank == 0:
+        import warnings
+        warnings.warn(f"--bsz {args.bsz} over {world} ranks leaves {per} images per GPU and step (every rank still loads and "
+                      f"decodes the whole batch to keep the single-process trajectory): this mode reproduces a 1-GPU run, it does "
+                      f"not speed it up.  Use --dp_weak (every rank loads its own --bsz images, global batch {world} x {args.bsz}) to scale.")
     return args
 
 

@@ -160,6 +160,13 @@ def cast_bf16(x, out=None):
     return out
 
 
+def widen_bf16(x, out):
+    """bf16 -> fp32 into `out` (same number of elements, a multiple of 4)."""
+    rc = _lib.lib().swat_widen_bf16(_p(x), _p(out), x.numel(), _lib.stream())
+    _chk(rc, "swat_widen_bf16")
+    return out
+
+
 def l2norm_fwd(x):
     rows, d = x.shape
     y = torch.empty_like(x)

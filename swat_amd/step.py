@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .ddp import SliceReducer
+from .ddp import GradWire, SliceReducer
 
 
 class FusedTrainStep:
@@ -60,6 +60,12 @@ class FusedTrainStep:
             # process-wide streams owned by the library (created once, together with the weight-gradient lane)
             self._comm_stream = torch.cuda.ExternalStream(_lib.lib().swat_vit_aux_stream(0), device=dev)  # all-reduces
             self._opt_stream = torch.cuda.ExternalStream(_lib.lib().swat_vit_aux_stream(1), device=dev)   # AdamW slices at N > 1
+
+    def _wire(self):
+        w = getattr(self, "_grad_wire", None)
+        if w is None:
+            w = self._grad_wire = GradWire(self.arena.numel, self.arena.flat.device)
+        return w
 
     def _head_ws(self, B, dev):
         ws = self._ws.get(B)
@@ -173,7 +179,7 @@ class FusedTrainStep:
             assert sum(p[1] - p[0] for p in pend) == hi - lo, "bucket is not one contiguous arena range"
             lib.swat_vit_lane_order(ready_h)  # `comm` follows everything the bucket's stages ran on either stream
             with torch.cuda.stream(comm):
-                dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
+                self._wire().reduce(g, lo, hi)  # all_reduce | reduce_scatter + all_gather, fp32 | bf16 on the links (ddp.GradWire)
             side.wait_stream(comm)
             vis = [p for p in pend if p[2] is None]
             if vis:  # the tower's stages of the bucket: one AdamW launch over their joint range (one LR group)

@@ -62,6 +62,29 @@ def _worker(rank, world, port, q):
         for lo_, hi_ in [(0, 64), (128, 512), (960, 1000)]:
             want[lo_:hi_] = torch.arange(lo_, hi_, dtype=torch.float32) * tot
         assert torch.equal(flat, want)
+
+        # ---- how a gradient range crosses the links (ddp.GradWire): all_reduce | reduce_scatter + all_gather, fp32 | bf16 ----
+        from swat_amd.ddp import GradWire
+        g0 = torch.Generator().manual_seed(100 + rank)
+        base = torch.randn(4096, generator=g0) * 1e-3
+        both = [torch.randn(4096, generator=torch.Generator().manual_seed(100 + r)) * 1e-3 for r in range(world)]
+        exact = sum(both)
+        for wire in ("fp32", "bf16"):
+            for coll in ("all_reduce", "rs_ag"):
+                gw = GradWire(4096, torch.device("cpu"), wire=wire, collective=coll)
+                buf = base.clone()
+                gw.reduce(buf, 64, 4032)                      # a 64-aligned range: divisible by the world size -> rs_ag really runs
+                assert torch.equal(buf[:64], base[:64]) and torch.equal(buf[4032:], base[4032:])
+                got, want_r = buf[64:4032], exact[64:4032]
+                if wire == "fp32":
+                    assert torch.equal(got, want_r), (wire, coll)
+                else:
+                    # bf16 wire: every addend rounded to 8 significant bits (unit roundoff 2^-8) and every partial sum
+                    # rounded again: |err| <= (1 + log2(world)) * 2^-8 * sum_r |g_r| per element — the bound the
+                    # data-parallel step's bf16 option is held to (world 2: 2^-7)
+                    bound = 2.0 ** -7 * sum(b.abs() for b in both)[64:4032] + 1e-12
+                    assert bool(((got - want_r).abs() <= bound).all()), (wire, coll)
+                    assert not torch.equal(got, want_r)       # it did go through bf16
         q.put((rank, "ok"))
     except Exception as e:  # noqa
         import traceback

@@ -12,19 +12,22 @@ extern "C" {
 #endif
 
 /* Time every GEMM launch with start / stop hipEvents attached to the kernel's own dispatch packet (kernel execution
- *     time, as rocprofv3 reports it).  end() synchronises and fills 9 slots indexed layout * 3 + {0: 64-row tile,
- *     1: 128-row tile, 2: producer / consumer kernel} with total milliseconds, launch counts and 2*M*N*K*batch flops;
- *     returns the launches seen. */
+ *     time, as rocprofv3 reports it).  end() synchronises and fills 12 slots — layout * 3 + {0: 64-row tile,
+ *     1: 128- / 256-row tile, 2: producer / consumer kernel} for NT / NN / TN, 9: the persistent forward (csrc/vit_mega.hip:
+ *     all blocks in one launch), 10-11: unused — with total milliseconds, launch counts and flops; returns the launches
+ *     seen.  The three arrays hold 12 entries. */
 int swat_gemm_prof_begin(int max_launches);
 int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind);
 /* Pin one tile configuration (-1 = automatic) — tests and tuning.  14-19, 25-28, 43: LDS-DMA ring (64x64 / 128x128 /
  *     128x64 tiles, 2-8 stages, 4 or 8 waves); 30-34: register ring on whole k-steps; 20-24: register ring with K tails
  *     and batch strides (the fallback of every other number); 50-65: producer / consumer kernel (csrc/gemm_pc.hip:
- *     128x128, 160x128, 96x64, 96x96, 128x64, 64x64 tiles, loader-wave and ring-depth variants). */
+ *     128x128, 160x128, 96x64, 96x96, 128x64, 64x64 tiles, loader-wave and ring-depth variants); 80: 256 x 256, NT / NN
+ *     (csrc/gemm_big.hip). */
 int swat_gemm_set_tile(int cfg);
 /* Ablation bits (results WRONG): 1 no operand loads after the prologue, 2 no LDS reads / MFMA, 4 no epilogue, 8 no
  *     k-order skew, 16 per-workgroup time stamps into the trace buffer, 32 per-wave epilogue instead of the LDS-staged
- *     one, 64 loader waves read into registers instead of LDS-DMA, 512 never pick the producer / consumer kernel. */
+ *     one, 64 loader waves read into registers instead of LDS-DMA, 512 never pick the producer / consumer kernel, 1024 never
+ *     pick the 256 x 256 tile. */
 int swat_gemm_set_exp(int bits);
 int swat_gemm_set_trace(void* dev_buf); /* exp bit 16: 4 (LDS-DMA kernel) or 8 (producer / consumer) uint64 per workgroup */
 int swat_gemm_set_swizzle(int mode);    /* 0 = plain 2-D grid, -1 = XCD-aware tile order (default) */

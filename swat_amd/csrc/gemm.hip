@@ -736,6 +736,15 @@ static int pick_cfg_base(int layout, const GemmArgs& a, int batch) {
     // thousands of rows (ViT-B/16: 6 304, ViT-L/14: 8 224 at B = 32) fill several rounds with any tile: there the
     // 128-wide tiles' lower operand traffic wins the deep-K products (register ring 128x128 / 128x64) and the wgrads
     const bool many_rows = (layout == L_TN ? a.K : a.M) >= 4096;
+    // forward / data-gradient products with thousands of rows: the 256 x 256 tile (gemm_big.hip) runs its main loop matrix-core
+    // bound (~50 % of the MFMA peak per CU), but a product is only 1.5-3 rounds of such tiles, so tile quantisation and the
+    // 64 K-element epilogue per workgroup eat most of it.  Measured per launch (tools/perf_gemm_big.py, M = 8 224, d = 1 024):
+    // in_proj 73 vs 77 us, c_proj 110 vs 114, c_fc dgrad 99 vs 102, in_proj dgrad 77 vs 81 — and out_proj 45 vs 37, c_fc
+    // 173 vs 135, c_proj dgrad 177 vs 150; at M = 6 304 (33 x 25 tiles -> worse rounds) it loses everywhere.  So: deep
+    // reductions (K >= 2 048) and the in_proj shape at >= 8 192 rows only.
+    if (many_rows && layout != L_TN && !(g_exp & 1024) && a.M >= 8192 && a.N >= 1024 && a.N % 256 == 0 && a.inner == 1 && a.lda % 8 == 0 &&
+        a.ldb % 8 == 0 && !a.C2 && !a.actin && (a.K >= 2048 || (a.K >= 1024 && a.N == 3 * a.K)))
+        return 80;
     if (layout == L_NT) {
         if (a.N >= 2048 && a.K <= 1024 && a.M >= 128) return 43;
         return many_rows && a.K >= 2048 ? 50 : 14;  // (50 = producer / consumer 128 x 128, several rounds: ViT-L/14 step 34.3 ->
@@ -763,6 +772,17 @@ struct GemmProf {
 };
 static GemmProf g_prof;
 
+// other kernel files time their launches with the same facility: -> true and the start / stop events of the next slot
+bool gemm_prof_take(int kind, double flops, hipEvent_t& ev0, hipEvent_t& ev1) {
+    if (!(g_prof.on && g_prof.n < g_prof.cap)) return false;
+    ev0 = g_prof.ev[2 * g_prof.n];
+    ev1 = g_prof.ev[2 * g_prof.n + 1];
+    g_prof.kind[g_prof.n] = kind;
+    g_prof.flops[g_prof.n] = flops;
+    ++g_prof.n;
+    return true;
+}
+
 int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     int tile = pick_cfg(layout, a, batch);
     if (tile >= 50 && (batch > 4 || a.K % 64 != 0)) tile = (a.K % 64 == 0) ? 14 : 20;  // the producer / consumer kernel: whole k-steps, <= 4 planes
@@ -776,14 +796,16 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     // kernel's execution time as rocprofv3 reports it, without the ~2-3 us each separately recorded event adds
     hipEvent_t ev0 = prof ? g_prof.ev[2 * g_prof.n] : nullptr, ev1 = prof ? g_prof.ev[2 * g_prof.n + 1] : nullptr;
     int rc;
-    if (tile >= 70 && tile <= 72 && batch == 1 && a.inner == 1) rc = launch_gemm_pc_group(layout, &a, 1, s, ev0, ev1, tile);  // persistent tile loop
+    if (tile == 80 && (layout == L_TN || batch != 1 || a.inner != 1 || a.K % 64 != 0 || a.K < 128 || a.lda % 8 || a.ldb % 8)) tile = layout == L_TN ? 50 : 14;
+    if (tile == 80) rc = launch_gemm_big(layout, a, s, ev0, ev1);  // 256 x 256, matrix-core bound (gemm_big.hip)
+    else if (tile >= 70 && tile <= 72 && batch == 1 && a.inner == 1) rc = launch_gemm_pc_group(layout, &a, 1, s, ev0, ev1, tile);  // persistent tile loop
     else if (tile >= 70) { set_error("gemm: persistent configuration %d needs one unbatched product", tile); rc = -1; }
     else if (tile >= 50) rc = launch_gemm_pc(layout, a, batch, tile, s, ev0, ev1);
     else if (layout == L_NT) rc = launch_gemm<L_NT>(a, batch, tile, s, ev0, ev1);
     else if (layout == L_NN) rc = launch_gemm<L_NN>(a, batch, tile, s, ev0, ev1);
     else rc = launch_gemm<L_TN>(a, batch, tile, s, ev0, ev1);
     if (prof) {
-        g_prof.kind[g_prof.n] = layout * 3 + (tile >= 50 ? 2 : 0) + (tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43);
+        g_prof.kind[g_prof.n] = layout * 3 + (tile >= 50 && tile != 80 ? 2 : 0) + (tile == 80) + (tile == 15 || tile == 16 || tile == 21 || tile == 22 || tile == 32 || tile == 33 || (tile >= 25 && tile <= 28) || tile == 43);
         g_prof.flops[g_prof.n] = 2.0 * a.M * a.N * a.K * batch;
         ++g_prof.n;
     }
@@ -856,12 +878,13 @@ SWAT_API int swat_gemm_prof_begin(int max_launches) {
     return 0;
 }
 
-// Stop, synchronise the events and report per kind (layout * 3 + {64-row tile, 128-row tile, producer / consumer}; 9 kinds):
-// total ms, launches, flops.
+// Stop, synchronise the events and report per kind — 12 entries: layout * 3 + {64-row tile, 128-row / 256-row tile, producer /
+// consumer} for NT / NN / TN, then 9 = the persistent forward (csrc/vit_mega.hip: all blocks' products, LayerNorms and
+// attention in one launch), 10-11 unused: total ms, launches, flops.
 SWAT_API int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind) {
     using swat::g_prof;
     g_prof.on = false;
-    for (int k = 0; k < 9; ++k) { ms_by_kind[k] = 0; count_by_kind[k] = 0; flops_by_kind[k] = 0; }
+    for (int k = 0; k < 12; ++k) { ms_by_kind[k] = 0; count_by_kind[k] = 0; flops_by_kind[k] = 0; }
     for (int i = 0; i < g_prof.n; ++i) {
         SWAT_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
         float ms = 0.f;

@@ -64,6 +64,59 @@ __device__ __forceinline__ bf16x8_t read_frag(const unsigned char* tile, int bas
     }
 }
 
+// ---- k-strided tile of R columns as power-of-two parts -----------------------------------------------------------
+__host__ __device__ __forceinline__ constexpr int stp_start(int R, int col) {  // first column of the part that holds column `col`
+    int s = 0;
+    while (R - s >= 128) {
+        if (col < s + 128) return s;
+        s += 128;
+    }
+    for (int w = 64; w >= 16; w >>= 1)
+        if (R - s >= w) {
+            if (col < s + w) return s;
+            s += w;
+        }
+    return s;
+}
+__host__ __device__ __forceinline__ constexpr int stp_width(int R, int col) {
+    int s = 0;
+    while (R - s >= 128) {
+        if (col < s + 128) return 128;
+        s += 128;
+    }
+    for (int w = 64; w >= 16; w >>= 1)
+        if (R - s >= w) {
+            if (col < s + w) return w;
+            s += w;
+        }
+    return 16;
+}
+__host__ __device__ __forceinline__ constexpr int stp_f(int w, int k) {  // 32-B group XOR of k-row k inside a part of width w
+    return w == 128 ? ((k & 3) | ((k >> 1) & 4)) : w == 64 ? (((k >> 1) & 1) | ((k >> 2) & 2)) : w == 32 ? ((k >> 3) & 1) : 0;
+}
+// byte offset of the 16-B chunk (k-row k, columns col .. col+7; col % 8 == 0) in the image of a [64][R] tile
+template <int R>
+__host__ __device__ __forceinline__ constexpr int stp_off(int k, int col) {
+    const int s = stp_start(R, col), w = stp_width(R, col);
+    const int c32 = (col - s) >> 4, e = (col >> 3) & 1;
+    const int unit = w == 16 ? (k ^ ((k >> 1) & 4)) : k * (w >> 4) + (c32 ^ stp_f(w, k));
+    return s * 128 + unit * 32 + e * 16;
+}
+// inverse: which (k, col) lives at byte offset `byte` (multiple of 16) of the image
+template <int R>
+__host__ __device__ __forceinline__ constexpr void stp_inv(int byte, int& k, int& col) {
+    const int s = stp_start(R, byte >> 7), w = stp_width(R, byte >> 7);  // part p covers bytes [128 s, 128 (s + w))
+    const int rel = byte - s * 128, unit = rel >> 5, e = (rel >> 4) & 1;
+    int c32 = 0;
+    if (w == 16) k = unit ^ ((unit >> 1) & 4);
+    else {
+        const int lg = w == 128 ? 3 : w == 64 ? 2 : 1;
+        k = unit >> lg;
+        c32 = (unit & ((1 << lg) - 1)) ^ stp_f(w, k);
+    }
+    col = s + 16 * c32 + 8 * e;
+}
+
 // ---- epilogue shared by both kernels: lane holds C[m][n..n+3], m = mbase + 16 i + (lane & 15), n = nbase + 16 j + 4 (lane >> 4)
 // bf16-output epilogue with 16-byte stores.  Two accumulator tiles that are neighbours in n trade halves with
 // v_permlane16_swap: afterwards lane (r16, g) holds row r16 of tile j + (g & 1), columns 8 * (g >> 1) .. + 7 — eight

@@ -39,6 +39,10 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s);
 dim3 plan_grid(GemmArgs& b, int bm, int bn, int batch);
 // producer / consumer kernel, tile configurations >= 50 (gemm_pc.hip); K % 64 == 0 (batch > 1: split-K planes)
 int launch_gemm_pc(int layout, const GemmArgs& a, int batch, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+// swat_gemm_prof_begin / _end: take the next timing slot for a launch of `kind` (see swat_gemm_prof_end) — gemm.hip
+bool gemm_prof_take(int kind, double flops, hipEvent_t& ev0, hipEvent_t& ev1);
+// 256 x 256 tile, NT / NN, one unbatched product, K % 64 == 0 (gemm_big.hip)
+int launch_gemm_big(int layout, const GemmArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 // up to 64 products of one layout in ONE persistent launch (gemm_pc.hip); every product: batch 1, K % 64 == 0, fp32 or
 // bf16 output with 16-B rows (what gemm_group_dispatch checks before it comes here)
 int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int cfg = 0);

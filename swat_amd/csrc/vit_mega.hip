@@ -30,6 +30,7 @@
 // (buffer_inv sc1), its wait, workgroup barrier, and only then the next phase's loads.  Counters are zeroed by a
 // hipMemsetAsync in front of every launch; every spin is bounded (give-up code in the status block).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include <utility>
 #include "gemm_device.hpp"
@@ -84,42 +85,26 @@ __device__ __forceinline__ void mg_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 
 __device__ __forceinline__ unsigned long long mg_clock() { return wall_clock64(); }  // 100 MHz
 
-// W-slice prefetch into the XCD's L2 (no register, no wait): one 4-byte LDS-DMA per 128-B line of the next phase's weight
-// slice, landing in a 256-B scratch behind the ring.  A weight slice is read by only two CUs of an XCD, so without this the
-// ring's DMAs run at HBM latency (~2 us per stage: 55 GB/s per CU measured); touched ahead, they hit L2.
-constexpr bool MG_TOUCH = false;   // measured: touching lines ahead costs the TA path as much as loading them
-struct MegaTouch {
-    const unsigned short* W;   // next phase's weight matrix (null: nothing to prefetch)
-    int ldw, nrows, row0, qkv_h, d, nk;   // tile row n -> W row (qkv_h >= 0: head-strided in_proj rows, else row0 + n)
+// ---- the weight slice of a GEMM phase: tile row n of the phase -> row of W ([N][K] row-major, K contiguous) -------------------
+struct MegaW {
+    const unsigned short* W;   // null: this member has no product in the phase
+    int ldw, nk;               // row stride (elements), 64-deep k-steps
+    int row0, qkv_h, d;        // qkv_h >= 0: in_proj rows of head qkv_h (n >> 6 selects q / k / v), else rows row0 + n
+    __device__ __forceinline__ int row(int n) const { return qkv_h >= 0 ? (n >> 6) * d + 64 * qkv_h + (n & 63) : row0 + n; }
 };
-__device__ __forceinline__ void mg_touch(const MegaTouch& t, unsigned char* scratch, int wave3, int lane) {
-    if (!MG_TOUCH || !t.W) return;
-    const int lines = t.nrows * t.nk;          // one line = 64 k of one W row
-    for (int i = wave3 * 64 + lane; i < (lines + 63) / 64 * 64; i += 3 * 64) {
-        const int ii = i < lines ? i : lines - 1;
-        const int ks = ii / t.nrows, n = ii % t.nrows;   // k-step major: the first k-steps arrive first
-        const int row = t.qkv_h >= 0 ? (n >> 6) * t.d + 64 * t.qkv_h + (n & 63) : t.row0 + n;
-        const unsigned short* src = t.W + (int64_t)row * t.ldw + 64 * ks;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)scratch, 4, 0, 0);
-    }
-}
 
-// the lines of ONE 64-deep k-step of a weight slice (nrows lines): consumer wave w touches rows 64 w .. 64 w + 63
-__device__ __forceinline__ void mg_touch_step(const MegaTouch& t, int ks, unsigned char* scratch, int wave, int lane) {
-    if (!MG_TOUCH || !t.W || ks >= t.nk || 64 * wave >= t.nrows) return;
-    int n = 64 * wave + lane;
-    n = n < t.nrows ? n : t.nrows - 1;
-    const int row = t.qkv_h >= 0 ? (n >> 6) * t.d + 64 * t.qkv_h + (n & 63) : t.row0 + n;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.W + (int64_t)row * t.ldw + 64 * ks),
-                                     (__attribute__((address_space(3))) void*)scratch, 4, 0, 0);
+__device__ __forceinline__ void mg_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
-constexpr int MG_TOUCH_AHEAD = 8;   // k-steps between a line's touch and its LDS-DMA (HBM latency + the ring's 3 stages)
 
 // team-wide hand-off: all members' phase outputs are complete and visible when this returns (see the file header).
-// While lane 0 waits for the team, waves 1-3 pull the next phase's weight slice into L2.
-__device__ __forceinline__ void team_sync(const MegaFwd& p, int team, unsigned target, const MegaTouch& touch, unsigned char* scratch,
-                                          unsigned long long* tr = nullptr) {
+// `early(lw)` runs on the four loader waves between the two workgroup barriers — while lane 0 waits for the team they already
+// stream the first stages of the NEXT phase's weight slice into the LDS ring (weights depend on no hand-off).  The second
+// barrier is a raw s_barrier: __syncthreads() would drain those LDS-DMAs (vmcnt(0)).
+template <class Early>
+__device__ __forceinline__ void team_sync(const MegaFwd& p, int team, unsigned target, Early&& early, unsigned long long* tr = nullptr) {
     if (tr && threadIdx.x == 0) tr[0] = mg_clock();   // stores issued
     mg_drain();          // every storing wave
     __syncthreads();
@@ -146,19 +131,15 @@ __device__ __forceinline__ void team_sync(const MegaFwd& p, int team, unsigned t
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (tr) tr[3] = mg_clock();                   // acquire complete
-    } else if (wave >= 1 && wave <= 3) {
-        mg_touch(touch, scratch, wave - 1, threadIdx.x & 63);
+    } else if (wave >= MG_NC) {
+        early(wave - MG_NC);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mg_barrier();
 }
 
 template <int N_>
 __device__ __forceinline__ void mg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
-__device__ __forceinline__ void mg_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 template <int IMM>
 __device__ __forceinline__ bf16x8_t mg_lds_b128(unsigned addr) {
     bf16x8_t v;
@@ -173,74 +154,117 @@ __device__ __forceinline__ void mg_static_for_impl(F&& f, std::integer_sequence<
 template <int N_, typename F>
 __device__ __forceinline__ void mg_static_for(F&& f) { mg_static_for_impl<N_>(f, std::make_integer_sequence<int, N_>{}); }
 
-// ---- one GEMM phase: C[112, BN] = A[rows, K] (row-major, lda) x W^T, W rows picked by wrow(n), both operands
+// dynamic s_waitcnt vmcnt(n) (n is wave uniform; the instruction wants an immediate)
+__device__ __forceinline__ void mg_wait_vmcnt_n(int n) {
+    switch (n) {
+#define MG_W(k_) case k_: asm volatile("s_waitcnt vmcnt(" #k_ ")" ::: "memory"); break;
+        MG_W(0) MG_W(1) MG_W(2) MG_W(3) MG_W(4) MG_W(5) MG_W(6) MG_W(7) MG_W(8) MG_W(9) MG_W(10) MG_W(11) MG_W(12) MG_W(13) MG_W(14) MG_W(15)
+        MG_W(16) MG_W(17) MG_W(18) MG_W(19) MG_W(20) MG_W(21) MG_W(22) MG_W(23) MG_W(24) MG_W(25) MG_W(26) MG_W(27) MG_W(28) MG_W(29) MG_W(30)
+        MG_W(31) MG_W(32) MG_W(33) MG_W(34) MG_W(35) MG_W(36) MG_W(37) MG_W(38) MG_W(39) MG_W(40)
+#undef MG_W
+        default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;   // more may fly than we need to allow: still correct
+    }
+}
+
+// ---- the loader waves' piece lists.  A stage of the ring = [A: 14 pieces of 8 rows x 128 B | W: BN / 8 pieces]; loader wave lw
+// moves A pieces lw, lw + 4, .. and W pieces lw, lw + 4, ..  (k-contiguous image of gemm_device.hpp: kc_off, swizzle applied
+// to the per-lane source address).
+template <int BN>
+struct MgPieces {
+    static constexpr int PA = MG_ROWS / 8, PB = BN / 8;
+    static constexpr int MAXA = (PA + MG_NL - 1) / MG_NL, MAXW = (PB + MG_NL - 1) / MG_NL;
+    static constexpr int A_BYTES = PA * 1024, STAGE = (PA + PB) * 1024;
+    __device__ static __forceinline__ int na(int lw) { return (PA - lw + MG_NL - 1) / MG_NL; }
+    __device__ static __forceinline__ int nw(int lw) { return (PB - lw + MG_NL - 1) / MG_NL; }
+};
+
+// W pieces of stage `st` into ring buffer `buf` (their k offset added by the caller through `cur`)
+template <int BN>
+__device__ __forceinline__ void mg_issue_w(unsigned char* smem, int buf, const char* cur, const unsigned (&voff)[MgPieces<BN>::MAXW], int lw) {
+    using PC = MgPieces<BN>;
+#pragma unroll
+    for (int i = 0; i < PC::MAXW; ++i)
+        if (lw + MG_NL * i < PC::PB)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cur + voff[i]),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * PC::STAGE + PC::A_BYTES + (lw + MG_NL * i) * 1024),
+                                             16, 0, 0);
+}
+template <int BN>
+__device__ __forceinline__ void mg_w_offsets(const MegaW& w, int lw, int lane, unsigned (&voff)[MgPieces<BN>::MAXW]) {
+#pragma unroll
+    for (int i = 0; i < MgPieces<BN>::MAXW; ++i) {
+        const int byte = (lw + MG_NL * i) * 1024 + lane * 16;
+        const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
+        voff[i] = (unsigned)(w.row(row < BN ? row : BN - 1) * w.ldw + 8 * t) * 2u;
+    }
+}
+// the part of a GEMM phase that needs no hand-off: W of stages 0 .. NS-2 (run by the loader waves inside team_sync)
+template <int BN, int NS>
+__device__ __forceinline__ void mg_w_prologue(unsigned char* smem, const MegaW& w, int lw) {
+    if (!w.W) return;
+    unsigned voff[MgPieces<BN>::MAXW];
+    mg_w_offsets<BN>(w, lw, threadIdx.x & 63, voff);
+    const char* cur = reinterpret_cast<const char*>(w.W);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) mg_issue_w<BN>(smem, st, cur + 128 * st, voff, lw);
+}
+
+// ---- one GEMM phase: C[112, BN] = A[rows, K] (row-major, lda) x W^T, W rows given by w.row(n), both operands
 // k-contiguous.  Structure and LDS image of gemm_pc_kernel<L_NT> (one tile, FM = 7 row fragments for every consumer
-// wave, CN consumer waves side by side in n).  On return the fp32 tile sits in LDS at smem as [112][BN + 4] and the
-// workgroup has passed a barrier behind it.
-template <int BN, int CN, int NS, class WRow>
-__device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned short* A, int lda, int rows, const unsigned short* W,
-                                            int ldw, WRow wrow, int K, const MegaTouch& tcur, const MegaTouch& tnext, unsigned char* scratch) {
+// wave, CN consumer waves side by side in n); the W pieces of the first NS-1 stages were issued by mg_w_prologue before the
+// hand-off completed.  On return the fp32 tile sits in LDS at smem as [112][BN + 4] and the workgroup has passed a barrier
+// behind it.
+template <int BN, int CN, int NS>
+__device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned short* A, int lda, int rows, const MegaW& w) {
     constexpr int NL = MG_NL, NC = MG_NC;
     constexpr int FM = MG_FM, WN = BN / CN, FN = WN / 16;
     static_assert(BN % (16 * CN) == 0 && CN <= NC, "wave tiles are whole fragments");
-    constexpr int PA = MG_ROWS / 8, PB = BN / 8, P = PA + PB;
-    constexpr int A_BYTES = PA * 1024, STAGE = P * 1024;
-    constexpr int LPS = (P + NL - 1) / NL;
+    using PC = MgPieces<BN>;
+    constexpr int A_BYTES = PC::A_BYTES, STAGE = PC::STAGE;
     static_assert(NS >= 4 && NS * STAGE <= MG_LDS && MG_ROWS * (BN + 4) * 4 <= NS * STAGE, "LDS ring");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nk = K >> 6;
+    const int nk = w.nk;   // >= NS (d = 768: 12 or 48 k-steps)
 
     if (wave >= NC) {
         // ================================ loader waves ================================
         const int lw = wave - NC;
-        unsigned voff[LPS];
-        unsigned amask = 0, dmask = 0;
+        const int nA = PC::na(lw), nW = PC::nw(lw), per = nA + nW;   // pieces of this wave per stage
+        unsigned voffA[PC::MAXA], voffW[PC::MAXW];
 #pragma unroll
-        for (int i = 0; i < LPS; ++i) {
-            int q = lw + NL * i;
-            if (q >= P) { q -= NL; dmask |= 1u << i; }
-            const bool isA = q < PA;
-            if (isA) amask |= 1u << i;
-            const int byte = (isA ? q : q - PA) * 1024 + lane * 16;
+        for (int i = 0; i < PC::MAXA; ++i) {
+            const int byte = (lw + NL * i) * 1024 + lane * 16;
             const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
-            if (isA) {
-                const int gr = row < rows ? row : rows - 1;
-                voff[i] = (unsigned)(gr * lda + 8 * t) * 2u;
-            } else {
-                voff[i] = (unsigned)(wrow(row) * ldw + 8 * t) * 2u;
-            }
+            const int gr = row < rows ? row : rows - 1;
+            voffA[i] = (unsigned)(gr * lda + 8 * t) * 2u;
         }
+        mg_w_offsets<BN>(w, lw, lane, voffW);
         const char* curA = reinterpret_cast<const char*>(A);
-        const char* curB = reinterpret_cast<const char*>(W);
-        auto issue = [&](int buf) {
-            unsigned char* st = smem + buf * STAGE + lw * 1024;
+        const char* curW = reinterpret_cast<const char*>(w.W);
+        auto issue_a = [&](int buf, int st) {
 #pragma unroll
-            for (int i = 0; i < LPS; ++i) {
-                const char* src = ((amask >> i) & 1) ? curA : curB;
-                unsigned char* dst = st + (NL * i - (((dmask >> i) & 1) ? NL : 0)) * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + voff[i]),
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-            curA += 128; curB += 128;
+            for (int i = 0; i < PC::MAXA; ++i)
+                if (lw + NL * i < PC::PA)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(curA + 128 * st + voffA[i]),
+                                                     (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (lw + NL * i) * 1024), 16, 0, 0);
         };
+        // in flight, oldest first: W(0 .. NS-2) (issued inside the hand-off), now A(0 .. NS-2), then whole stages
 #pragma unroll
-        for (int s = 0; s < NS - 1; ++s)
-            if (s < nk) issue(s);
+        for (int st = 0; st < NS - 1; ++st) issue_a(st, st);
         int t = 0, buf = NS - 1;
         for (; t + NS - 1 < nk; ++t) {
-            mg_wait_vmcnt<(NS - 3) * LPS>();
+            // barrier t: stages <= t + 1 have landed.  Still allowed to fly: the A pieces of the prologue stages t + 2 .. NS-2
+            // and the t whole stages issued in this loop so far (at most NS-3 of them)
+            const int pro = NS - 3 - t;
+            mg_wait_vmcnt_n(pro > 0 ? pro * nA + t * per : (NS - 3) * per);
             mg_barrier();
-            issue(buf);
+            issue_a(buf, t + NS - 1);
+            mg_issue_w<BN>(smem, buf, curW + 128 * (t + NS - 1), voffW, lw);
             buf = buf + 1 == NS ? 0 : buf + 1;
         }
-        for (; t < nk; ++t) {
-            switch (nk - 2 - t) {
-                case 1: mg_wait_vmcnt<LPS>(); break;
-                case 2: mg_wait_vmcnt<(NS >= 5 ? 2 : 0) * LPS>(); break;
-                case 3: mg_wait_vmcnt<(NS >= 6 ? 3 : 0) * LPS>(); break;
-                default: mg_wait_vmcnt<0>(); break;
-            }
+        for (; t < nk; ++t) {   // tail: everything is issued; stages t + 2 .. nk - 1 may still fly
+            const int fly = nk - 2 - t;
+            mg_wait_vmcnt_n(fly > 0 ? (fly < NS - 3 ? fly : NS - 3) * per : 0);
             mg_barrier();
         }
     } else {
@@ -315,24 +339,12 @@ __device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned s
                 half(T1{}, fb[0], fb[1], so, 1);
                 half(T1{}, fb[1], fb[0], sn, 0);
                 mg_barrier();
-                // keep the weight stream MG_TOUCH_AHEAD k-steps ahead in L2; it runs on into the next GEMM phase's slice
-                if (t + MG_TOUCH_AHEAD < nk) mg_touch_step(tcur, t + MG_TOUCH_AHEAD, scratch, wave, lane);
-                else mg_touch_step(tnext, t + MG_TOUCH_AHEAD - nk, scratch, wave, lane);
                 so = sn;
             }
             half(T1{}, fb[0], fb[1], so, 1);
             half(T0{}, fb[1], fb[0], 0u, 0);
-            mg_touch_step(tnext, MG_TOUCH_AHEAD - 1, scratch, wave, lane);
         } else {
-            for (int t = 0; t < nk; ++t) {
-                mg_barrier();
-                if (t + 1 < nk) {
-                    if (t + MG_TOUCH_AHEAD < nk) mg_touch_step(tcur, t + MG_TOUCH_AHEAD, scratch, wave, lane);
-                    else mg_touch_step(tnext, t + MG_TOUCH_AHEAD - nk, scratch, wave, lane);
-                } else {
-                    mg_touch_step(tnext, MG_TOUCH_AHEAD - 1, scratch, wave, lane);
-                }
-            }
+            for (int t = 0; t < nk; ++t) mg_barrier();
         }
         // accumulators -> LDS fp32 tile, behind a barrier: every consumer has finished reading the ring
         // (the loaders are past their last stage barrier: this extra barrier is matched below)
@@ -500,7 +512,6 @@ __device__ __forceinline__ void mg_attention(const unsigned short* qt, const uns
 
 __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[MG_LDS];
-    unsigned char* scratch = smem + MG_LDS - 1024;   // landing place of the L2-prefetch touches (never read)
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     // team <-> XCD affinity (speed only): blocks b, b + 8, ... share an XCD under round-robin placement
@@ -519,9 +530,13 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
     unsigned seq = 0;
     int stamp = 0;
     MG_STAMP(stamp++);
-    const MegaTouch none{nullptr, 0, 0, 0, -1, 0, 0};
-#define MG_SYNC(touch_, k_)                                                                                           \
-    team_sync(p, team, ++seq * MG_TEAM, touch_, scratch,                                                              \
+    // MG_SYNC(next_, BN_, NS_): hand-off; the loader waves meanwhile start the weight stream of the GEMM phase that follows it
+#define MG_SYNC(next_, BN_, NS_, k_)                                                                                  \
+    team_sync(p, team, ++seq * MG_TEAM, [&](int lw) { mg_w_prologue<BN_, NS_>(smem, next_, lw); },                     \
+              (p.trace && l == 0 && panel == team) ? p.trace + (size_t)blockIdx.x * 64 + 8 + 4 * (k_) : nullptr);     \
+    if (l == 0) MG_STAMP(stamp++)
+#define MG_SYNC0(k_)                                                                                                  \
+    team_sync(p, team, ++seq * MG_TEAM, [&](int) {},                                                                  \
               (p.trace && l == 0 && panel == team) ? p.trace + (size_t)blockIdx.x * 64 + 8 + 4 * (k_) : nullptr);     \
     if (l == 0) MG_STAMP(stamp++)
 #define MG_GEMM_DONE(k_)                                                                                             \
@@ -542,27 +557,19 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
             unsigned short* qkv = p.qkv + li * M * 3 * d;
             unsigned short* f = p.f + li * M * mlp;
             unsigned short* ga = p.gact + li * Mp * mlp;
-            const unsigned short* Wqkv = p.shadow + po + p.lo[QKVW];
-            const unsigned short* Wout = p.shadow + po + p.lo[OUTW];
-            const unsigned short* Wfc = p.shadow + po + p.lo[FCW];
-            const unsigned short* Wpr = p.shadow + po + p.lo[PRW];
-            // weight slices of this layer's four products (and the next in_proj) as prefetch descriptors
-            const MegaTouch tQ{member < p.H ? Wqkv : nullptr, d, 192, 0, member, d, d >> 6};
-            const MegaTouch tO{Wout, d, 48, 48 * member, -1, d, d >> 6};
-            const MegaTouch tF{Wfc, d, 192, 192 * member, -1, d, d >> 6};
-            const MegaTouch tP{Wpr, mlp, 48, 48 * member, -1, d, mlp >> 6};
-            const bool more = l + 1 < p.L || panel + p.nteams < p.npanels;
-            const MegaTouch tQn{(more && member < p.H) ? p.shadow + (l + 1 < p.L ? po + p.layer_stride : 0) + p.lo[QKVW] : nullptr,
-                                d, 192, 0, member, d, d >> 6};
+            // weight slices of this member in the layer's four products
+            const MegaW wQ{member < p.H ? p.shadow + po + p.lo[QKVW] : nullptr, d, d >> 6, 0, member, d};
+            const MegaW wO{p.shadow + po + p.lo[OUTW], d, d >> 6, 48 * member, -1, d};
+            const MegaW wF{p.shadow + po + p.lo[FCW], d, d >> 6, 192 * member, -1, d};
+            const MegaW wP{p.shadow + po + p.lo[PRW], mlp, mlp >> 6, 48 * member, -1, d};
             // ---------------- LN1 ----------------
             mg_layernorm(p, xin, p.params + po + p.lo[LN1W], p.params + po + p.lo[LN1B], h1, p.mean1 + li * M, p.rstd1 + li * M,
                          row0, rows, member);
-            MG_SYNC((l == 0 && panel == team) ? (MegaTouch{tQ.W, d, 192, 0, member, d, MG_TOUCH_AHEAD}) : none, 0);
+            MG_SYNC(wQ, 192, 4, 0);
             // ---------------- QKV + attention (member = head) ----------------
             if (member < p.H) {
                 const int h = member;
-                mg_gemm_nt<192, 4, 4>(smem, h1 + (int64_t)row0 * d, d, rows, Wqkv, d,
-                                      [&](int n) { return (n >> 6) * d + 64 * h + (n & 63); }, d, tQ, tO, scratch);
+                mg_gemm_nt<192, 4, 4>(smem, h1 + (int64_t)row0 * d, d, rows, wQ);
                 const float* cl = reinterpret_cast<const float*>(smem);
                 MG_GEMM_DONE(0);
                 unsigned short* tiles = reinterpret_cast<unsigned short*>(smem + MG_ROWS * 196 * 4);  // q | k | v : [128][ATP] each
@@ -584,27 +591,25 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
                 for (int im = wave >> 2; im < nimg; im += 2)   // waves 0-3: images 0, 2, ..; waves 4-7: images 1, 3, ..
                     mg_attention(tiles, tiles + 128 * ATP, tiles + 2 * 128 * ATP, im * T, T, wave & 3, lane, scale,
                                  at + (int64_t)(row0 + im * T) * d + 64 * h, d);
-            } else if (tid < 64) {   // members without a head: only the first k-steps of their out_proj slice, into L2
-                for (int ks = 0; ks < MG_TOUCH_AHEAD; ++ks) mg_touch_step(tO, ks, scratch, 0, tid);
             }
-            MG_SYNC(none, 1);
+            MG_SYNC(wO, 48, 6, 1);
             // ---------------- out_proj + bias + residual -> x1 ----------------
             {
                 const int n0 = 48 * member;
-                mg_gemm_nt<48, 3, 6>(smem, at + (int64_t)row0 * d, d, rows, Wout, d, [&](int n) { return n0 + n; }, d, tO, tF, scratch);
+                mg_gemm_nt<48, 3, 6>(smem, at + (int64_t)row0 * d, d, rows, wO);
                 MG_GEMM_DONE(1);
                 mg_epi_residual(reinterpret_cast<const float*>(smem), p.params + po + p.lo[OUTB] + n0, xin + (int64_t)row0 * d + n0,
                                 x1 + (int64_t)row0 * d + n0, d, rows, tid);
             }
-            MG_SYNC(none, 2);
+            MG_SYNC0(2);
             // ---------------- LN2 ----------------
             mg_layernorm(p, x1, p.params + po + p.lo[LN2W], p.params + po + p.lo[LN2B], h2, p.mean2 + li * M, p.rstd2 + li * M,
                          row0, rows, member);
-            MG_SYNC(none, 3);
+            MG_SYNC(wF, 192, 4, 3);
             // ---------------- c_fc + bias, activation -> f, g ----------------
             {
                 const int n0 = 192 * member;
-                mg_gemm_nt<192, 4, 4>(smem, h2 + (int64_t)row0 * d, d, rows, Wfc, d, [&](int n) { return n0 + n; }, d, tF, tP, scratch);
+                mg_gemm_nt<192, 4, 4>(smem, h2 + (int64_t)row0 * d, d, rows, wF);
                 MG_GEMM_DONE(2);
                 const int cc = tid % 24;
                 const float* bp = p.params + po + p.lo[FCB] + n0 + 8 * cc;
@@ -626,18 +631,19 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
                 else if (p.act == 2) epi(std::integral_constant<int, 2>{});
                 else epi(std::integral_constant<int, 0>{});
             }
-            MG_SYNC(none, 4);
+            MG_SYNC(wP, 48, 6, 4);
             // ---------------- c_proj + bias + residual -> next block's input ----------------
             {
                 const int n0 = 48 * member;
-                mg_gemm_nt<48, 3, 6>(smem, ga + (int64_t)row0 * mlp, mlp, rows, Wpr, mlp, [&](int n) { return n0 + n; }, mlp, tP, tQn, scratch);
+                mg_gemm_nt<48, 3, 6>(smem, ga + (int64_t)row0 * mlp, mlp, rows, wP);
                 MG_GEMM_DONE(3);
                 mg_epi_residual(reinterpret_cast<const float*>(smem), p.params + po + p.lo[PRB] + n0, x1 + (int64_t)row0 * d + n0,
                                 xout + (int64_t)row0 * d + n0, d, rows, tid);
             }
-            MG_SYNC(none, 5);
+            MG_SYNC0(5);
         }
     }
+#undef MG_SYNC0
 #undef MG_SYNC
 #undef MG_GEMM_DONE
     MG_STAMP(stamp++);
@@ -683,7 +689,11 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
     m.status = g_mega_state + 16 * 32;
     m.trace = g_mega_trace;
     SWAT_HIP(hipMemsetAsync(g_mega_state, 0, 17 * 128, s));
-    hipLaunchKernelGGL(vit_fwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, m);
+    // products + attention inside the launch (what bench.py's roofline divides by the launch's duration)
+    const double flops = (double)L * B * T * (2.0 * d * 3 * d + 2.0 * d * d + 4.0 * d * mlp + 4.0 * T * d);
+    hipEvent_t e0, e1;
+    if (gemm_prof_take(9, flops, e0, e1)) hipExtLaunchKernelGGL(vit_fwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, e0, e1, 0, m);
+    else hipLaunchKernelGGL(vit_fwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, m);
     return check_launch("vit_fwd_mega_kernel");
 }
 

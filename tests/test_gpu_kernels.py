@@ -407,11 +407,12 @@ def test_adamw_matches_torch():
 
 PC_LAYOUTS = {50: ("nt", "nn", "tn"), 51: ("nt", "nn"), 53: ("nt", "nn", "tn"), 54: ("tn",), 55: ("nt", "nn", "tn"),
               56: ("nt", "nn", "tn"), 58: ("nt", "nn"),
-              70: ("nt", "nn", "tn"), 71: ("nt", "nn", "tn"), 72: ("nt", "nn", "tn")}  # 70-72: the persistent tile loop
+              70: ("nt", "nn", "tn"), 71: ("nt", "nn", "tn"), 72: ("nt", "nn", "tn"),  # 70-72: the persistent tile loop
+              80: ("nt", "nn")}                                                        # 80: 256 x 256 (gemm_big.hip)
 
 
 @pytest.mark.parametrize("cfg", [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 43,
-                                 50, 51, 53, 54, 55, 56, 58, 70, 71, 72])
+                                 50, 51, 53, 54, 55, 56, 58, 70, 71, 72, 80])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm_every_tile_configuration(cfg, layout):
     """All register-staged and LDS-DMA pipelined tile configurations give the same product (ragged M/N edges)."""
@@ -435,3 +436,42 @@ def test_gemm_every_tile_configuration(cfg, layout):
     finally:
         _lib.lib().swat_gemm_set_tile(-1)
     close(C, ref, False, K)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+@pytest.mark.parametrize("epi", ["bias_act_c2", "residual_f32", "actin"])
+def test_gemm_256_tile_epilogues_on_many_rows(layout, epi):
+    """gemm_big.hip (256 x 256, the many-row tile pick_cfg takes for ViT-B/16 / ViT-L/14 products) with the fused epilogues
+    of the step, ragged edges on both sides (M = 8 224 = 32.1 tiles, N = 1 000 = 3.9 tiles), against fp32 torch."""
+    from swat_amd import ops, _lib
+    M, N, K = 8224, 1000, 1024
+    a = rnd(M, K, seed=41, dtype=BF)
+    w = rnd(N, K, seed=42, scale=0.05, dtype=BF)
+    ref = a.float() @ w.float().t()
+    B = w if layout == "nt" else w.t().contiguous()
+    lay, ldb = (ops.NT, K) if layout == "nt" else (ops.NN, N)
+    bias = rnd(N, seed=43)
+    _lib.lib().swat_gemm_set_tile(80)
+    try:
+        if epi == "bias_act_c2":
+            C = torch.empty(M, N, device=dev(), dtype=BF)
+            C2 = torch.empty(M, N, device=dev(), dtype=BF)
+            ops.gemm(lay, a, B, M, N, K, K, ldb, C, N, bias=bias, act="quick_gelu", C2=C2)
+            want = (ref + bias).to(BF)
+            close(C.float(), want.float(), True, K)
+            wf = want.float()
+            close(C2.float(), (C.float() * torch.sigmoid(1.702 * C.float())), True, 8)
+        elif epi == "residual_f32":
+            C = rnd(M, N, seed=44)
+            res = C.clone()
+            ops.gemm(lay, a, B, M, N, K, K, ldb, C, N, bias=bias, residual=C)
+            close(C, ref + bias + res, False, K)
+        else:
+            f = rnd(M, N, seed=45, dtype=BF)
+            C = torch.empty(M, N, device=dev(), dtype=BF)
+            ops.gemm(lay, a, B, M, N, K, K, ldb, C, N, actin=f, ldact=N, act="quick_gelu")
+            x = f.float()
+            sg = torch.sigmoid(1.702 * x)
+            close(C.float(), ref * (sg * (1 + 1.702 * x * (1 - sg))), True, K)
+    finally:
+        _lib.lib().swat_gemm_set_tile(-1)

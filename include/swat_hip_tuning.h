@@ -26,8 +26,8 @@ int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops
 int swat_gemm_set_tile(int cfg);
 /* Ablation bits (results WRONG): 1 no operand loads after the prologue, 2 no LDS reads / MFMA, 4 no epilogue, 8 no
  *     k-order skew, 16 per-workgroup time stamps into the trace buffer, 32 per-wave epilogue instead of the LDS-staged
- *     one, 64 loader waves read into registers instead of LDS-DMA, 512 never pick the producer / consumer kernel, 1024 never
- *     pick the 256 x 256 tile. */
+ *     one, 64 loader waves read into registers instead of LDS-DMA, 512 never pick the producer / consumer kernel, 2048
+ *     (results right) let pick_cfg take the 256 x 256 tile for deep many-row products.  SWAT_GEMM_EXP presets the bits. */
 int swat_gemm_set_exp(int bits);
 int swat_gemm_set_trace(void* dev_buf); /* exp bit 16: 4 (LDS-DMA kernel) or 8 (producer / consumer) uint64 per workgroup */
 int swat_gemm_set_swizzle(int mode);    /* 0 = plain 2-D grid, -1 = XCD-aware tile order (default) */

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void gemm_ring2_kernel(const GemmArgs p) {
     }
 }
 
-static int g_exp = 0;
+static int g_exp = getenv("SWAT_GEMM_EXP") ? atoi(getenv("SWAT_GEMM_EXP")) : 0;  // tuning bits (swat_gemm_set_exp; the variable: whole-job A/B runs)
 static unsigned long long* g_trace_host = nullptr;
 static int g_swz_mode = -1;  // -1 automatic, 0 off (swat_gemm_set_swizzle)
 
@@ -737,12 +737,13 @@ static int pick_cfg_base(int layout, const GemmArgs& a, int batch) {
     // 128-wide tiles' lower operand traffic wins the deep-K products (register ring 128x128 / 128x64) and the wgrads
     const bool many_rows = (layout == L_TN ? a.K : a.M) >= 4096;
     // forward / data-gradient products with thousands of rows: the 256 x 256 tile (gemm_big.hip) runs its main loop matrix-core
-    // bound (~50 % of the MFMA peak per CU), but a product is only 1.5-3 rounds of such tiles, so tile quantisation and the
-    // 64 K-element epilogue per workgroup eat most of it.  Measured per launch (tools/perf_gemm_big.py, M = 8 224, d = 1 024):
-    // in_proj 73 vs 77 us, c_proj 110 vs 114, c_fc dgrad 99 vs 102, in_proj dgrad 77 vs 81 — and out_proj 45 vs 37, c_fc
-    // 173 vs 135, c_proj dgrad 177 vs 150; at M = 6 304 (33 x 25 tiles -> worse rounds) it loses everywhere.  So: deep
-    // reductions (K >= 2 048) and the in_proj shape at >= 8 192 rows only.
-    if (many_rows && layout != L_TN && !(g_exp & 1024) && a.M >= 8192 && a.N >= 1024 && a.N % 256 == 0 && a.inner == 1 && a.lda % 8 == 0 &&
+    // bound (~50 % of the MFMA peak per CU, the guide template's own figure), but a ViT-L/14 product is only 1.5-3 rounds of such
+    // tiles, so tile quantisation and the 64 K-element epilogue per workgroup eat it.  Measured per launch alone
+    // (tools/perf_gemm_big.py, M = 8 224, d = 1 024): in_proj 73 vs 77 us, c_proj 110 vs 114, c_fc dgrad 99 vs 102, in_proj dgrad
+    // 77 vs 81 — but out_proj 45 vs 37, c_fc 173 vs 135, c_proj dgrad 177 vs 150; at M = 6 304 it loses everywhere.  Inside
+    // the ViT-L/14 step even the four winning shapes cost 1.5 % (968 vs 982 img/s: a 512-thread, 128-KiB workgroup leaves the
+    // weight-gradient lane nothing to overlap with).  So it is OPT-IN (swat_gemm_set_exp bit 2048 / SWAT_GEMM_EXP=2048).
+    if ((g_exp & 2048) && many_rows && layout != L_TN && a.M >= 8192 && a.N >= 1024 && a.N % 256 == 0 && a.inner == 1 && a.lda % 8 == 0 &&
         a.ldb % 8 == 0 && !a.C2 && !a.actin && (a.K >= 2048 || (a.K >= 1024 && a.N == 3 * a.K)))
         return 80;
     if (layout == L_NT) {

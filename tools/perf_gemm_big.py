@@ -1,5 +1,5 @@
 """Dev tool: the many-row products of ViT-L/14 (M = 8 224) and ViT-B/16 (M = 6 304) under the 256 x 256 tile (cfg 80,
-csrc/gemm_big.hip) against the tile pick_cfg chose before it existed (swat_gemm_set_exp(1024) switches 80 off)."""
+csrc/gemm_big.hip) against the tile pick_cfg takes by default (the 256 x 256 tile is opt-in: swat_gemm_set_exp bit 2048)."""
 import ctypes
 import os
 import sys
@@ -48,9 +48,7 @@ for arch, M, d in (("ViT-L/14", 8224, 1024), ("ViT-B/16", 6304, 768)):
     print(f"{arch}: M = {M}, d = {d}   (us per launch, TFLOP/s)")
     t_old = t_new = 0.0
     for name, layout, m, n, k, epi in shapes:
-        L.swat_gemm_set_exp(1024)
         old = run(layout, m, n, k, epi, -1)
-        L.swat_gemm_set_exp(0)
         new = run(layout, m, n, k, epi, 80)
         fl = 2.0 * m * n * k
         t_old += old; t_new += new

@@ -36,7 +36,8 @@ int swat_gemm_set_swizzle(int mode);    /* 0 = plain 2-D grid, -1 = XCD-aware ti
  *     0 or 1 = one launch, no planes).  Deterministic either way; the per-element summation order differs. */
 int swat_vit_set_split_k(int planes);
 /* The transformer blocks of the forward as ONE persistent launch (csrc/vit_mega.hip; ViT-B/32 regime: d = 768, 12 heads of 64,
- *     38 <= T <= 56): 1 = on when the shapes qualify (default), 0 = always op by op.  Same buffers, same rounding points. */
+ *     38 <= T <= 56): 1 = on when the shapes qualify and the batch fills whole rounds of 16 two-image panels (B = 27-32, 59-64;
+ *     default), 2 = on for every batch of a qualifying shape (tests), 0 = always op by op.  Same buffers, same rounding points. */
 int swat_vit_set_mega(int mode);
 /* Synchronises the device and returns the status word of the persistent forwards since the last call: 0 = every team
  *     hand-off completed; otherwise bit 30 is set and the low bits name the hand-off a workgroup gave up on (0.5 s). */

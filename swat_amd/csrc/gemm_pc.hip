@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stddef.h>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 #include "gemm_device.hpp"
@@ -785,17 +786,25 @@ __global__ __launch_bounds__(64 * (CM * CN + NL)) void gemm_pcg_kernel(const Gem
 
 // Descriptor cache: the product lists of a training job repeat every step (same buffers), so a list is uploaded once and
 // kept for the life of the process (a ViT-L/14 step has ~200 distinct lists of one product: 3 KB of device memory each).
-struct PcgSig {  // what identifies a product (GemmArgs has padding bytes: never compared raw); 64 bytes, no padding
-    const void *A, *B, *C, *C2, *bias, *aux;  // aux: residual / actin / rowbias / colsum folded together
-    int M, N, K, lda, ldb, ldc, flags, pad;
+struct PcgSig {  // EVERY GemmArgs field the kernel reads (GemmArgs has padding bytes: never compared raw); no padding inside
+    const void *A, *B, *C, *C2, *bias, *residual, *actin, *rowbias, *colsum, *trace;
+    int64_t sC0, sC1;
+    int M, N, K, lda, ldb, ldc, ldact, act, out_f32, rpg, gstride, roff, epi0, exp;
+    float alpha;
+    int pad;
     bool operator==(const PcgSig& o) const { return memcmp(this, &o, sizeof(PcgSig)) == 0; }
 };
 struct PcgEntry {
     std::vector<PcgSig> sig;
     GemmGroup* dev;
     int G, cfg, layout;
+    uint64_t stamp;  // last use (least recently used entry is evicted beyond PCG_CACHE_MAX)
 };
+constexpr size_t PCG_CACHE_MAX = 512;  // distinct product lists kept (a ViT-L/14 step has ~200 of one product each)
 static std::unordered_map<uint64_t, std::vector<PcgEntry>> g_pcg_cache;
+static size_t g_pcg_entries = 0;
+static uint64_t g_pcg_clock = 0;
+static std::mutex g_pcg_mutex;  // the cache is process-wide: two host threads may launch grouped products concurrently
 
 struct PcgTile { int bm, bn, maxg; };
 static PcgTile pcg_tile(int layout, int cfg) {
@@ -828,13 +837,16 @@ int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s
     for (int i = 0; i < n; ++i) {
         const GemmArgs& a = probs[i];
         memset(&sig[i], 0, sizeof(PcgSig));
-        sig[i].A = a.A; sig[i].B = a.B; sig[i].C = a.C; sig[i].C2 = a.C2; sig[i].bias = a.bias;
-        sig[i].aux = (const void*)((uintptr_t)a.residual ^ ((uintptr_t)a.actin << 1) ^ ((uintptr_t)a.rowbias << 2) ^ ((uintptr_t)a.colsum << 3));
+        sig[i].A = a.A; sig[i].B = a.B; sig[i].C = a.C; sig[i].C2 = a.C2; sig[i].bias = a.bias; sig[i].residual = a.residual;
+        sig[i].actin = a.actin; sig[i].rowbias = a.rowbias; sig[i].colsum = a.colsum; sig[i].trace = a.trace;
+        sig[i].sC0 = a.sC0; sig[i].sC1 = a.sC1;
         sig[i].M = a.M; sig[i].N = a.N; sig[i].K = a.K; sig[i].lda = a.lda; sig[i].ldb = a.ldb; sig[i].ldc = a.ldc;
-        sig[i].flags = a.act | (a.out_f32 << 4) | (a.rpg << 8) | (a.ldact << 16);
+        sig[i].ldact = a.ldact; sig[i].act = a.act; sig[i].out_f32 = a.out_f32; sig[i].rpg = a.rpg; sig[i].gstride = a.gstride;
+        sig[i].roff = a.roff; sig[i].epi0 = a.epi0; sig[i].exp = a.exp; sig[i].alpha = a.alpha;
         const unsigned char* b = reinterpret_cast<const unsigned char*>(&sig[i]);
         for (size_t j = 0; j < sizeof(PcgSig); ++j) key = (key ^ b[j]) * 1099511628211ull;
     }
+    std::lock_guard<std::mutex> lock(g_pcg_mutex);
     PcgEntry* e = nullptr;
     auto& bucket = g_pcg_cache[key];
     for (auto& c : bucket)
@@ -876,9 +888,25 @@ int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s
             set_error("gemm group: descriptor upload failed: %s", hipGetErrorString(ce));
             return -1;
         }
-        bucket.push_back(PcgEntry{sig, d, G, t.bm * 1024 + t.bn, layout});
-        e = &bucket.back();
+        if (g_pcg_entries >= PCG_CACHE_MAX) {  // evict the least recently used list (its descriptor is no longer referenced by any
+            uint64_t oldest = ~0ull;           // launch the host has not already enqueued: hipFree synchronises before it frees)
+            std::vector<PcgEntry>* ob = nullptr;
+            size_t oi = 0;
+            for (auto& kv : g_pcg_cache)
+                for (size_t j = 0; j < kv.second.size(); ++j)
+                    if (kv.second[j].stamp < oldest) { oldest = kv.second[j].stamp; ob = &kv.second; oi = j; }
+            if (ob) {
+                (void)hipFree((*ob)[oi].dev);
+                ob->erase(ob->begin() + (long)oi);
+                --g_pcg_entries;
+            }
+        }
+        auto& bucket2 = g_pcg_cache[key];  // (eviction may have touched the map's buckets)
+        bucket2.push_back(PcgEntry{sig, d, G, t.bm * 1024 + t.bn, layout, 0});
+        e = &bucket2.back();
+        ++g_pcg_entries;
     }
+    e->stamp = ++g_pcg_clock;
     if (layout == L_NT) pcg_launch<L_NT>(t, e->G, s, ev0, ev1, e->dev);
     else if (layout == L_NN) pcg_launch<L_NN>(t, e->G, s, ev0, ev1, e->dev);
     else pcg_launch<L_TN>(t, e->G, s, ev0, ev1, e->dev);

@@ -661,6 +661,13 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
                      float* rstd1, float* mean2, float* rstd2, hipStream_t s) {
     // one panel = 2 images (attention reads 64 key rows from the second image's first row: 2 T + 14 <= 128 tile rows)
     if (g_mega_mode == 0 || d != 768 || mlp != 3072 || H != 12 || d / H != 64 || T < 38 || T > 56 || B < 1 || L < 1) return 1;
+    // 16 teams walk the panels in rounds of 16: a launch pays whole rounds (~0.8 ms each for 12 blocks), so batches that leave
+    // the last round mostly empty — and big batches, where the op-by-op products fill the chip on their own (B = 256: M = 12 800
+    // rows) — stay on the op-by-op path.  mode 2 (tests) takes every batch.
+    {
+        const int np = (B + 1) / 2, rounds = (np + 15) / 16;
+        if (g_mega_mode != 2 && (rounds > 2 || np < rounds * 16 - 3)) return 1;
+    }
     const int64_t stride = L > 1 ? layer_offs[12] - layer_offs[0] : 0;
     for (int l = 1; l < L; ++l)
         for (int k = 0; k < 12; ++k)
@@ -701,7 +708,7 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
 using namespace swat;
 
 SWAT_API int swat_vit_set_mega(int mode) {
-    SWAT_REQUIRE(mode == 0 || mode == 1, "swat_vit_set_mega: mode must be 0 or 1");
+    SWAT_REQUIRE(mode >= 0 && mode <= 2, "swat_vit_set_mega: mode must be 0, 1 or 2");
     g_mega_mode = mode;
     return 0;
 }

@@ -5,7 +5,7 @@
 #   <tag>_pmc_sq                    : SQ counters per GEMM instantiation (MFMA busy, waits, LDS conflicts)
 #   <tag>_pmc_fetch, _pmc_write     : FETCH_SIZE / WRITE_SIZE in separate passes (MI355X_MICROARCH.md §HBM)
 # Counter passes never combine --pmc with a trace domain; the program sits directly behind `--`.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-secondary"
@@ -24,13 +24,13 @@ def load(d):
     res = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{O}/{TAG}_{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "gemm_" in r["Kernel_Name"]:
+            if ("gemm_" in r["Kernel_Name"] and "sgemm_small" not in r["Kernel_Name"]) or "vit_fwd_mega" in r["Kernel_Name"]:   # every kernel bench.py's roofline times
                 k = r["Kernel_Name"].split("(")[0].replace("void swat::", "")
                 res[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return res
 sq, fe, wr = load("pmc_sq"), load("pmc_fetch"), load("pmc_write")
 out = {"source": "rocprofv3 --pmc (three separate passes: 8 SQ counters; FETCH_SIZE; WRITE_SIZE) over 'bench.py --steps 4 --warmup 2 --overlap 0 "
-                 "--no-cpu-baseline --no-secondary' (kernels run alone, one stream); means per launch of every GEMM instantiation",
+                 "--no-cpu-baseline --no-secondary' (kernels run alone, one stream); means per launch of every GEMM instantiation and of the persistent forward (vit_fwd_mega_kernel: all twelve blocks in one launch)",
        "reading": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32 (the counter sums "
                   "the 32 shader engines); wait fractions are of SQ_WAVE_CYCLES (quad-cycles); FETCH_SIZE is doubled (gfx950 tallies 128-B "
                   "requests at 64 B, MI355X_MICROARCH.md HBM section), WRITE_SIZE as is; KB -> bytes",

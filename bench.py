@@ -625,6 +625,8 @@ def main():
         dt = t.item()
     loss = step.loss.item()
     assert math.isfinite(loss), "training diverged"
+    from swat_amd import _lib as _l
+    assert _l.lib().swat_vit_mega_status() == 0, "the persistent forward reported a hand-off that gave up"
 
     out = None
     if rank == 0:

@@ -39,7 +39,7 @@ int swat_vit_set_split_k(int planes);
  *     38 <= T <= 56): 1 = on when the shapes qualify and the batch fills whole rounds of 16 two-image panels (B = 27-32, 59-64;
  *     default), 2 = on for every batch of a qualifying shape (tests), 0 = always op by op.  Same buffers, same rounding points. */
 int swat_vit_set_mega(int mode);
-/* Synchronises the device and returns the status word of the persistent forwards since the last call: 0 = every team
+/* Synchronises the device, returns and clears the status word of the persistent forwards since the last call: 0 = every team
  *     hand-off completed; otherwise bit 30 is set and the low bits name the hand-off a workgroup gave up on (0.5 s). */
 int swat_vit_mega_status(void);
 /* Per-workgroup phase stamps of the next persistent forwards (64 x uint64 per workgroup, 100 MHz ticks); null = off. */

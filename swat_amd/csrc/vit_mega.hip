@@ -650,7 +650,7 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
-static unsigned* g_mega_state = nullptr;   // [16 teams x 32 words | status 32 words] = 2176 B, zeroed before every launch
+static unsigned* g_mega_state = nullptr;   // [16 teams x 32 words: zeroed before every launch | status 32 words: sticky] = 2176 B
 static int g_mega_mode = 1;                // swat_vit_set_mega: 0 = op-by-op forward, 1 = persistent forward when eligible
 static unsigned long long* g_mega_trace = nullptr;
 
@@ -676,7 +676,7 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
         if (layer_offs[k] % 8) return 1;  // 16-B rows of the bf16 shadow
     if (stride % 8) return 1;
     if (!g_mega_state) {
-        if (hipMalloc((void**)&g_mega_state, 17 * 128) != hipSuccess) {
+        if (hipMalloc((void**)&g_mega_state, 17 * 128) != hipSuccess || hipMemset(g_mega_state, 0, 17 * 128) != hipSuccess) {
             set_error("vit_mega: hipMalloc of the hand-off state failed");
             return -1;
         }
@@ -695,7 +695,7 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
     m.ctr = g_mega_state;
     m.status = g_mega_state + 16 * 32;
     m.trace = g_mega_trace;
-    SWAT_HIP(hipMemsetAsync(g_mega_state, 0, 17 * 128, s));
+    SWAT_HIP(hipMemsetAsync(g_mega_state, 0, 16 * 128, s));  // the arrival counters; the status word behind them is sticky (read-and-clear)
     // products + attention inside the launch (what bench.py's roofline divides by the launch's duration)
     const double flops = (double)L * B * T * (2.0 * d * 3 * d + 2.0 * d * d + 4.0 * d * mlp + 4.0 * T * d);
     hipEvent_t e0, e1;
@@ -719,7 +719,8 @@ SWAT_API int swat_vit_mega_status(void) {
     unsigned v = 0;
     SWAT_HIP(hipDeviceSynchronize());
     SWAT_HIP(hipMemcpy(&v, g_mega_state + 16 * 32, 4, hipMemcpyDeviceToHost));
-    return (int)(v & 0x7fffffffu) | (v ? 0x40000000 : 0);
+    if (v) SWAT_HIP(hipMemset(g_mega_state + 16 * 32, 0, 128));
+    return (int)(v & 0x3fffffffu) | (v ? 0x40000000 : 0);
 }
 
 // tuning: per-workgroup phase stamps (64 x uint64 per workgroup, 100 MHz ticks) of the next persistent forwards; null = off

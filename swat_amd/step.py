@@ -229,4 +229,9 @@ class FusedTrainStep:
     def pop_loss_sum(self):
         v = self.loss_accum.item()
         self.loss_accum.zero_()
+        # the persistent forward's hand-offs are bounded spins: a give-up is recorded, not hung on — surface it at the
+        # step's one synchronisation point (the values of such a step are garbage)
+        st = _lib.lib().swat_vit_mega_status()
+        if st != 0:
+            raise _lib.SwatHipError(f"vit_fwd_mega_kernel: a team hand-off gave up (status {st:#x}); set swat_vit_set_mega(0) to run op by op")
         return v

@@ -746,6 +746,12 @@ static int pick_cfg_base(int layout, const GemmArgs& a, int batch) {
     if ((g_exp & 2048) && many_rows && layout != L_TN && a.M >= 8192 && a.N >= 1024 && a.N % 256 == 0 && a.inner == 1 && a.lda % 8 == 0 &&
         a.ldb % 8 == 0 && !a.C2 && !a.actin && (a.K >= 2048 || (a.K >= 1024 && a.N == 3 * a.K)))
         return 80;
+    // many rows onto a NARROW output (N <= 1 536: out_proj / c_proj forward, every data gradient that lands on the residual width):
+    // the producer / consumer 160 x 128 tile over several rounds.  Measured per launch (tools/perf_gemm_big.py, round 3; the
+    // previous choices 50 / 30 / 14 in brackets) — M = 8 224, d = 1 024: c_proj 92 us = 749 TF (113), c_fc dgrad 84 = 821 TF (104),
+    // out_proj dgrad 28 (36), in_proj dgrad 67 = 772 TF (81); M = 6 304, d = 768: 42 (59), 35 = 843 TF (53), 14 (19), 28 = 809 TF (41).
+    // The forward out_proj (fp32 residual epilogue, K = d) and every wide product (N >= 2 048) keep their tiles: 51 loses there.
+    if (many_rows && layout != L_TN && !(g_exp & 512) && a.N <= 1536 && a.K >= 256 && (a.K >= 2048 || layout == L_NN)) return 51;
     if (layout == L_NT) {
         if (a.N >= 2048 && a.K <= 1024 && a.M >= 128) return 43;
         return many_rows && a.K >= 2048 ? 50 : 14;  // (50 = producer / consumer 128 x 128, several rounds: ViT-L/14 step 34.3 ->

@@ -930,12 +930,14 @@ static int launch_pc_layout(const GemmArgs& a, int batch, int cfg, hipStream_t s
     // layout masks: 1 = NT, 2 = NN, 4 = TN
     switch (cfg) {
         case 50: SWAT_PC(7, 128, 128, 2, 2, 4, 4) break;
-        case 51: SWAT_PC(3, 160, 128, 2, 2, 4, 4) break;
+        case 51: SWAT_PC(7, 160, 128, 2, 2, 4, 4) break;
         case 53: SWAT_PC(7, 96, 64, 2, 2, 4, 4) break;
         case 54: SWAT_PC(4, 96, 96, 2, 2, 4, 4) break;
         case 55: SWAT_PC(7, 128, 64, 2, 2, 4, 4) break;
         case 56: SWAT_PC(7, 64, 64, 2, 2, 4, 4) break;
         case 58: SWAT_PC(3, 128, 128, 2, 4, 4, 4) break;
+        case 59: SWAT_PC(3, 192, 128, 3, 2, 4, 4) break;   // 6 consumer waves of 64 x 64, the whole 160 KB of LDS
+        case 66: SWAT_PC(3, 192, 128, 3, 4, 4, 4) break;   // 12 consumer waves of 64 x 32
         case 60: SWAT_PC(3, 96, 64, 2, 2, 4, 7) break;
         case 61: SWAT_PC(4, 96, 96, 2, 2, 4, 6) break;
         case 62: SWAT_PC(7, 64, 64, 2, 2, 4, 8) break;

@@ -592,11 +592,11 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
                     mg_attention(tiles, tiles + 128 * ATP, tiles + 2 * 128 * ATP, im * T, T, wave & 3, lane, scale,
                                  at + (int64_t)(row0 + im * T) * d + 64 * h, d);
             }
-            MG_SYNC(wO, 48, 6, 1);
+            MG_SYNC(wO, 48, 7, 1);
             // ---------------- out_proj + bias + residual -> x1 ----------------
             {
                 const int n0 = 48 * member;
-                mg_gemm_nt<48, 3, 6>(smem, at + (int64_t)row0 * d, d, rows, wO);
+                mg_gemm_nt<48, 3, 7>(smem, at + (int64_t)row0 * d, d, rows, wO);
                 MG_GEMM_DONE(1);
                 mg_epi_residual(reinterpret_cast<const float*>(smem), p.params + po + p.lo[OUTB] + n0, xin + (int64_t)row0 * d + n0,
                                 x1 + (int64_t)row0 * d + n0, d, rows, tid);
@@ -631,11 +631,11 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
                 else if (p.act == 2) epi(std::integral_constant<int, 2>{});
                 else epi(std::integral_constant<int, 0>{});
             }
-            MG_SYNC(wP, 48, 6, 4);
+            MG_SYNC(wP, 48, 7, 4);
             // ---------------- c_proj + bias + residual -> next block's input ----------------
             {
                 const int n0 = 48 * member;
-                mg_gemm_nt<48, 3, 6>(smem, ga + (int64_t)row0 * mlp, mlp, rows, wP);
+                mg_gemm_nt<48, 3, 7>(smem, ga + (int64_t)row0 * mlp, mlp, rows, wP);
                 MG_GEMM_DONE(3);
                 mg_epi_residual(reinterpret_cast<const float*>(smem), p.params + po + p.lo[PRB] + n0, x1 + (int64_t)row0 * d + n0,
                                 xout + (int64_t)row0 * d + n0, d, rows, tid);

@@ -324,7 +324,10 @@ _ARCH_CLASSES = {"ViT-B-16": 200, "ViT-L-14": 1000}  # semi-aves; ImageNet (BASE
 def finetune_secondary(dev, arch, gflop_per_img, bsz=32, steps=20, warmup=5):
     """The same fused step on another BASELINE config (ViT-B/16 semi-aves; ViT-L/14 ImageNet, C = 1000), one GPU, B = 32."""
     n_cls = _ARCH_CLASSES[arch]
-    args, model, head, step, sched = build_job(dev, 1, bsz, n_cls=n_cls, arch=arch)
+    ov = int(os.environ.get("SWAT_BENCH_OVERLAP", "2"))   # tuning: 0 one stream, 1 weight-gradient lane, 2 (default) + trailing AdamW
+    args, model, head, step, sched = build_job(dev, 1, bsz, n_cls=n_cls, arch=arch, trail=ov == 2)
+    from swat_amd import _lib
+    _lib.lib().swat_vit_set_overlap(min(ov, 1))
     g = torch.Generator(device=dev).manual_seed(4321)
     images = torch.randn(bsz, 3, 224, 224, device=dev, generator=g)
     labels = torch.randint(0, n_cls, (bsz,), device=dev, generator=g)

@@ -257,9 +257,11 @@ int swat_attn_bwd_small(const void* qkv_bf16, const void* dout_bf16, void* dqkv_
 int swat_attn_fwd_tiled(const void* qkv_bf16, void* out_bf16, float* lse, int B, int T, int d, int H, int causal,
                         swat_stream_t stream);
 /*     its backward in two launches (dQ per query tile; dK, dV per key tile), each recomputing P from Q, K and lse;
- *     out = the forward's output (for delta = rowsum(dO * O)). */
+ *     out = the forward's output (for delta = rowsum(dO * O), which the first launch leaves in `workspace`:
+ *     swat_attn_bwd_tiled_workspace_bytes(B, T, H) bytes). */
+int64_t swat_attn_bwd_tiled_workspace_bytes(int B, int T, int H);
 int swat_attn_bwd_tiled(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16, const float* lse,
-                        void* dqkv_bf16, int B, int T, int d, int H, swat_stream_t stream);
+                        void* dqkv_bf16, int B, int T, int d, int H, void* workspace, swat_stream_t stream);
 
 /* A2 (whole)  model.encode_image(images) as one call: CutMix-aware patch embed, cls/pos, ln_pre, L
  *     pre-LN blocks, ln_post(cls), proj -> feats [B,E] fp32 (un-normalised).

@@ -21,6 +21,8 @@
 
 namespace swat {
 
+void launch_attn_fwd_tiled2(const unsigned short* qkv, unsigned short* out, float* lse, int B, int T, int d, int H, int causal, hipStream_t s);  // attention_tiled2.hip
+
 // S = Q K^T for the wave's 16 query rows, then the row softmax; returns P (fp32, already rounded through bf16) in s[][]
 __device__ __forceinline__ void scores_softmax(const unsigned short* base, int64_t ld, int d, int T, int wave, int r16, int g,
                                                float scale, af32x4_t (&s)[4]) {
@@ -268,7 +270,6 @@ SWAT_API int swat_attn_fwd_tiled(const void* qkv_bf16, void* out_bf16, float* ls
                                  swat_stream_t stream) {
     SWAT_REQUIRE(qkv_bf16 && out_bf16 && B > 0 && T > 0 && T <= 320 && H > 0 && d == 64 * H,
                  "swat_attn_fwd_tiled: needs T <= 320 and head width 64 (T=%d d=%d H=%d)", T, d, H);
-    hipLaunchKernelGGL(swat::attn_fwd_tiled_kernel, dim3(B * H, (T + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)qkv_bf16, (unsigned short*)out_bf16, lse, T, d, H, 0.125f, causal);
+    swat::launch_attn_fwd_tiled2((const unsigned short*)qkv_bf16, (unsigned short*)out_bf16, lse, B, T, d, H, causal, (hipStream_t)stream);
     return swat::check_launch("swat_attn_fwd_tiled");
 }

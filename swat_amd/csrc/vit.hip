@@ -168,7 +168,7 @@ static int attn_backward(const VitDims& D, const unsigned short* qkv, const unsi
                          const float* lse = nullptr) {
     const int T = D.T, d = D.d, dh = D.dh, H = D.H, ldp = D.ldp, BH = D.B * D.H;
     if (T <= 64 && dh == 64) return swat_attn_bwd_small(qkv, dout, dqkv, D.B, T, d, H, s);  // recomputes P from Q, K
-    if (T <= 320 && dh == 64 && out && lse) return swat_attn_bwd_tiled(qkv, out, dout, lse, dqkv, D.B, T, d, H, s);
+    if (T <= 320 && dh == 64 && out && lse) return swat_attn_bwd_tiled(qkv, out, dout, lse, dqkv, D.B, T, d, H, dP, s);  // dP: [B*H, T, ldp] fp32 scratch holds the row deltas
     const int64_t sP0 = (int64_t)H * T * ldp, sP1 = (int64_t)T * ldp, sQ0 = (int64_t)T * 3 * d, sO0 = (int64_t)T * d;
     {   // dV = P^T dO
         GemmArgs a = G(P, dout, dqkv + 2 * d, T, dh, T, ldp, d, 3 * d, 0);

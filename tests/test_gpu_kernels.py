@@ -261,8 +261,9 @@ def test_attention_tiled(B, H, T, causal):
     assert (lse - torch.logsumexp(s, -1).reshape(B * H, T)).abs().max().item() < 5e-3
     if causal:
         return  # the text tower is frozen: no backward
+    ws = torch.empty(lib.swat_attn_bwd_tiled_workspace_bytes(B, T, H), device=qkv.device, dtype=torch.uint8)
     _lib.check(lib.swat_attn_bwd_tiled(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(do), _lib.ptr(lse), _lib.ptr(dqkv), B, T, d, H,
-                                       _lib.stream()), "swat_attn_bwd_tiled")
+                                       _lib.ptr(ws), _lib.stream()), "swat_attn_bwd_tiled")
     o.backward(do.float())
     ref = torch.cat([g.grad.permute(0, 2, 1, 3).reshape(B * T, d) for g in (q, k, v)], dim=1)
     assert (dqkv.float() - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 1e-3

@@ -3,8 +3,8 @@
 // call sites utils/training.py:332,1474 (+ autograd).  Same arithmetic and rounding points as csrc/attention.hip /
 // attention_bwd_tiled.hip (P and dS rounded to bf16 before they are multiplied again, fp32 statistics); what changed is the
 // data movement, which is what bounds these kernels (MFMA busy ~5 % at T = 257):
-//   * a workgroup holds W = 4..9 waves of 16 query rows (two workgroups per (image, head) at T = 197 / 257: 224 / 288 rows
-//     instead of 256 / 320 in 64-row tiles), so a staged key tile serves up to 144 queries;
+//   * a workgroup holds W = 4..9 waves of 16 rows (8 when T > 144), so a staged tile serves up to 144 rows; waves whose rows
+//     all lie past T skip the arithmetic;
 //   * K AND V tiles are staged in LDS, double-buffered: the next tile's global loads are issued before the current tile's
 //     MFMAs and written to the other buffer after them — ONE barrier per key tile, no global load inside the MFMA chains
 //     (the first forms read every K / V fragment straight from global memory, per wave, between two barriers);
@@ -72,7 +72,7 @@ __device__ __forceinline__ void fwd2_tile(const unsigned short* ktile, const uns
                     if (kk >= rem || (causal && k0 + kk > q)) s[j][e] = -INFINITY;
                 }
             }
-            mx = fmaxf(fmaxf(mx, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));
+            mx = fmaxf(fmaxf(mx, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));   // (not inline asm: MFMA -> VALU hazard nops are the compiler's)
         }
     }
     const float mnew = fmaxf(m, xor_max(mx) * c2);   // finite from the first tile on: key 0 is never masked
@@ -103,6 +103,7 @@ __device__ __forceinline__ void fwd2_tile(const unsigned short* ktile, const uns
     }
 }
 
+
 template <int W, int OCC>
 __global__ __launch_bounds__(64 * W, OCC) void attn_fwd_tiled2_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
                                                                  float* __restrict__ lse, int T, int d, int H, float scale, int causal) {
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(64 * W, OCC) void attn_fwd_tiled2_kernel(const unsi
     const int64_t ld = 3 * (int64_t)d;
     const unsigned short* base = qkv + (int64_t)b * T * ld + h * 64;
     const int q = q0 + wave * 16 + r16, qq = q < T ? q : T - 1;
+    const bool active = q0 + wave * 16 < T;   // a wave whose 16 rows all lie past T only helps staging
     abf16x8_t qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(base + (int64_t)qq * ld + 32 * ks + 8 * g);
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(64 * W, OCC) void attn_fwd_tiled2_kernel(const unsi
         const unsigned short* vtile = ktile + 64 * ATP;
         if (kt + 1 < nkt) st.issue(base, ld, d, T, k0 + 64, tid);
         const int rem = T - k0;   // keys left: 16-key blocks / 32-key halves past T are skipped (T = 257: a 1-key last tile)
-        if (rem >= 64 && !causal) fwd2_tile<false>(ktile, vtile, qf, o, lacc, m, c2, 64, 0, 0, 0, r16, g);
+        if (!active) {
+        } else if (rem >= 64 && !causal) fwd2_tile<false>(ktile, vtile, qf, o, lacc, m, c2, 64, 0, 0, 0, r16, g);
         else fwd2_tile<true>(ktile, vtile, qf, o, lacc, m, c2, rem, causal, k0, q, r16, g);
         if (kt + 1 < nkt) {
             unsigned short* nk = tiles + ((kt + 1) & 1) * 2 * 64 * ATP;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(64 * W, OCC) void attn_bwd_dq2_kernel(const unsigne
     const unsigned short* ob = out + (int64_t)b * T * d + h * 64;
     const unsigned short* dob = dout + (int64_t)b * T * d + h * 64;
     const int q = q0 + wave * 16 + r16, qq = q < T ? q : T - 1;
-    const bool valid = q < T;
+    const bool valid = q < T, active = q0 + wave * 16 < T;
     KvStage<NT> st;
     st.issue(base, ld, d, T, 0, tid);
     abf16x8_t qf[2], dof[2];
@@ -200,35 +203,37 @@ __global__ __launch_bounds__(64 * W, OCC) void attn_bwd_dq2_kernel(const unsigne
         const unsigned short* ktile = tiles + (kt & 1) * 2 * 64 * ATP;
         const unsigned short* vtile = ktile + 64 * ATP;
         if (kt + 1 < nkt) st.issue(base, ld, d, T, k0 + 64, tid);
-        af32x4_t p[4], ds[4];
-        const int rem = T - k0;
+        if (active) {
+            af32x4_t p[4], ds[4];
+            const int rem = T - k0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            p[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
-            ds[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (16 * j < rem) {
+            for (int j = 0; j < 4; ++j) {
+                p[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+                ds[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (16 * j < rem) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    p[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ktile + (16 * j + r16) * ATP + 32 * ks + 8 * g), qf[ks], p[j], 0, 0, 0);
-                    ds[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(vtile + (16 * j + r16) * ATP + 32 * ks + 8 * g), dof[ks], ds[j], 0, 0, 0);
-                }
+                    for (int ks = 0; ks < 2; ++ks) {
+                        p[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ktile + (16 * j + r16) * ATP + 32 * ks + 8 * g), qf[ks], p[j], 0, 0, 0);
+                        ds[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(vtile + (16 * j + r16) * ATP + 32 * ks + 8 * g), dof[ks], ds[j], 0, 0, 0);
+                    }
 #pragma unroll
-                for (int e = 0; e < 4; ++e)   // dS = P * scale * (dP - delta), P = exp2(s * scale * log2 e - lse * log2 e): four VALU ops
-                    ds[j][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[j][e], c2, -lq2)) * __builtin_fmaf(ds[j][e], scale, -dsc);
-                if (rem < 64) {
+                    for (int e = 0; e < 4; ++e)   // dS = P * scale * (dP - delta), P = exp2(s * scale * log2 e - lse * log2 e): four VALU ops
+                        ds[j][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[j][e], c2, -lq2)) * __builtin_fmaf(ds[j][e], scale, -dsc);
+                    if (rem < 64) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (16 * j + 4 * g + e >= rem) ds[j][e] = 0.f;   // keys past T
+                        for (int e = 0; e < 4; ++e)
+                            if (16 * j + 4 * g + e >= rem) ds[j][e] = 0.f;   // keys past T
+                    }
                 }
             }
+            const abf16x8_t dsf[2] = {acc_frag(ds, 0), acc_frag(ds, 1)};
+#pragma unroll
+            for (int jc = 0; jc < 4; ++jc)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    if (32 * ks < rem)
+                        dq[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(ktile, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), dsf[ks], dq[jc], 0, 0, 0);
         }
-        const abf16x8_t dsf[2] = {acc_frag(ds, 0), acc_frag(ds, 1)};
-#pragma unroll
-        for (int jc = 0; jc < 4; ++jc)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                if (32 * ks < rem)
-                    dq[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(ktile, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), dsf[ks], dq[jc], 0, 0, 0);
         if (kt + 1 < nkt) {
             unsigned short* nk = tiles + ((kt + 1) & 1) * 2 * 64 * ATP;
             st.commit(nk, nk + 64 * ATP, tid);
@@ -297,6 +302,7 @@ __global__ __launch_bounds__(64 * W, OCC) void attn_bwd_dkdv2_kernel(const unsig
     const float* lrow = lse + (int64_t)blockIdx.x * T;
     const float* drow = delta + (int64_t)blockIdx.x * T;
     const int key = k0 + wave * 16 + r16, kk = key < T ? key : T - 1;
+    const bool active = k0 + wave * 16 < T;
     QdoStage<NT> st;
     st.issue(base, ld, dob, d, lrow, drow, T, 0, tid);
     abf16x8_t kf[2], vf[2];
@@ -321,39 +327,41 @@ __global__ __launch_bounds__(64 * W, OCC) void attn_bwd_dkdv2_kernel(const unsig
         const unsigned short* dotile = qtile + 64 * ATP;
         const float* stt = stats + (qt & 1) * 128;
         if (qt + 1 < nqt) st.issue(base, ld, dob, d, lrow, drow, T, q0 + 64, tid);
-        af32x4_t p[4], ds[4];
+        if (active) {
+            af32x4_t p[4], ds[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            p[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
-            ds[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (16 * j < rem) {
+            for (int j = 0; j < 4; ++j) {
+                p[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+                ds[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (16 * j < rem) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    p[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(qtile + (16 * j + r16) * ATP + 32 * ks + 8 * g), kf[ks], p[j], 0, 0, 0);
-                    ds[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(dotile + (16 * j + r16) * ATP + 32 * ks + 8 * g), vf[ks], ds[j], 0, 0, 0);
-                }
-                const af32x4_t lq2 = *(const __attribute__((address_space(3))) af32x4_t*)(stt + 16 * j + 4 * g);
-                const af32x4_t dsc = *(const __attribute__((address_space(3))) af32x4_t*)(stt + 64 + 16 * j + 4 * g);
+                    for (int ks = 0; ks < 2; ++ks) {
+                        p[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(qtile + (16 * j + r16) * ATP + 32 * ks + 8 * g), kf[ks], p[j], 0, 0, 0);
+                        ds[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(dotile + (16 * j + r16) * ATP + 32 * ks + 8 * g), vf[ks], ds[j], 0, 0, 0);
+                    }
+                    const af32x4_t lq2 = *(const __attribute__((address_space(3))) af32x4_t*)(stt + 16 * j + 4 * g);
+                    const af32x4_t dsc = *(const __attribute__((address_space(3))) af32x4_t*)(stt + 64 + 16 * j + 4 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    p[j][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[j][e], c2, -lq2[e]));
-                    ds[j][e] = p[j][e] * __builtin_fmaf(ds[j][e], scale, -dsc[e]);
-                }
-                if (rem < 64) {
+                    for (int e = 0; e < 4; ++e) {
+                        p[j][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[j][e], c2, -lq2[e]));
+                        ds[j][e] = p[j][e] * __builtin_fmaf(ds[j][e], scale, -dsc[e]);
+                    }
+                    if (rem < 64) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (16 * j + 4 * g + e >= rem) p[j][e] = ds[j][e] = 0.f;   // queries past T
+                        for (int e = 0; e < 4; ++e)
+                            if (16 * j + 4 * g + e >= rem) p[j][e] = ds[j][e] = 0.f;   // queries past T
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (32 * ks < rem) {
-                const abf16x8_t pf = acc_frag(p, ks), dsf = acc_frag(ds, ks);
+            for (int ks = 0; ks < 2; ++ks) {
+                if (32 * ks < rem) {
+                    const abf16x8_t pf = acc_frag(p, ks), dsf = acc_frag(ds, ks);
 #pragma unroll
-                for (int jc = 0; jc < 4; ++jc) {
-                    dv[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dotile, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), pf, dv[jc], 0, 0, 0);
-                    dk[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(qtile, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), dsf, dk[jc], 0, 0, 0);
+                    for (int jc = 0; jc < 4; ++jc) {
+                        dv[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dotile, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), pf, dv[jc], 0, 0, 0);
+                        dk[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(qtile, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), dsf, dk[jc], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -374,12 +382,13 @@ __global__ __launch_bounds__(64 * W, OCC) void attn_bwd_dkdv2_kernel(const unsig
 }
 
 static int att_w();
-// waves per workgroup and query tiles per (image, head): the fewest tiles of <= 9 waves, then the fewest waves that cover T
+// waves per workgroup and row tiles per (image, head): one workgroup of up to 9 waves when that covers T; otherwise 8-wave
+// workgroups (two per SIMD: a 9-wave group leaves one SIMD with 3 waves and the other three waiting for it at every
+// barrier), the last of which may hold waves with no rows — those only help staging (T = 257: 8 + 8 + 1 fragments)
 static void tiled2_shape(int T, int& W, int& tiles) {
     const int frags = (T + 15) / 16;
-    tiles = (frags + 8) / 9;
-    W = (frags + tiles - 1) / tiles;
-    if (W < 4) W = 4;
+    if (frags <= 9) { W = frags < 4 ? 4 : frags; tiles = 1; }
+    else { W = 8; tiles = (frags + 7) / 8; }
     if (att_w() >= 4 && att_w() <= 9) { W = att_w(); tiles = (frags + W - 1) / W; }
 }
 
@@ -393,7 +402,7 @@ static void tiled2_shape(int T, int& W, int& tiles) {
         default: hipLaunchKernelGGL((KERN<9, OCC>), grid, dim3(576), 0, s, __VA_ARGS__); break;         \
     }
 #define SWAT_ATT2(KERN, WHICH, ...)                                                                     \
-    switch (att_occ(WHICH)) {                                                                           \
+    switch (att_occ(WHICH, W)) {                                                                           \
         case 3: SWAT_ATT2W(KERN, 3, __VA_ARGS__) break;                                                 \
         case 4: SWAT_ATT2W(KERN, 4, __VA_ARGS__) break;                                                 \
         case 5: SWAT_ATT2W(KERN, 5, __VA_ARGS__) break;                                                 \
@@ -402,13 +411,15 @@ static void tiled2_shape(int T, int& W, int& tiles) {
     }
 
 // experiment knob: SWAT_ATT_OCC = three digits (forward, dQ, dK/dV): waves per SIMD the kernels are compiled for
-static int att_occ(int which) {
-    static int v[3] = {0, 0, 0};
-    if (!v[0]) {
+// (default: a 9-wave workgroup puts 3 waves on one SIMD and a second one never fits beside it below 5 per SIMD, so it may as
+// well have 168 registers; 7- and 8-wave workgroups run two per CU at 4 per SIMD)
+static int att_occ(int which, int W) {
+    static int v[3] = {-1, 0, 0};
+    if (v[0] < 0) {
         const char* e = getenv("SWAT_ATT_OCC");
-        for (int i = 0; i < 3; ++i) v[i] = (e && strlen(e) == 3 && e[i] >= '3' && e[i] <= '7') ? e[i] - '0' : 4;
+        for (int i = 0; i < 3; ++i) v[i] = (e && strlen(e) == 3 && e[i] >= '3' && e[i] <= '7') ? e[i] - '0' : 0;
     }
-    return v[which];
+    return v[which] ? v[which] : (W == 9 ? 3 : 4);
 }
 // experiment knob: SWAT_ATT_W = waves per workgroup (4..9), 0 = the rule below
 static int att_w() {

@@ -239,10 +239,12 @@ def test_attention_one_workgroup_per_head(B, H, T):
 
 
 @pytest.mark.parametrize("B,H,T,causal", [(2, 3, 65, 0), (2, 12, 197, 0), (1, 16, 257, 0), (3, 8, 77, 1), (2, 2, 320, 0), (1, 2, 128, 1),
-                                              (2, 4, 50, 0), (1, 1, 64, 1)])
+                                              (2, 4, 50, 0), (1, 1, 64, 1), (2, 2, 129, 0), (1, 3, 144, 0), (2, 2, 241, 0), (1, 2, 256, 1)])
 def test_attention_tiled(B, H, T, causal):
-    """64 < T <= 320 (ViT-B/16, ViT-L/14, the causal text tower): query-tile workgroups with the running-maximum
-    softmax forward (+ row log-sum-exp), one workgroup per head walking all tile pairs backward; vs torch autograd."""
+    """64 < T <= 320 (ViT-B/16, ViT-L/14, the causal text tower): row-tile workgroups of 4..9 waves over LDS-staged key /
+    query tiles, running-maximum softmax forward (+ row log-sum-exp), dQ per query tile and dK / dV per key tile backward;
+    vs torch autograd.  The T values cover one workgroup per head (<= 144 rows), 8-wave tiles with idle waves (257),
+    exact tiles (256) and a 1-row last fragment (129, 241, 257)."""
     from swat_amd import _lib
     lib = _lib.lib()
     d = 64 * H
@@ -267,6 +269,12 @@ def test_attention_tiled(B, H, T, causal):
     o.backward(do.float())
     ref = torch.cat([g.grad.permute(0, 2, 1, 3).reshape(B * T, d) for g in (q, k, v)], dim=1)
     assert (dqkv.float() - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 1e-3
+    # bit-identical when repeated (and without the lse output): every element is summed by one wave in a fixed order
+    out2, dqkv2 = torch.empty_like(out), torch.empty_like(dqkv)
+    _lib.check(lib.swat_attn_fwd_tiled(_lib.ptr(qkv), _lib.ptr(out2), None, B, T, d, H, causal, _lib.stream()), "swat_attn_fwd_tiled")
+    _lib.check(lib.swat_attn_bwd_tiled(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(do), _lib.ptr(lse), _lib.ptr(dqkv2), B, T, d, H,
+                                       _lib.ptr(ws), _lib.stream()), "swat_attn_bwd_tiled")
+    assert torch.equal(out, out2) and torch.equal(dqkv, dqkv2)
 
 
 @pytest.mark.parametrize("causal", [False, True])

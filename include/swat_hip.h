@@ -118,7 +118,8 @@ int swat_near_dup_marks(const float* feats, int64_t n, int d, float thr, uint8_t
  *     nn.MultiheadAttention matmuls and their autograd (cuBLAS in the reference).
  *     Batched: block z uses offsets (z / inner) * s?0 + (z % inner) * s?1 (elements).
  *     Epilogue: v = alpha*acc (+bias[n]) (+residual[m,n] fp32, may alias C) (*act'(actin[m,n]));
- *     C is bf16 or fp32 (out_f32); C2 (bf16, optional) = act(C) with act 1 = QuickGELU, 2 = erf-GELU.
+ *     C is bf16 or fp32 (out_f32); C2 (bf16, optional) = act(C) with act 1 = QuickGELU, 2 = erf-GELU; C may be NULL with a
+ *     C2: only the activated output is stored (inference: nothing re-reads the pre-activation), same values.
  *     lda/ldb multiples of 8, ldc multiple of 4 and >= roundup(N,4). */
 int swat_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda,
                    int ldb, int ldc, int batch, int inner, int64_t sA0, int64_t sA1, int64_t sB0,

@@ -45,6 +45,11 @@ int swat_vit_mega_status(void);
 /* Per-workgroup phase stamps of the next persistent forwards (64 x uint64 per workgroup, 100 MHz ticks); null = off. */
 int swat_vit_mega_trace(void* device_buffer);
 
+/* swat_adamw's launch shape: 0 = wide (up to 4096 blocks, the fastest alone), n > 0 = n blocks of 256 threads handling four
+ *     16-byte quads per array and trip (n = 256: one block per CU, 4 of its 32 wave slots) so that GEMM workgroups on another
+ *     stream share the CUs with it.  Same arithmetic per element.  Also SWAT_ADAMW_BLOCKS in the environment. */
+int swat_adamw_set_blocks(int blocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -416,44 +416,57 @@ struct AdamSegs {
     int64_t begin[5];
     int n;
 };
+// U quads per thread and trip: U = 1 is the wide form (up to 4096 blocks: fastest alone); U = 4 with ONE block per CU (the "thin"
+// form, swat_adamw_set_blocks) keeps the same bytes in flight per CU from 4 waves instead of 64, so the workgroups of a GEMM on
+// another stream still find wave slots, registers and all of the LDS on every CU — a wide launch occupies every slot for its
+// whole duration and the GEMM behind it simply waits (tools/step_timeline.py: c_fc dgrad 51 us beside it, 14.5 us alone).
+template <int U>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, unsigned short* __restrict__ shadow, int64_t n,
                                                     AdamSegs segs, const float* __restrict__ lrs, float beta1, float beta2,
                                                     float eps, float wd, const float* __restrict__ bc /* [2]: 1-b1^t, 1-b2^t */,
                                                     float grad_scale) {
     const float bc1 = bc[0], sbc2 = sqrtf(bc[1]);
-    const int64_t n4 = n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e = i << 2;
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += U * stride) {
         // every byte is touched once per step: nontemporal accesses keep the stream out of the way of the GEMMs' L2 lines
-        typedef float nt4 __attribute__((ext_vector_type(4)));
-        const nt4 pn = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p) + i);
-        const nt4 gn = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(g) + i);
-        const nt4 mn = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(m) + i);
-        const nt4 vn = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(v) + i);
-        float4 pv = make_float4(pn[0], pn[1], pn[2], pn[3]);
-        const float4 gv = make_float4(gn[0], gn[1], gn[2], gn[3]);
-        float4 mv = make_float4(mn[0], mn[1], mn[2], mn[3]);
-        float4 vv = make_float4(vn[0], vn[1], vn[2], vn[3]);
-        float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
-        float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+        nt4 pn[U], gn[U], mn[U], vn[U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int s = 0;
-#pragma unroll
-            for (int q = 1; q < 4; ++q) s += (q < segs.n && e + k >= segs.begin[q]) ? 1 : 0;
-            const float lr = lrs[s];
-            const float gg = ga[k] * grad_scale;
-            pa[k] *= 1.0f - lr * wd;
-            ma[k] = beta1 * ma[k] + (1.0f - beta1) * gg;
-            va[k] = beta2 * va[k] + (1.0f - beta2) * gg * gg;
-            const float denom = sqrtf(va[k]) / sbc2 + eps;
-            pa[k] -= (lr / bc1) * (ma[k] / denom);
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n4) {
+                pn[u] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p) + i);
+                gn[u] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(g) + i);
+                mn[u] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(m) + i);
+                vn[u] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(v) + i);
+            }
         }
-        __builtin_nontemporal_store((nt4){pa[0], pa[1], pa[2], pa[3]}, reinterpret_cast<nt4*>(p) + i);
-        __builtin_nontemporal_store((nt4){ma[0], ma[1], ma[2], ma[3]}, reinterpret_cast<nt4*>(m) + i);
-        __builtin_nontemporal_store((nt4){va[0], va[1], va[2], va[3]}, reinterpret_cast<nt4*>(v) + i);
-        if (shadow) reinterpret_cast<ushort4*>(shadow)[i] = make_ushort4(f2bf(pa[0]), f2bf(pa[1]), f2bf(pa[2]), f2bf(pa[3]));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n4) break;
+            const int64_t e = i << 2;
+            float pa[4] = {pn[u][0], pn[u][1], pn[u][2], pn[u][3]}, ma[4] = {mn[u][0], mn[u][1], mn[u][2], mn[u][3]};
+            float va[4] = {vn[u][0], vn[u][1], vn[u][2], vn[u][3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int sg = 0;
+#pragma unroll
+                for (int q = 1; q < 4; ++q) sg += (q < segs.n && e + k >= segs.begin[q]) ? 1 : 0;
+                const float lr = lrs[sg];
+                const float gg = gn[u][k] * grad_scale;
+                pa[k] *= 1.0f - lr * wd;
+                ma[k] = beta1 * ma[k] + (1.0f - beta1) * gg;
+                va[k] = beta2 * va[k] + (1.0f - beta2) * gg * gg;
+                const float denom = sqrtf(va[k]) / sbc2 + eps;
+                pa[k] -= (lr / bc1) * (ma[k] / denom);
+            }
+            __builtin_nontemporal_store((nt4){pa[0], pa[1], pa[2], pa[3]}, reinterpret_cast<nt4*>(p) + i);
+            __builtin_nontemporal_store((nt4){ma[0], ma[1], ma[2], ma[3]}, reinterpret_cast<nt4*>(m) + i);
+            __builtin_nontemporal_store((nt4){va[0], va[1], va[2], va[3]}, reinterpret_cast<nt4*>(v) + i);
+            if (shadow) reinterpret_cast<ushort4*>(shadow)[i] = make_ushort4(f2bf(pa[0]), f2bf(pa[1]), f2bf(pa[2]), f2bf(pa[3]));
+        }
     }
 }
 
@@ -651,6 +664,13 @@ SWAT_API int swat_gather_cast_bf16(const float* in, void* out_bf16, int64_t rows
     return check_launch("swat_gather_cast_bf16");
 }
 
+static int g_adamw_blocks = -1;  // > 0: the thin form with this many blocks (swat_adamw_set_blocks / SWAT_ADAMW_BLOCKS)
+SWAT_API int swat_adamw_set_blocks(int blocks) {
+    SWAT_REQUIRE(blocks >= 0 && blocks <= 4096, "swat_adamw_set_blocks: 0 (wide form) or 1..4096 blocks");
+    g_adamw_blocks = blocks;
+    return 0;
+}
+
 SWAT_API int swat_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
                         const int64_t* seg_begin, int n_seg, const float* lrs_dev, float beta1, float beta2, float eps,
                         float weight_decay, const float* bias_corr_dev, float grad_scale, swat_stream_t s) {
@@ -659,9 +679,17 @@ SWAT_API int swat_adamw(float* params, const float* grads, float* exp_avg, float
     AdamSegs segs{};
     segs.n = n_seg;
     for (int i = 0; i < n_seg; ++i) segs.begin[i] = seg_begin[i];
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)s, params, grads, exp_avg,
-                       exp_avg_sq, (unsigned short*)shadow_bf16, n, segs, lrs_dev, beta1, beta2, eps, weight_decay,
-                       bias_corr_dev, grad_scale);
+    if (g_adamw_blocks < 0) {
+        const char* e = getenv("SWAT_ADAMW_BLOCKS");
+        g_adamw_blocks = e ? atoi(e) : 0;
+    }
+    if (g_adamw_blocks > 0 && n / 4 >= (int64_t)g_adamw_blocks * 256 * 4)
+        hipLaunchKernelGGL(adamw_kernel<4>, dim3(g_adamw_blocks), dim3(256), 0, (hipStream_t)s, params, grads, exp_avg, exp_avg_sq,
+                           (unsigned short*)shadow_bf16, n, segs, lrs_dev, beta1, beta2, eps, weight_decay, bias_corr_dev, grad_scale);
+    else
+        hipLaunchKernelGGL(adamw_kernel<1>, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)s, params, grads, exp_avg,
+                           exp_avg_sq, (unsigned short*)shadow_bf16, n, segs, lrs_dev, beta1, beta2, eps, weight_decay,
+                           bias_corr_dev, grad_scale);
     return check_launch("swat_adamw");
 }
 

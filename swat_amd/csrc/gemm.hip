@@ -743,6 +743,13 @@ static int pick_cfg_base(int layout, const GemmArgs& a, int batch) {
     // 77 vs 81 — but out_proj 45 vs 37, c_fc 173 vs 135, c_proj dgrad 177 vs 150; at M = 6 304 it loses everywhere.  Inside
     // the ViT-L/14 step even the four winning shapes cost 1.5 % (968 vs 982 img/s: a 512-thread, 128-KiB workgroup leaves the
     // weight-gradient lane nothing to overlap with).  So it is OPT-IN (swat_gemm_set_exp bit 2048 / SWAT_GEMM_EXP=2048).
+    // tens of thousands of rows (mined-feature extraction encodes 1024 images / captions per batch: M = 51 200 / 78 848): the
+    // 256 x 256 tile's quantisation loss is gone (1 800+ tiles) and it wins every product but out_proj.  Measured per launch
+    // (tools/perf_gemm.py, M = 51 200, d = 768; the previous choice in brackets): in_proj 234 us = 775 TF (303), c_fc 387 (426),
+    // c_proj 292 = 827 TF (332); M = 78 848, d = 512: in_proj 187 (284), c_proj 223 (280).
+    if (a.M >= 32768 && layout == L_NT && !(g_exp & 512) && (a.N >= 1024 || a.K >= 2048) && a.N % 256 == 0 && a.inner == 1 &&
+        a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.actin && a.K >= 512)
+        return 80;
     if ((g_exp & 2048) && many_rows && layout != L_TN && a.M >= 8192 && a.N >= 1024 && a.N % 256 == 0 && a.inner == 1 && a.lda % 8 == 0 &&
         a.ldb % 8 == 0 && !a.C2 && !a.actin && (a.K >= 2048 || (a.K >= 1024 && a.N == 3 * a.K)))
         return 80;
@@ -920,5 +927,7 @@ SWAT_API int swat_gemm_bf16(int layout, const void* A, const void* B, void* C, i
     a.inner = inner; a.sA0 = sA0; a.sA1 = sA1; a.sB0 = sB0; a.sB1 = sB1; a.sC0 = sC0; a.sC1 = sC1;
     a.bias = bias; a.residual = residual; a.actin = (const unsigned short*)actin; a.ldact = ldact; a.act = act;
     a.out_f32 = out_f32; a.alpha = alpha; a.rpg = 0; a.gstride = 0; a.roff = 0; a.rowbias = nullptr;
+    SWAT_REQUIRE(C || (C2 && !out_f32), "swat_gemm_bf16: C may be null only with a bf16 C2 (activated output only)");
+    if (!C) { a.C = C2; a.c2_only = 1; }
     return swat::gemm_dispatch(layout, a, batch, (hipStream_t)stream);
 }

@@ -135,7 +135,7 @@ __device__ __forceinline__ void pc_store_tile(const GemmArgs& p, const float* cl
             u32x4_t pk;
 #pragma unroll
             for (int h = 0; h < 4; ++h) pk[h] = pack_bf16x2(v[2 * h], v[2 * h + 1]);
-            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(p.C) + o) = pk;
+            if (!p.c2_only) *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(p.C) + o) = pk;
             if (p.C2) {  // second output: activation of the ROUNDED pre-activation (what backward re-reads)
                 u32x4_t pk2;
 #pragma unroll
@@ -791,7 +791,7 @@ struct PcgSig {  // EVERY GemmArgs field the kernel reads (GemmArgs has padding 
     int64_t sC0, sC1;
     int M, N, K, lda, ldb, ldc, ldact, act, out_f32, rpg, gstride, roff, epi0, exp;
     float alpha;
-    int pad;
+    int c2_only;
     bool operator==(const PcgSig& o) const { return memcmp(this, &o, sizeof(PcgSig)) == 0; }
 };
 struct PcgEntry {
@@ -842,7 +842,7 @@ int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s
         sig[i].sC0 = a.sC0; sig[i].sC1 = a.sC1;
         sig[i].M = a.M; sig[i].N = a.N; sig[i].K = a.K; sig[i].lda = a.lda; sig[i].ldb = a.ldb; sig[i].ldc = a.ldc;
         sig[i].ldact = a.ldact; sig[i].act = a.act; sig[i].out_f32 = a.out_f32; sig[i].rpg = a.rpg; sig[i].gstride = a.gstride;
-        sig[i].roff = a.roff; sig[i].epi0 = a.epi0; sig[i].exp = a.exp; sig[i].alpha = a.alpha;
+        sig[i].roff = a.roff; sig[i].epi0 = a.epi0; sig[i].exp = a.exp; sig[i].alpha = a.alpha; sig[i].c2_only = a.c2_only;
         const unsigned char* b = reinterpret_cast<const unsigned char*>(&sig[i]);
         for (size_t j = 0; j < sizeof(PcgSig); ++j) key = (key ^ b[j]) * 1099511628211ull;
     }

@@ -15,6 +15,7 @@ struct GemmArgs {
     int64_t sA0, sA1, sB0, sB1, sC0, sC1;
     void* C;                       // primary output (bf16 or f32)
     void* C2;                      // optional second output (bf16): act(C)
+    int c2_only;                   // with C2: do not store C (inference: nothing re-reads the pre-activation)
     const float* bias;             // [N] fp32 or null
     const float* residual;         // [M,N] fp32 (ld = ldc) or null (may alias C)
     const unsigned short* actin;   // [M,N] bf16 (ld = ldact): dgrad through the activation

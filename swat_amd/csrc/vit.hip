@@ -356,6 +356,7 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
         {
             GemmArgs a = G(h2, sh + lo[FCW], f, M, D.mlp, d, d, d, D.mlp, 0);
             a.bias = params + lo[FCB]; a.act = D.act; a.C2 = ga;
+            a.c2_only = !D.save;  // inference: the pre-activation is never re-read
             TRY(gemm_dispatch(L_NT, a, 1, s));
         }
         {
@@ -711,6 +712,7 @@ SWAT_API int swat_transformer_forward(const int32_t* dims, const int64_t* offs, 
         {
             GemmArgs a = G(h, sh + lo[FCW], f, M, D.mlp, d, d, d, D.mlp, 0);
             a.bias = params + lo[FCB]; a.act = D.act; a.C2 = ga;
+            a.c2_only = 1;  // a frozen tower: no backward re-reads the pre-activation
             TRY(gemm_dispatch(L_NT, a, 1, s));
         }
         {

@@ -19,10 +19,11 @@ def _chk(rc, what):
 
 def gemm(layout, A, B, M, N, K, lda, ldb, C, ldc, batch=1, inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
          bias=None, residual=None, actin=None, ldact=0, act=None, C2=None, alpha=1.0):
-    """Raw GEMM entry on explicit pointers/strides; A, B bf16 tensors (any shape), C bf16 or fp32."""
+    """Raw GEMM entry on explicit pointers/strides; A, B bf16 tensors (any shape), C bf16 or fp32 (None with a C2: only the
+    activated output is stored)."""
     rc = _lib.lib().swat_gemm_bf16(layout, _p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, batch, inner,
                                    sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], _p(bias), _p(residual), _p(actin),
-                                   ldact, ACT[act], _p(C2), int(C.dtype == _F32), float(alpha), _lib.stream())
+                                   ldact, ACT[act], _p(C2), int(C is not None and C.dtype == _F32), float(alpha), _lib.stream())
     _chk(rc, "swat_gemm_bf16")
     return C
 

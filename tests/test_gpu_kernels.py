@@ -447,6 +447,27 @@ def test_gemm_every_tile_configuration(cfg, layout):
     close(C, ref, False, K)
 
 
+@pytest.mark.parametrize("cfg", [14, 20, 43, 33, 51, 53])
+def test_gemm_activated_output_only(cfg):
+    """C = NULL with a C2 (the c_fc product of an inference forward): every kernel family stores act(round(pre-activation)) and
+    nothing else — the bits of the two-output form."""
+    from swat_amd import ops, _lib
+    M, N, K = 1600, 3072, 768
+    a = rnd(M, K, seed=51, dtype=BF)
+    w = rnd(N, K, seed=52, scale=0.05, dtype=BF)
+    bias = rnd(N, seed=53)
+    _lib.lib().swat_gemm_set_tile(cfg)
+    try:
+        C = torch.empty(M, N, device=dev(), dtype=BF)
+        C2 = torch.empty(M, N, device=dev(), dtype=BF)
+        ops.gemm(ops.NT, a, w, M, N, K, K, K, C, N, bias=bias, act="quick_gelu", C2=C2)
+        only = torch.full((M, N), float("nan"), device=dev(), dtype=BF)
+        ops.gemm(ops.NT, a, w, M, N, K, K, K, None, N, bias=bias, act="quick_gelu", C2=only)
+        assert torch.equal(only, C2)
+    finally:
+        _lib.lib().swat_gemm_set_tile(-1)
+
+
 @pytest.mark.parametrize("layout", ["nt", "nn"])
 @pytest.mark.parametrize("epi", ["bias_act_c2", "residual_f32", "actin"])
 def test_gemm_256_tile_epilogues_on_many_rows(layout, epi):
@@ -470,6 +491,9 @@ def test_gemm_256_tile_epilogues_on_many_rows(layout, epi):
             close(C.float(), want.float(), True, K)
             wf = want.float()
             close(C2.float(), (C.float() * torch.sigmoid(1.702 * C.float())), True, 8)
+            only = torch.empty(M, N, device=dev(), dtype=BF)   # inference form: C = NULL, only the activated output, same bits
+            ops.gemm(lay, a, B, M, N, K, K, ldb, None, N, bias=bias, act="quick_gelu", C2=only)
+            assert torch.equal(only, C2)
         elif epi == "residual_f32":
             C = rnd(M, N, seed=44)
             res = C.clone()

@@ -5,7 +5,7 @@ import torch
 from swat_amd import ops, _lib
 
 dev = torch.device("cuda:0"); L = _lib.lib()
-M, d = 1600, 768
+M, d = int(os.environ.get("SWAT_PG_M", 1600)), int(os.environ.get("SWAT_PG_D", 768))   # ViT-L/14: 8224 1024; ViT-B/16: 6304 768
 shapes = [  # (name, layout, M, N, K, epilogue)  in the kernel's own (rows, cols, reduction) terms
     ("fwd qkv", ops.NT, M, 3 * d, d, "bias"), ("fwd out", ops.NT, M, d, d, "res"), ("fwd fc", ops.NT, M, 4 * d, d, "fc"), ("fwd proj", ops.NT, M, d, 4 * d, "res"),
     ("dgrad proj->4d", ops.NN, M, 4 * d, d, "actin"), ("dgrad fc->d", ops.NN, M, d, 4 * d, "bf16"), ("dgrad out", ops.NN, M, d, d, "bf16"), ("dgrad qkv->d", ops.NN, M, d, 3 * d, "bf16"),

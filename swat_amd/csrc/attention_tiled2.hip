@@ -404,20 +404,18 @@ static void tiled2_shape(int T, int& W, int& tiles) {
 #define SWAT_ATT2(KERN, WHICH, ...)                                                                     \
     switch (att_occ(WHICH, W)) {                                                                           \
         case 3: SWAT_ATT2W(KERN, 3, __VA_ARGS__) break;                                                 \
-        case 4: SWAT_ATT2W(KERN, 4, __VA_ARGS__) break;                                                 \
-        case 5: SWAT_ATT2W(KERN, 5, __VA_ARGS__) break;                                                 \
-        case 6: SWAT_ATT2W(KERN, 6, __VA_ARGS__) break;                                                 \
-        default: SWAT_ATT2W(KERN, 7, __VA_ARGS__) break;                                                \
+        default: SWAT_ATT2W(KERN, 4, __VA_ARGS__) break;                                                \
     }
 
-// experiment knob: SWAT_ATT_OCC = three digits (forward, dQ, dK/dV): waves per SIMD the kernels are compiled for
+// tuning knob: SWAT_ATT_OCC = three digits (forward, dQ, dK/dV), each 3 or 4: waves per SIMD the kernels are compiled for
+// (5-7 were measured too: the register limit spills and every kernel loses 10-60 %)
 // (default: a 9-wave workgroup puts 3 waves on one SIMD and a second one never fits beside it below 5 per SIMD, so it may as
 // well have 168 registers; 7- and 8-wave workgroups run two per CU at 4 per SIMD)
 static int att_occ(int which, int W) {
     static int v[3] = {-1, 0, 0};
     if (v[0] < 0) {
         const char* e = getenv("SWAT_ATT_OCC");
-        for (int i = 0; i < 3; ++i) v[i] = (e && strlen(e) == 3 && e[i] >= '3' && e[i] <= '7') ? e[i] - '0' : 0;
+        for (int i = 0; i < 3; ++i) v[i] = (e && strlen(e) == 3 && e[i] >= '3' && e[i] <= '4') ? e[i] - '0' : 0;
     }
     return v[which] ? v[which] : (W == 9 ? 3 : 4);
 }

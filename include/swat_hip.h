@@ -93,6 +93,17 @@ int swat_dense_pack_queries(const float* queries, int n_q, int d, void* packed, 
 int swat_sim_candidates_packed(const void* packed, int n_q, const float* db, int64_t n_db, int d,
                                const float* thr_dev, int64_t row_base, void* cand_keys, int cap, void* cand_cnt,
                                float* max_norm2, void* workspace, int64_t workspace_bytes, swat_stream_t stream);
+/*     The same pass over a bf16 SHADOW of the shard, built once per index (the reference keeps the fp32 matrix of mined.pth in
+ *     memory for every class query, retrieval/sample_retrieval.py:1387-1415; this is its scan-side image): rows rounded to bf16
+ *     once and stored in the scan's fragment order, swat_dense_shadow_bytes(n_db, d) = 2 n_db d bytes (0: d not supported).
+ *     swat_dense_build_shadow also leaves max |row|^2 of the fp32 rows in *max_norm2 (zero it first).  The candidate lists are
+ *     those of swat_sim_candidates_packed bit for bit (same roundings, same order of accumulation) from half the HBM bytes;
+ *     the exact re-scoring and the completeness proof still read the fp32 rows. */
+int64_t swat_dense_shadow_bytes(int64_t n_db, int d);
+int swat_dense_build_shadow(const float* db, int64_t n_db, int d, void* shadow, float* max_norm2, swat_stream_t stream);
+int swat_sim_candidates_shadow(const void* packed, int n_q, const void* shadow, int64_t n_db, int d, const float* thr_dev,
+                               int64_t row_base, void* cand_keys, int cap, void* cand_cnt, void* workspace,
+                               int64_t workspace_bytes, swat_stream_t stream);
 /*     sort each query's candidates, emit the (value desc, row asc) top-k (cap <= 8192). */
 int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k,
                          int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);

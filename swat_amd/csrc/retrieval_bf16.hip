@@ -225,6 +225,10 @@ template <int N_>
 __device__ __forceinline__ void rb_wait_lgkm() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_) : "memory");
 }
+template <int N_>
+__device__ __forceinline__ void rb_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
 __device__ __forceinline__ void rb_pin(rb_bf16x8_t& v) { asm volatile("" : "+v"(v)); }
 
 // The deep form (d % (32 D) == 0): 32-deep steps, database registers D steps ahead (a ring of D register sets, the step loop
@@ -233,7 +237,11 @@ __device__ __forceinline__ void rb_pin(rb_bf16x8_t& v) { asm volatile("" : "+v"(
 // of step s "at most LPS + 4 outstanding" (the database loads of steps s-2+D and s-1+D and the query pieces of step s+1) means
 // the query pieces of step s and the database registers of step s have landed while up to D-1 steps of database rows stay in
 // flight.  Past the end of the stream the same loads are re-issued on the last position, which keeps the counts uniform.
-template <int NQT, int D, int WAVES, int ABL = 0>  // WAVES x 16 database rows per block share one query chunk.   ABL: timing ablations (tuning only; results are wrong): 1 no MFMA, 2 no query DMA, 4 no barrier
+// DB16: the database operand is the bf16 SHADOW of the index (dense_shadow_kernel: rows rounded once, each 32-k chunk stored in the
+// scan's own k order, so a lane's fragment is ONE 16-byte load) — half the HBM bytes per row; the row norms come from the build.
+// KD (shadow only): 32-k chunks per step.  KD = 2 halves the barriers and counted waits per row (timing ablations of the shadow scan,
+// 0.485 ms: no barrier 0.326, no query DMA 0.365, no MFMA / LDS reads 0.277, no candidates 0.410, none of them 0.220 = the HBM stream).
+template <int NQT, int D, int WAVES, int ABL = 0, bool DB16 = false, int KD = 1>  // WAVES x 16 database rows per block share one query chunk.   ABL: timing ablations (tuning only; results are wrong): 1 no MFMA, 2 no query DMA, 4 no barrier
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates_bf16_deep_kernel(const unsigned short* __restrict__ qp, int n_tiles, int n_q, int q0,
                                                                           const float* __restrict__ db, int64_t n_db, int d,
                                                                           const float* __restrict__ thr, int64_t row_base,
@@ -247,12 +255,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
     constexpr int BR = 16 * WAVES;           // database rows per block
     static_assert(LPS <= 4, "counted waits cover up to four pieces per wave");
     constexpr int RING = 4;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * QBYTES];
+    static_assert(KD == 1 || (DB16 && KD == 2), "two chunks per step: the shadow scan only");
+    constexpr int STAGE = KD * QBYTES;       // LDS bytes of one step's query chunks
+    constexpr int DBL = (DB16 && KD == 1) ? 1 : 2;  // database loads per step
+    extern __shared__ __attribute__((aligned(1024))) unsigned char rb_dyn_smem[];   // KD = 2: 4 x 2 x 13 KiB is past the static limit
+    __shared__ __attribute__((aligned(1024))) unsigned char rb_st_smem[KD == 1 ? RING * QBYTES : 1024];
+    unsigned char* const smem = KD == 1 ? rb_st_smem : rb_dyn_smem;
     __shared__ float sthr[QROWS];  // thresholds of this pass's queries: the block epilogue's common path issues no memory op
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int nchunk = d >> 5;
+    const int nchunk = (d >> 5) / KD;  // steps per row block
     const int64_t nblocks = (n_db + BR - 1) / BR;
     if ((int64_t)blockIdx.x >= nblocks) return;
     if (tid < QROWS) sthr[tid] = q0 + tid < n_q ? thr[q0 + tid] : INFINITY;  // visible after the first step's barrier
@@ -273,18 +286,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
     const size_t chunk_stride = (size_t)n_tiles * 1024;
     auto issue_q = [&](int buf, int c) {
 #pragma unroll
-        for (int i = 0; i < LPS; ++i)
-            if (i < my_lps) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + c * chunk_stride + qdst[i] + lane16),
-                                             (__attribute__((address_space(3))) void*)(smem + buf * QBYTES + qdst[i]), 16, 0, 0);
+        for (int h = 0; h < KD; ++h)
+#pragma unroll
+            for (int i = 0; i < LPS; ++i)
+                if (i < my_lps) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + (size_t)(KD * c + h) * chunk_stride + qdst[i] + lane16),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * STAGE + h * QBYTES + qdst[i]), 16, 0, 0);
     };
     // database fragment of a step: lane reads k = 32 c + 8 g .. + 7 of row blk * BR + wave * 16 + r16 (16 rows x 128 B lines):
     // a scalar base (block, chunk) + one constant 32-bit lane offset; the last, partial block clamps its rows to n_db - 1
     const unsigned row_in_blk = (unsigned)(wave * 16 + r16);
-    const unsigned voff = (row_in_blk * (unsigned)d + 4u * g) * 4u;  // k 4g..4g+3 (and +16 below): 64 contiguous bytes per row and instruction
+    constexpr unsigned EB = DB16 ? 2u : 4u;  // bytes per database element; a 32-k chunk of a row is 128 B (fp32) / 64 B (shadow)
+    const unsigned voff = DB16 ? row_in_blk * (unsigned)d * 2u + 16u * g : (row_in_blk * (unsigned)d + 4u * g) * 4u;  // fp32: k 4g..4g+3 (and +16 below): 64 contiguous bytes per row and instruction; shadow: 16-B unit g of the chunk
     const int64_t last_blk = nblocks - 1;
     const unsigned last_rows = (unsigned)(n_db - last_blk * BR);  // 1 .. BR
-    const unsigned voff_last = ((row_in_blk < last_rows ? row_in_blk : last_rows - 1) * (unsigned)d + 4u * g) * 4u;
-    const size_t blk_bytes = (size_t)BR * d * 4;
+    const unsigned lrow = row_in_blk < last_rows ? row_in_blk : last_rows - 1;
+    const unsigned voff_last = DB16 ? lrow * (unsigned)d * 2u + 16u * g : (lrow * (unsigned)d + 4u * g) * 4u;
+    const size_t blk_bytes = (size_t)BR * d * EB;
     rb_f32x4_t nx[D][2];
     const unsigned qr = (unsigned)(r16 * 64 + ((g ^ ((r16 >> 2) & 3)) << 4));
     const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
@@ -307,10 +324,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
     // database loads are inline asm: the compiler's own bookkeeping would drain the queue (vmcnt(0)) at every use because it
     // cannot count across the loop's merges; the registers are handed to the compiler by the pin behind the counted wait
     auto load_db = [&](rb_f32x4_t (&dst)[2]) {
-        const char* base = reinterpret_cast<const char*>(db) + lblk * blk_bytes + (size_t)lc * 128;  // uniform
+        const char* base = reinterpret_cast<const char*>(db) + lblk * blk_bytes + (size_t)lc * (32 * EB * KD);  // uniform
         const unsigned off = lblk == last_blk ? voff_last : voff;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0]) : "v"(off), "s"(base));
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(dst[1]) : "v"(off), "s"(base));
+        if constexpr (DBL == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(dst[1]) : "v"(off), "s"(base));  // fp32: k + 16; shadow: the next chunk
         next_l();
     };
     load_db(nx[0]);
@@ -320,40 +337,57 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
     for (int64_t s0 = 0; s0 < steps; s0 += D) {
         rb_static_for<D>([&](auto R) {
             constexpr int r = decltype(R)::value;
+            // two steps of database loads and the next step's query pieces may stay in flight behind this wait
             if (s0 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first D steps drain the prologue
-            else if ((ABL & 2) || my_lps == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (LPS == 1 || my_lps == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else if (LPS == 2 || my_lps == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (LPS == 3 || my_lps == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if ((ABL & 2) || my_lps == 0) rb_wait_vm<2 * DBL>();
+            else if (LPS == 1 || my_lps == 1) rb_wait_vm<2 * DBL + KD>();
+            else if (LPS == 2 || my_lps == 2) rb_wait_vm<2 * DBL + 2 * KD>();
+            else if (LPS == 3 || my_lps == 3) rb_wait_vm<2 * DBL + 3 * KD>();
+            else rb_wait_vm<2 * DBL + 4 * KD>();
             if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
-            asm volatile("" : "+v"(nx[r][0]), "+v"(nx[r][1])::"memory");  // landed: the counted wait above covers them
-            const rb_f32x4_t a = nx[r][0], b = nx[r][1];
-            ss = fmaf(a[0], a[0], ss); ss = fmaf(a[1], a[1], ss); ss = fmaf(a[2], a[2], ss); ss = fmaf(a[3], a[3], ss);
-            ss = fmaf(b[0], b[0], ss); ss = fmaf(b[1], b[1], ss); ss = fmaf(b[2], b[2], ss); ss = fmaf(b[3], b[3], ss);
-            unsigned w0 = pack_bf16x2(a[0], a[1]), w1 = pack_bf16x2(a[2], a[3]), w2 = pack_bf16x2(b[0], b[1]), w3 = pack_bf16x2(b[2], b[3]);
+            unsigned w0, w1, w2, w3;
+            unsigned x0 = 0u, x1 = 0u, x2 = 0u, x3 = 0u;  // KD = 2: the second chunk's fragment
+            if constexpr (DB16) {
+                asm volatile("" : "+v"(nx[r][0])::"memory");  // landed: the counted wait above covers it
+                const rb_f32x4_t a = nx[r][0];
+                w0 = __float_as_uint(a[0]); w1 = __float_as_uint(a[1]); w2 = __float_as_uint(a[2]); w3 = __float_as_uint(a[3]);
+                if constexpr (KD == 2) {
+                    asm volatile("" : "+v"(nx[r][1])::"memory");
+                    const rb_f32x4_t b = nx[r][1];
+                    x0 = __float_as_uint(b[0]); x1 = __float_as_uint(b[1]); x2 = __float_as_uint(b[2]); x3 = __float_as_uint(b[3]);
+                    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)::"memory");
+                }
+            } else {
+                asm volatile("" : "+v"(nx[r][0]), "+v"(nx[r][1])::"memory");  // landed: the counted wait above covers them
+                const rb_f32x4_t a = nx[r][0], b = nx[r][1];
+                ss = fmaf(a[0], a[0], ss); ss = fmaf(a[1], a[1], ss); ss = fmaf(a[2], a[2], ss); ss = fmaf(a[3], a[3], ss);
+                ss = fmaf(b[0], b[0], ss); ss = fmaf(b[1], b[1], ss); ss = fmaf(b[2], b[2], ss); ss = fmaf(b[3], b[3], ss);
+                w0 = pack_bf16x2(a[0], a[1]); w1 = pack_bf16x2(a[2], a[3]); w2 = pack_bf16x2(b[0], b[1]); w3 = pack_bf16x2(b[2], b[3]);
+            }
             // the registers of this step are consumed HERE, before the loads below are issued: a use behind them would have to
             // wait for the youngest load (the compiler cannot count across the LDS-DMA pieces and drains the queue)
             asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(ss)::"memory");
             const uint4 u = make_uint4(w0, w1, w2, w3);
             const rb_bf16x8_t dfr = __builtin_bit_cast(rb_bf16x8_t, u);
+            const rb_bf16x8_t dfr1 = __builtin_bit_cast(rb_bf16x8_t, make_uint4(x0, x1, x2, x3));
             // step s + 2's query chunk (its buffer was last read in step s - 2: everyone is past that), step s + D's rows
             if constexpr (!(ABL & 2)) { issue_q((r + 2) & 3, qc); next_q(); }
             load_db(nx[r]);
             // NQT fragment reads, QD in flight: read t + QD reuses the register of tile t behind its MFMA
-            constexpr int QD = NQT < 4 ? NQT : 4;
-            const unsigned qs = lds_base + (unsigned)((r & 3) * QBYTES) + qr;
+            constexpr int NV = KD * NQT;  // fragment v: chunk v / NQT of the step, query tile v % NQT — 1 KiB apart in the stage buffer
+            constexpr int QD = NV < 4 ? NV : 4;
+            const unsigned qs = lds_base + (unsigned)((r & 3) * STAGE) + qr;
             rb_bf16x8_t qf[QD];
             if constexpr (ABL & 1) {
                 acc[r % NQT][0] += __builtin_bit_cast(float, u.x ^ u.y ^ u.z ^ u.w);
             } else {
             rb_static_for<QD>([&](auto T) { qf[decltype(T)::value] = rb_lds_b128<decltype(T)::value * 1024>(qs); });
-            rb_static_for<NQT>([&](auto T) {
+            rb_static_for<NV>([&](auto T) {
                 constexpr int t = decltype(T)::value;
-                rb_wait_lgkm<(NQT - 1 - t < QD - 1 ? NQT - 1 - t : QD - 1)>();
+                rb_wait_lgkm<(NV - 1 - t < QD - 1 ? NV - 1 - t : QD - 1)>();
                 rb_pin(qf[t % QD]);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, qf[t % QD], acc[t], 0, 0, 0);
-                if constexpr (t + QD < NQT) qf[t % QD] = rb_lds_b128<(t + QD) * 1024>(qs);
+                acc[t % NQT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t < NQT ? dfr : dfr1, qf[t % QD], acc[t % NQT], 0, 0, 0);
+                if constexpr (t + QD < NV) qf[t % QD] = rb_lds_b128<(t + QD) * 1024>(qs);
             });
             }
             if constexpr (r == D - 1) {  // nchunk % D == 0: a block can only end on the last step of the unrolled group
@@ -407,10 +441,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
     // the re-issued tail pieces must land before the LDS is handed back, and the tail's database registers stay reserved
     // until their loads have landed
 #pragma unroll
-    for (int r = 0; r < D; ++r) asm volatile("s_waitcnt vmcnt(0)" ::"v"(nx[r][0]), "v"(nx[r][1]) : "memory");
+    for (int r = 0; r < D; ++r) {
+        if constexpr (DBL == 1) asm volatile("s_waitcnt vmcnt(0)" ::"v"(nx[r][0]) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::"v"(nx[r][0]), "v"(nx[r][1]) : "memory");
+    }
     norm2_max = wave_max(norm2_max);
     if (lane == 0) {
-        atomicMax(max_norm2_bits, __float_as_uint(norm2_max));
+        if constexpr (!DB16) atomicMax(max_norm2_bits, __float_as_uint(norm2_max));
         stage_cnt[wave_slot] = wcount;  // may exceed stage_cap: the regroup pass reports the overflow
     }
 }
@@ -478,6 +515,30 @@ __global__ void pack_queries_kernel(const float* __restrict__ q, int n_q, int d,
         v = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
     }
     *reinterpret_cast<uint4*>(out + unit * 8) = v;
+}
+
+// bf16 shadow of the database for the candidate scan (built once per index): row r, 32-k chunk c, 16-B unit g holds
+// k = 32c + {4g..4g+3, 16+4g..16+4g+3} rounded to nearest even — exactly the fragment lane (r16, g) of the scan builds from the
+// fp32 row, so the approximate scores are bit-identical to the fp32-database scan.  One wave per row; the wave also leaves
+// max |row|^2 (fp32, lane-strided partial sums + a fixed xor tree: deterministic) for the completeness proof.
+__global__ __launch_bounds__(256) void dense_shadow_kernel(const float* __restrict__ db, int64_t n_db, int d, uint4* __restrict__ out,
+                                                           unsigned* __restrict__ max_norm2_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_db) return;
+    const int units = d >> 3;  // 16-B output units per row
+    const float* src = db + row * d;
+    float ss = 0.f;
+    for (int u = lane; u < units; u += 64) {
+        const int c = u >> 2, g = u & 3;
+        const float4 a = *reinterpret_cast<const float4*>(src + 32 * c + 4 * g), b = *reinterpret_cast<const float4*>(src + 32 * c + 16 + 4 * g);
+        ss = fmaf(a.x, a.x, ss); ss = fmaf(a.y, a.y, ss); ss = fmaf(a.z, a.z, ss); ss = fmaf(a.w, a.w, ss);
+        ss = fmaf(b.x, b.x, ss); ss = fmaf(b.y, b.y, ss); ss = fmaf(b.z, b.z, ss); ss = fmaf(b.w, b.w, ss);
+        out[row * units + u] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (lane == 0) atomicMax(max_norm2_bits, __float_as_uint(ss));
 }
 
 }  // namespace swat
@@ -553,10 +614,10 @@ SWAT_API int64_t swat_dense_workspace_bytes(int n_q) {
 
 // Candidate pass, deep form (d % 128 == 0, n_q <= 4096): as swat_sim_candidates_bf16 with the queries given as the packed
 // image and a workspace of swat_dense_workspace_bytes(n_q) bytes for the per-wave staging of the candidate records.
-SWAT_API int swat_sim_candidates_packed(const void* packed, int n_q, const float* db, int64_t n_db, int d, const float* thr_dev,
-                                        int64_t row_base, void* cand_keys, int cap, void* cand_cnt, float* max_norm2,
-                                        void* workspace, int64_t workspace_bytes, swat_stream_t s) {
-    SWAT_REQUIRE(packed && db && thr_dev && cand_keys && cand_cnt && max_norm2 && workspace, "swat_sim_candidates_packed: null pointer");
+static int dense_candidates_packed(const void* packed, int n_q, const float* db, bool shadow, int64_t n_db, int d, const float* thr_dev,
+                                   int64_t row_base, void* cand_keys, int cap, void* cand_cnt, float* max_norm2,
+                                   void* workspace, int64_t workspace_bytes, swat_stream_t s) {
+    SWAT_REQUIRE(packed && db && thr_dev && cand_keys && cand_cnt && (max_norm2 || shadow) && workspace, "swat_sim_candidates_packed: null pointer");
     SWAT_REQUIRE(n_q <= 4096, "swat_sim_candidates_packed: n_q=%d above 4096", n_q);
     SWAT_REQUIRE(workspace_bytes >= swat_dense_workspace_bytes(n_q), "swat_sim_candidates_packed: workspace of %lld bytes is too small",
                  (long long)workspace_bytes);
@@ -570,9 +631,24 @@ SWAT_API int swat_sim_candidates_packed(const void* packed, int n_q, const float
     hipStream_t st = (hipStream_t)s;
     const int n_tiles = dense_tiles(n_q);
     static const int abl = getenv("SWAT_DENSE_ABL") ? atoi(getenv("SWAT_DENSE_ABL")) : 0;  // tuning: timing ablations, wrong results
+    static const int kd = getenv("SWAT_DENSE_KD") ? atoi(getenv("SWAT_DENSE_KD")) : 2;  // tuning: 32-k chunks per step of the shadow scan
     static const int waves = getenv("SWAT_DENSE_WAVES") ? atoi(getenv("SWAT_DENSE_WAVES")) : 12;  // tuning: 4 = 64-row blocks, 3 workgroups per CU
 #define SWAT_CAND_DEEP(NQT_, ABL_)                                                                                       \
-    if (waves == 12) {                                                                                                   \
+    if (shadow && d % 256 == 0 && kd == 2) {                                                                             \
+        const int64_t nblocks = (n_db + 191) / 192;                                                                      \
+        const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);                                                 \
+        auto kern = sim_candidates_bf16_deep_kernel<NQT_, 4, 12, ABL_, true, 2>;                                         \
+        const int lds = 4 * 2 * 16 * NQT_ * 64;                                                                          \
+        SWAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, st, (const unsigned short*)packed, n_tiles, n_q, q0, db,    \
+                           n_db, d, thr_dev, row_base, stage, stage_cap, stage_cnt, (unsigned*)max_norm2);               \
+    } else if (shadow) {                                                                                                 \
+        const int64_t nblocks = (n_db + 191) / 192;                                                                      \
+        const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);                                                 \
+        hipLaunchKernelGGL((sim_candidates_bf16_deep_kernel<NQT_, 4, 12, ABL_, true>), dim3(grid), dim3(768), 0, st,     \
+                           (const unsigned short*)packed, n_tiles, n_q, q0, db, n_db, d, thr_dev, row_base, stage,       \
+                           stage_cap, stage_cnt, (unsigned*)max_norm2);                                                  \
+    } else if (waves == 12) {                                                                                            \
         const int64_t nblocks = (n_db + 191) / 192;                                                                      \
         const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);                                                 \
         hipLaunchKernelGGL((sim_candidates_bf16_deep_kernel<NQT_, 4, 12, ABL_>), dim3(grid), dim3(768), 0, st,           \
@@ -609,4 +685,35 @@ SWAT_API int swat_sim_candidates_packed(const void* packed, int n_q, const float
     hipLaunchKernelGGL(regroup_candidates_kernel, dim3(kDenseSlots / 16), dim3(256), 3 * n_q * sizeof(unsigned), st, stage, stage_cap,
                        stage_cnt, kDenseSlots, (unsigned long long*)cand_keys, cap, (unsigned*)cand_cnt, n_q);
     return check_launch("swat_sim_candidates_packed");
+}
+
+SWAT_API int swat_sim_candidates_packed(const void* packed, int n_q, const float* db, int64_t n_db, int d, const float* thr_dev,
+                                        int64_t row_base, void* cand_keys, int cap, void* cand_cnt, float* max_norm2,
+                                        void* workspace, int64_t workspace_bytes, swat_stream_t s) {
+    return dense_candidates_packed(packed, n_q, db, false, n_db, d, thr_dev, row_base, cand_keys, cap, cand_cnt, max_norm2, workspace,
+                                   workspace_bytes, s);
+}
+
+// The bf16 shadow of a database shard (see dense_shadow_kernel): bytes, the build (also max |row|^2 of the fp32 rows into
+// *max_norm2, which the caller zeroes first), and the candidate pass that scans the shadow instead of the fp32 rows — same
+// candidate lists bit for bit (same roundings), half the HBM bytes per row.
+SWAT_API int64_t swat_dense_shadow_bytes(int64_t n_db, int d) {
+    if (n_db <= 0 || d <= 0 || d % 128 != 0) return 0;
+    return n_db * d * 2;
+}
+
+SWAT_API int swat_dense_build_shadow(const float* db, int64_t n_db, int d, void* shadow, float* max_norm2, swat_stream_t s) {
+    SWAT_REQUIRE(db && shadow && max_norm2, "swat_dense_build_shadow: null pointer");
+    SWAT_REQUIRE(n_db > 0 && d > 0 && d % 128 == 0, "swat_dense_build_shadow: d=%d must be a multiple of 128", d);
+    SWAT_REQUIRE((n_db + 3) / 4 < (1ll << 31), "swat_dense_build_shadow: too many rows for one launch");
+    hipLaunchKernelGGL(dense_shadow_kernel, dim3((unsigned)((n_db + 3) / 4)), dim3(256), 0, (hipStream_t)s, db, n_db, d, (uint4*)shadow,
+                       (unsigned*)max_norm2);
+    return check_launch("swat_dense_build_shadow");
+}
+
+SWAT_API int swat_sim_candidates_shadow(const void* packed, int n_q, const void* shadow, int64_t n_db, int d, const float* thr_dev,
+                                        int64_t row_base, void* cand_keys, int cap, void* cand_cnt, void* workspace,
+                                        int64_t workspace_bytes, swat_stream_t s) {
+    return dense_candidates_packed(packed, n_q, (const float*)shadow, true, n_db, d, thr_dev, row_base, cand_keys, cap, cand_cnt, nullptr,
+                                   workspace, workspace_bytes, s);
 }

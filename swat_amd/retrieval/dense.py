@@ -117,10 +117,40 @@ def _prepared(db, queries, k, sample):
     return _cache
 
 
-def candidates(c, db, row_base=0):
+class DenseShadow:
+    """bf16 image of a database shard for the candidate scan, built ONCE per index (csrc/retrieval_bf16.hip
+    dense_shadow_kernel): rows rounded to bf16 in the scan's fragment order + max |row|^2 of the fp32 rows.  topk_dense(...,
+    shadow=...) then streams 2 d bytes per row instead of 4 d and returns the same lists bit for bit (same roundings); the exact
+    re-scoring and the completeness proof keep reading the fp32 rows.  Costs half the shard's bytes again in HBM.  Tied to the
+    database tensor OBJECT and its version: an in-place update of the rows makes `matches` false and the fp32 scan answers."""
+
+    def __init__(self, db):
+        import weakref
+        assert db.dtype == torch.float32 and db.is_cuda and db.is_contiguous()
+        n, d = db.shape
+        nbytes = int(_lib.lib().swat_dense_shadow_bytes(n, d))
+        if nbytes == 0:
+            raise _lib.SwatHipError(f"DenseShadow: width {d} is not a multiple of 128 (the deep candidate kernel's shapes)")
+        self.rows = torch.empty(nbytes, dtype=torch.uint8, device=db.device)
+        self.n2 = torch.zeros(1, dtype=torch.float32, device=db.device)
+        _lib.check(_lib.lib().swat_dense_build_shadow(_lib.ptr(db), n, d, _lib.ptr(self.rows), _lib.ptr(self.n2), _lib.stream()),
+                   "swat_dense_build_shadow")
+        self._ref, self._key = weakref.ref(db), (db.data_ptr(), tuple(db.shape), db._version)
+
+    def matches(self, db):
+        return self._ref() is db and self._key == (db.data_ptr(), tuple(db.shape), db._version)
+
+
+def candidates(c, db, row_base=0, shadow=None):
     """The candidate pass on prepared buffers c (= _prepared(...)): appends to c["keys"] / c["cnt"], max |row|^2 to c["n2"]."""
     L = _lib.lib()
     nq = c["cnt"].numel()
+    if shadow is not None and c["ws"] is not None:
+        _lib.check(L.swat_sim_candidates_shadow(_lib.ptr(c["qb"]), nq, _lib.ptr(shadow.rows), db.shape[0], db.shape[1], _lib.ptr(c["thr"]),
+                                                int(row_base), _lib.ptr(c["keys"]), CAP, _lib.ptr(c["cnt"]), _lib.ptr(c["ws"]),
+                                                c["ws"].numel(), _lib.stream()), "swat_sim_candidates_shadow")
+        c["n2"].copy_(shadow.n2)
+        return
     args = (_lib.ptr(c["qb"]), nq, _lib.ptr(db), db.shape[0], db.shape[1], _lib.ptr(c["thr"]), int(row_base), _lib.ptr(c["keys"]), CAP,
             _lib.ptr(c["cnt"]), _lib.ptr(c["n2"]))
     if c["ws"] is not None:
@@ -134,9 +164,9 @@ BIG = 1 << 62
 last_path = None  # which route the last topk_dense call took (tests, bench.py)
 
 
-def topk_dense(db, queries, k, row_base=0, sample=16384):
+def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
     """-> (idx [n_q, k] int64 global rows (-1 padded), val [n_q, k] fp32, cnt [n_q]) in (value desc, row asc) order;
-    values and indices are those of the exact scan (oracle order), bit for bit."""
+    values and indices are those of the exact scan (oracle order), bit for bit.  shadow: a DenseShadow of db (optional)."""
     assert db.dtype == torch.float32 and queries.dtype == torch.float32 and k <= CAP
     n, d = db.shape
     nq = queries.shape[0]
@@ -152,7 +182,9 @@ def topk_dense(db, queries, k, row_base=0, sample=16384):
     L = _lib.lib()
     cnt.zero_()
     n2.zero_()
-    candidates(c, db, row_base)
+    if shadow is not None and not shadow.matches(db):
+        shadow = None  # built from other rows (or the rows changed in place): the fp32 scan answers
+    candidates(c, db, row_base, shadow)
     idx2, val2, cnt2, keys2 = c["idx2"], c["val2"], c["cnt2"], c["keys2"]
     _lib.check(L.swat_candidates_topk(_lib.ptr(keys), CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2),
                                       _lib.stream()), "swat_candidates_topk")
@@ -172,7 +204,7 @@ def topk_dense(db, queries, k, row_base=0, sample=16384):
     if c["fails"].item() != 0:  # the one host synchronisation of the call
         last_path = "exact-fallback"
         return topk_dense_exact(db, queries, k, row_base, sample)
-    last_path = "bf16-candidates+exact-rescore"
+    last_path = "bf16-shadow-candidates+exact-rescore" if shadow is not None and c["ws"] is not None else "bf16-candidates+exact-rescore"
     return idx, val, out_cnt
 
 

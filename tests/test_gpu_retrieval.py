@@ -204,6 +204,22 @@ def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale, d):
     # second call: cached thresholds / bf16 queries, same answer; an in-place change of the queries invalidates the cache
     idx2, val2, _ = dense.topk_dense(d_db, d_q, k, row_base=1000)
     assert torch.equal(idx2, idx) and torch.equal(val2, val)
+    if d % 128 == 0:
+        # the bf16 shadow of the shard (half the bytes per row): the same candidate lists bit for bit, hence the same answer
+        sh = dense.DenseShadow(d_db)
+        c = dense._prepared(d_db, d_q, k, 16384)
+        c["cnt"].zero_(); dense.candidates(c, d_db, 1000)
+        n_f32 = c["cnt"].clone(); keys_f32 = torch.sort(c["keys"][0, :int(n_f32[0])]).values.clone(); n2_f32 = c["n2"].clone()
+        c["cnt"].zero_(); c["n2"].zero_(); dense.candidates(c, d_db, 1000, shadow=sh)
+        assert torch.equal(c["cnt"], n_f32) and torch.equal(torch.sort(c["keys"][0, :int(n_f32[0])]).values, keys_f32)
+        assert abs(c["n2"].item() - n2_f32.item()) <= 1e-5 * n2_f32.item()
+        idx4, val4, cnt4 = dense.topk_dense(d_db, d_q, k, row_base=1000, shadow=sh)
+        assert dense.last_path == "bf16-shadow-candidates+exact-rescore"
+        assert torch.equal(idx4, e_idx) and torch.equal(val4, e_val) and torch.equal(cnt4, e_cnt)
+        d_db[0].mul_(1.0)  # an in-place write to the rows: the shadow no longer vouches for them, the fp32 scan answers
+        assert not sh.matches(d_db)
+        dense.topk_dense(d_db, d_q, k, row_base=1000, shadow=sh)
+        assert dense.last_path == "bf16-candidates+exact-rescore"
     d_q.mul_(-1.0)
     idx3, val3, _ = dense.topk_dense(d_db, d_q, k, row_base=1000)
     e3_idx, e3_val, _ = dense.topk_dense_exact(d_db, d_q, k, row_base=1000)

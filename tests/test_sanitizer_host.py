@@ -16,6 +16,9 @@ LIB = os.path.join(HERE, "..", "swat_amd", "lib", "libswat_hip_asan.so")
 def test_host_side_under_asan_ubsan():
     if not os.path.exists(LIB):
         pytest.skip("libswat_hip_asan.so not built (tools/build_asan.sh)")
+    srcs = glob.glob(os.path.join(HERE, "..", "swat_amd", "csrc", "*.h*")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    if max(os.path.getmtime(f) for f in srcs) > os.path.getmtime(LIB):
+        pytest.skip("libswat_hip_asan.so is older than the sources: rebuild it with tools/build_asan.sh")
     rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
     if not rt:
         pytest.skip("no libclang_rt.asan in this toolchain")

@@ -10,19 +10,20 @@ g = torch.Generator(device=dev).manual_seed(7)
 db = torch.randn(n, d, device=dev, generator=g); db /= db.norm(dim=-1, keepdim=True)
 q = torch.randn(nq, d, device=dev, generator=g); q /= q.norm(dim=-1, keepdim=True)
 def ev(): return torch.cuda.Event(enable_timing=True)
-dense.topk_dense(db, q, k); torch.cuda.synchronize()
+SH = dense.DenseShadow(db) if os.environ.get("SWAT_DENSE_SHADOW", "1") != "0" else None
+dense.topk_dense(db, q, k, shadow=SH); torch.cuda.synchronize()
 print("route:", dense.last_path, "| SWAT_DENSE_WAVES =", os.environ.get("SWAT_DENSE_WAVES", "12"))
 c = dense._cache
 for rep in range(3):
     a, b = ev(), ev()
     a.record()
-    for _ in range(5): dense.topk_dense(db, q, k)
+    for _ in range(5): dense.topk_dense(db, q, k, shadow=SH)
     b.record(); torch.cuda.synchronize()
     tot = a.elapsed_time(b) / 5
     c["cnt"].zero_(); c["n2"].zero_()
     a, b = ev(), ev(); a.record()
     for _ in range(5):
-        dense.candidates(c, db)
+        dense.candidates(c, db, shadow=SH)
     b.record(); torch.cuda.synchronize()
     tc = a.elapsed_time(b) / 5
     print(f"pass {tot:.3f} ms = {nq / tot * 1e3:,.0f} queries/s; candidate kernel {tc:.3f} ms = {n * d * 4 / tc / 1e6:.0f} GB/s "
@@ -39,7 +40,7 @@ marks = [ev() for _ in range(7)]
 torch.cuda.synchronize()
 marks[0].record()
 cnt.zero_(); n2.zero_()
-dense.candidates(c, db)
+dense.candidates(c, db, shadow=SH)
 marks[1].record()
 _lib.check(L.swat_candidates_topk(_lib.ptr(keys), dense.CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2), _lib.stream()), "ctk")
 marks[2].record()

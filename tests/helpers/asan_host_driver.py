@@ -56,6 +56,16 @@ run("swat_attn_fwd_tiled", N, N, N, 1, 100, 64, 1, 0, N)
 run("swat_attn_fwd_tiled", P(), P(1), N, 2, 400, 128, 2, 0, N)
 run("swat_attn_bwd_tiled", P(), P(1), P(2), P(3), P(4), 2, 100, 128, 2, N, N)
 run("swat_attn_fwd_small", P(), P(1), 2, 65, 128, 2, N)
+assert h.swat_dense_shadow_bytes(1000, 512) == 1000 * 512 * 2 and h.swat_dense_shadow_bytes(1000, 100) == 0
+run("swat_dense_build_shadow", N, 10, 512, P(), P(1), N)
+run("swat_dense_build_shadow", P(), 10, 100, P(1), P(2), N)
+run("swat_dense_build_shadow", P(), 1 << 20, 512, P(1), P(2), N)
+for nq in (1, 200, 1000):
+    wb = h.swat_dense_workspace_bytes(nq)
+    assert wb > 0 and h.swat_dense_packed_bytes(nq, 512) > 0
+    run("swat_sim_candidates_shadow", P(), nq, P(1), 1 << 20, 512, P(2), 0, P(3), 8192, P(4), P(5), wb, N)
+    run("swat_sim_candidates_shadow", P(), nq, P(1), 1 << 20, 512, P(2), 0, P(3), 8192, P(4), P(5), wb - 1, N)
+    run("swat_sim_candidates_packed", P(), nq, P(1), 1 << 20, 768, P(2), 0, P(3), 8192, P(4), P(5), P(6), wb, N)
 run("swat_cast_bf16", P(), P(1), 7, N)
 run("swat_widen_bf16", P(), P(1), 7, N)
 # ---- dispatch / tile planning over the step's shapes with fake pointers: fails at the first HIP call, cleanly ----

@@ -137,9 +137,13 @@ __global__ __launch_bounds__(64 * W, OCC) void attn_fwd_tiled2_kernel(const unsi
         const unsigned short* ktile = tiles + (kt & 1) * 2 * 64 * ATP;
         const unsigned short* vtile = ktile + 64 * ATP;
         if (kt + 1 < nkt) st.issue(base, ld, d, T, k0 + 64, tid);
-        const int rem = T - k0;   // keys left: 16-key blocks / 32-key halves past T are skipped (T = 257: a 1-key last tile)
-        if (!active) {
-        } else if (rem >= 64 && !causal) fwd2_tile<false>(ktile, vtile, qf, o, lacc, m, c2, 64, 0, 0, 0, r16, g);
+        // keys of this tile the wave's 16 rows can see: up to T, and under the causal mask up to the wave's last row — 16-key blocks /
+        // 32-key halves past that are skipped (T = 257: a 1-key last tile; T = 77 causal: rows 0-63 never touch the second tile)
+        const int wrow = q0 + wave * 16;
+        int rem = T - k0;
+        if (causal && wrow + 16 - k0 < rem) rem = wrow + 16 - k0;
+        if (!active || rem <= 0) {
+        } else if (rem >= 64 && (!causal || k0 + 63 <= wrow)) fwd2_tile<false>(ktile, vtile, qf, o, lacc, m, c2, 64, 0, 0, 0, r16, g);
         else fwd2_tile<true>(ktile, vtile, qf, o, lacc, m, c2, rem, causal, k0, q, r16, g);
         if (kt + 1 < nkt) {
             unsigned short* nk = tiles + ((kt + 1) & 1) * 2 * 64 * ATP;

@@ -308,13 +308,15 @@ def retrieval_secondary(dev, rank=0, world=1, d=512, steps=5, with_cpu=True):
     return rec
 
 
-def _pmc_traffic(kernel, d=512):
+def _pmc_traffic(kernel, d=512, contains=None):
     """HBM bytes per launch of a retrieval kernel from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh;
     counters cannot be collected inside this process).  None when the profile is absent or was taken at another d."""
-    p = os.path.join(ROOT, "profiles", "r02_retrieval_pmc.json")
+    p = os.path.join(ROOT, "profiles", "r03_retrieval_pmc.json")
+    if not os.path.exists(p):
+        p = os.path.join(ROOT, "profiles", "r02_retrieval_pmc.json")
     if not os.path.exists(p) or d != 512:
         return None
-    recs = [v for n, v in json.load(open(p)).items() if n.startswith(kernel) and isinstance(v, dict)]
+    recs = [v for n, v in json.load(open(p)).items() if n.startswith(kernel) and isinstance(v, dict) and (contains is None or contains in n)]
     return round(max(r["hbm_bytes_per_launch"] for r in recs)) if recs else None  # the shard scan is the largest launch of its kernel
 
 
@@ -490,7 +492,8 @@ def retrieval_dense_secondary(dev, rank=0, world=1, steps=5, with_cpu=True):
            "roofline": {"bound": "hbm", "kernel": "sim_candidates_bf16_deep_kernel (" + ("the shard's bf16 shadow" if shadow is not None else "fp32 rows") +
                                   " read once, bf16 v_mfma_f32_16x16x32_bf16 scores; timed with its staging memset and regroup_candidates_kernel)",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                        "traffic": _pmc_traffic("sim_candidates_bf16_deep_kernel"), "algorithmic_bytes_per_launch": n * d * 4,
+                        "traffic": _pmc_traffic("sim_candidates_bf16_deep_kernel", contains=", true," if shadow is not None else ", false,"),
+                        "algorithmic_bytes_per_launch": n * d * 4,
                         "bytes_read_per_launch": n * row_bytes, "frac_of_bytes_read": round(n * row_bytes / 1e9 / (ms_k * 1e-3) / HBM_PEAK_GBS, 4),
                         "note": "achieved / frac use SURVEY 8(d)'s algorithmic 2 048 B per fp32 row; with the bf16 shadow the kernel reads half "
                                 "of that, so frac_of_bytes_read is the HBM efficiency of the launch itself",

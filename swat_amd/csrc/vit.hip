@@ -546,6 +546,10 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             }
             // lane: c_proj dW = dx^T g and c_fc dW = dF^T h2, db = colsum(dF) (reductions over Mp rows: pad rows are zero)
             to_lane();
+            // c_fc: dh2 = dF W — enqueued BEFORE the lane's launches: the host needs ~20 us for those five calls, and a main chain
+            // that waits for them leaves the GPU idle (tools/step_timeline.py: 7 us per block behind the 12-us attention backward)
+            int S2 = 1;
+            TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
             {
                 const void* dys[2] = {w.dxb, w.dfb};
                 const void* xs2[2] = {ga, h2};
@@ -560,9 +564,6 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                 }
             }
             lane_done(doneA);  // last lane read of dxb and dfb
-            // c_fc: dh2 = dF W
-            int S2 = 1;
-            TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
             // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
             wait_lane(doneB);
             // (row pass here; the reduction of its partial sums to d(ln_2.weight / bias) and d(out_proj.bias) runs on the lane)
@@ -574,6 +575,9 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s, at, w.lse + (int64_t)l * D.B * D.H * T));
             // lane: out_proj dW = dx1^T a and in_proj dW = dqkv^T h1, db = colsum(dqkv)
             to_lane();
+            // in_proj: dh1 = dqkv W (enqueued before the lane's launches, as above)
+            int S1 = 1;
+            TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));
             TRY(swat_layernorm_bwd_finish(w.lnws2, M, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], ws));
             {
                 const void* dys[2] = {w.dxb2, w.dqkv};
@@ -589,9 +593,6 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                 }
             }
             lane_done(doneB);  // last lane read of dxb2 and dqkv
-            // in_proj: dh1 = dqkv W
-            int S1 = 1;
-            TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));
             // ln_1 backward: dx0 = dx1 + LN'(dh1)
             wait_lane(doneA);
             TRY(swat_layernorm_bwd_partial(w.dh, d, S1, (int64_t)M * d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,

@@ -94,3 +94,12 @@ cat $O/${TAG}_ret_stats.json | cut -c1-1200
 (cd $ROOT && python3 tools/stats_top.py gpurun_out/${TAG}_ret_stats 1 16)
 tail -1 $O/${TAG}_prof_stats.json | cut -c1-300
 cd $ROOT && python3 tools/stats_top.py gpurun_out/${TAG}_prof_stats0 25 22
+# ---- round 3 extras: the tiled attention kernels' counters, the extraction forward, the ViT-L/14 step, one step's timeline
+(cd $ROOT && bash tools/pmc_attn.sh > $O/${TAG}_attn_pmc.txt 2>&1)
+cd /tmp
+rm -rf $O/${TAG}_extract_stats $O/${TAG}_vitl14_stats $O/${TAG}_trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_extract_stats -- python3 $ROOT/tools/perf_extract.py vitb32_openclip_laion400m 1024 > $O/${TAG}_extract.txt 2> /dev/null
+SWAT_BENCH_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_vitl14_stats -- python3 $ROOT/bench.py --finetune-only ViT-L-14 > $O/${TAG}_vitl14.json 2> /dev/null
+rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -- $BENCH --steps 20 --warmup 5 > /dev/null 2>&1
+(cd $ROOT && python3 tools/step_timeline.py gpurun_out/${TAG}_trace 1 > $O/${TAG}_step_timeline.txt 2>&1; tail -22 $O/${TAG}_step_timeline.txt)
+rm -rf $O/${TAG}_trace

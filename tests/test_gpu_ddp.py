@@ -156,7 +156,7 @@ def test_bench_two_rank_plumbing_prints_one_json_line():
         assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["unit"] == "queries/s" and rec["value"] > 0
         assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["kernel"].startswith(kern) and rec["roofline"]["frac"] > 0
         assert "cpu_baseline" not in rec
-    assert "2 x 1250000" in seg["config"]["workload"] and dense["config"]["route"] == "bf16-candidates+exact-rescore"
+    assert "2 x 1250000" in seg["config"]["workload"] and dense["config"]["route"] == "bf16-shadow-candidates+exact-rescore"
 
 
 def _free_port():

@@ -50,7 +50,24 @@ class FusedTrainStep:
         # trailing mode: per backward stage, the slice's (all-reduce and) AdamW trail the weight-gradient lane
         # (swat_hip.h: swat_vit_set_overlap mode 2), so the HBM-bound optimizer overlaps the GEMM-bound backward of the
         # stages below.  Needs the slices to tile the whole arena.
-        self.bucket_blocks = int(os.environ.get("SWAT_DP_BUCKET_BLOCKS", "3"))  # transformer blocks per gradient all-reduce (N > 1)
+        # N > 1: transformer blocks per gradient collective, from the top of the tower down.  Default: graduated — two buckets of L/3
+        # blocks while most of the backward is still ahead to hide them, then halving, so that the LAST collective (block 1, the stem
+        # and the head) is small: the next step's forward (one persistent launch that reads every weight) cannot start before that
+        # bucket's all-reduce and AdamW are through, so its size is exposed in full.  ViT-B/32: 4 + 4 + 2 + 1 + (1 + stem + head) =
+        # 113 / 113 / 57 / 28 / 31 MB instead of 4 x 85 MB.  SWAT_DP_BUCKETS=a,b,c overrides the list, SWAT_DP_BUCKET_BLOCKS=n makes
+        # every bucket n blocks (the round-2 behaviour with n = 3).
+        L_ = self.visual.layers if self.train_visual else 0
+        if os.environ.get("SWAT_DP_BUCKETS"):
+            self.bucket_sched = [max(1, int(x)) for x in os.environ["SWAT_DP_BUCKETS"].split(",")]
+        elif os.environ.get("SWAT_DP_BUCKET_BLOCKS"):
+            self.bucket_sched = [max(1, int(os.environ["SWAT_DP_BUCKET_BLOCKS"]))] * 64
+        else:
+            a_ = max(1, L_ // 3)
+            self.bucket_sched, r_ = [a_, a_], L_ - 2 * a_
+            while r_ > 1:
+                t_ = max(1, r_ // 2)
+                self.bucket_sched.append(t_)
+                r_ -= t_
         self.trail = False
         if trail and self.train_visual:
             sl = sorted(self._stage_slices + [(self.off_head, self.off_head + (self.C * self.E + 63) // 64 * 64)]
@@ -168,10 +185,10 @@ class FusedTrainStep:
         def finish(args, lo, n):  # one GPU: this slice's AdamW behind the lane
             _lib.check(lib.swat_adamw(*args, side_h), "swat_adamw")
 
-        # N > 1: gradients leave in BUCKETS of `self.bucket_blocks` transformer blocks (one contiguous arena range each:
+        # N > 1: gradients leave in BUCKETS of `self.bucket_sched[i]` transformer blocks (one contiguous arena range each:
         # logit_scale rides in the first bucket, stage 0 and the head in the last), all-reduced on `comm` (RCCL, stream-ordered) with the
-        # range's AdamW launches behind it on `side`.  ViT-B/32: 5 collectives of ~85 MB per step instead of 16 of <= 28 MB —
-        # fewer launch latencies on the host and on the links, still overlapped with the backward of the blocks below.
+        # range's AdamW launches behind it on `side`.  ViT-B/32: 5 collectives per step instead of 16 of <= 28 MB — fewer launch
+        # latencies on the host and on the links, still overlapped with the backward of the blocks below.
         pend = []  # (lo, hi, adamw args) of the open bucket, in arena order of issue
 
         def flush():
@@ -198,7 +215,7 @@ class FusedTrainStep:
                 # arena order: [head | stage 0 | stage 1 | ... | stage L+1 | logit_scale] — the backward walks it from the top down
                 if self.off_ls is not None:
                     pend.append((self.off_ls, self.off_ls + 64, sl["ls"]))
-                blocks = 0
+                blocks, bucket = 0, 0
                 for s in range(self.visual.layers + 1, -1, -1):
                     self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
                     lo, hi = self._stage_slices[s]
@@ -206,9 +223,10 @@ class FusedTrainStep:
                     blocks += 1 if 1 <= s <= self.visual.layers else 0
                     if s == 0:
                         pend.append((self.off_head, self.off_head + (self.C * self.E + 63) // 64 * 64, sl["head"]))
-                    if s == 0 or (blocks >= self.bucket_blocks and s > 1):  # (stage 1 waits for stage 0: no tiny last bucket)
+                    want = self.bucket_sched[bucket] if bucket < len(self.bucket_sched) else 1 << 30
+                    if s == 0 or (blocks >= want and s > 1):  # (stage 1 always leaves with stage 0 and the head)
                         flush()
-                        blocks = 0
+                        blocks, bucket = 0, bucket + 1
             else:
                 _lib.check(lib.swat_vit_lane_follow(main.cuda_stream), "swat_vit_lane_follow")
                 finish(sl["head"], self.off_head, self.C * self.E)

@@ -1,17 +1,21 @@
-// swat_amd/csrc/attention_tiled2.hip — the tiled attention kernels (64 < T <= 320, head width 64), round-3 forms of the
-// query-tiled ones: forward and dQ.  ref: nn.MultiheadAttention inside open_clip's ResidualAttentionBlock,
-// call sites utils/training.py:332,1474 (+ autograd).  Same arithmetic and rounding points as csrc/attention.hip /
-// attention_bwd_tiled.hip (P and dS rounded to bf16 before they are multiplied again, fp32 statistics); what changed is the
-// data movement, which is what bounds these kernels (MFMA busy ~5 % at T = 257):
+// swat_amd/csrc/attention_tiled2.hip — the tiled attention kernels (64 < T <= 320, head width 64; round 3): forward, dQ and
+// dK / dV behind swat_attn_fwd_tiled / swat_attn_bwd_tiled (attention.hip, attention_bwd_tiled.hip keep the entry points and the
+// round-2 kernels for reference).  ref: nn.MultiheadAttention inside open_clip's ResidualAttentionBlock, call sites
+// utils/training.py:332,1474 (+ autograd).  fp32 statistics, P rounded to bf16 where it becomes an MFMA operand (and dS likewise);
+// unlike the T <= 64 kernels, dS is formed from the unrounded P.  What changed against round 2 is the data movement and the
+// per-score instruction count, which bound these kernels (MFMA busy ~13 % at T = 257):
 //   * a workgroup holds W = 4..9 waves of 16 rows (8 when T > 144), so a staged tile serves up to 144 rows; waves whose rows
 //     all lie past T skip the arithmetic;
-//   * K AND V tiles are staged in LDS, double-buffered: the next tile's global loads are issued before the current tile's
-//     MFMAs and written to the other buffer after them — ONE barrier per key tile, no global load inside the MFMA chains
-//     (the first forms read every K / V fragment straight from global memory, per wave, between two barriers);
+//   * the tiles of the OTHER side (K and V for forward / dQ; Q, dO, lse, delta for dK / dV) are staged in LDS, double-buffered:
+//     the next tile's global loads are issued before the current tile's MFMAs and written to the other buffer after them — ONE
+//     barrier per tile, no global load inside the MFMA chains (round 2 read every K / V fragment straight from global memory,
+//     per wave, between two barriers);
+//   * dK / dV gets S^T from the MFMA with the operand roles swapped, which is already the operand layout of the two products
+//     that contract over queries: P and dS never pass through LDS;
 //   * dQ's kernel also leaves delta = rowsum(dO * O) per row for the dK / dV kernel;
-//   * the kernels are VALU-bound (about 7 waves per SIMD each spending ~25 vector instructions per score), so the per-score
-//     work is cut to the bone: exp2 of one fma (scale and log2 e folded), masks only in the tile that holds T, the row sums
-//     of the forward on the idle matrix pipe, and dS from the unrounded P (P is rounded once, where it becomes an operand).
+//   * per score: exp2 of one fma (scale and log2 e folded), masks only in the tile that holds T or a causal diagonal, tiles /
+//     16-key blocks a wave cannot see skipped, the forward's row sums on the idle matrix pipe (an MFMA against ones).
+// Measurements, counters and the dead ends (inline-asm max over MFMA results, occupancy hints, smaller workgroups): DESIGN.md section 4.
 #include "attention.hpp"
 #include "../../include/swat_hip.h"
 #include <cstdlib>

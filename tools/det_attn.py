@@ -1,3 +1,5 @@
+"""Dev tool: repeat-run bit equality of the tiled attention forward (with / without the lse output) at the ViT-B/16 and ViT-L/14
+shapes — how the inline-asm MFMA hazard of round 3 was pinned down."""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import torch

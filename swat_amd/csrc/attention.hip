@@ -167,85 +167,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const unsigned shor
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Longer sequences (64 < T <= 64 * NT, NT <= 5: ViT-B/16 T = 197, ViT-L/14 T = 257, the text tower's causal T = 77):
-// one workgroup per (image, head, 64-query tile) walks the key tiles with the running-maximum softmax; the row
-// log-sum-exp is saved for the backward.  Same operand layouts as above.
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
-                                                             float* __restrict__ lse, int T, int d, int H, float scale, int causal) {
-    __shared__ __attribute__((aligned(16))) unsigned short vt[64 * ATP];
-    const int b = blockIdx.x / H, h = blockIdx.x % H, q0 = blockIdx.y * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-    const int64_t ld = 3 * (int64_t)d;
-    const unsigned short* base = qkv + (int64_t)b * T * ld + h * 64;
-    const int q = q0 + wave * 16 + r16, qq = q < T ? q : T - 1;
-    abf16x8_t qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(base + (int64_t)qq * ld + 32 * ks + 8 * g);
-    af32x4_t o[4];
-#pragma unroll
-    for (int jc = 0; jc < 4; ++jc) o[jc] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
-    const int nkt = causal ? (q0 + 63 < T ? q0 / 64 + 1 : (T + 63) / 64) : (T + 63) / 64;  // key tiles this query tile can see
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int k0 = kt * 64;
-        __syncthreads();  // every wave is done with the previous V tile
-        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
-            const int row = i >> 3, ch = i & 7;
-            const int rr = k0 + row < T ? k0 + row : T - 1;
-            *reinterpret_cast<au32x4_t*>(vt + row * ATP + ch * 8) = *reinterpret_cast<const au32x4_t*>(base + 2 * d + (int64_t)rr * ld + ch * 8);
-        }
-        af32x4_t s[4];
-        float mx = m;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int key = k0 + 16 * j + r16, kk = key < T ? key : T - 1;
-            s[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(base + d + (int64_t)kk * ld + 32 * ks + 8 * g), qf[ks], s[j], 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kcol = k0 + 16 * j + 4 * g + e;
-                s[j][e] = (kcol < T && !(causal && kcol > q)) ? s[j][e] * scale : -INFINITY;
-                mx = fmaxf(mx, s[j][e]);
-            }
-        }
-        mx = xor_max(mx);
-        const float alpha = mx == -INFINITY ? 1.0f : __expf(m - mx);  // (m = -inf, mx finite: exp(-inf) = 0)
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[j][e] = s[j][e] == -INFINITY ? 0.f : bf2f(f2bf(__expf(s[j][e] - mx)));
-                sum += s[j][e];
-            }
-        l = l * alpha + xor_sum(sum);
-        m = mx;
-        const abf16x8_t pf[2] = {acc_frag(s, 0), acc_frag(s, 1)};
-        __syncthreads();  // V tile staged
-#pragma unroll
-        for (int jc = 0; jc < 4; ++jc) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[jc][e] *= alpha;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                o[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(vt, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), pf[ks], o[jc], 0, 0, 0);
-        }
-    }
-    if (q < T) {
-        const float inv = 1.0f / l;
-#pragma unroll
-        for (int jc = 0; jc < 4; ++jc) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[jc][e] *= inv;
-            store4(out + ((int64_t)b * T + q) * d + h * 64 + 16 * jc + 4 * g, o[jc]);
-        }
-        if (lse && g == 0) lse[(int64_t)blockIdx.x * T + q] = m + __logf(l);
-    }
-}
+// (Longer sequences, 64 < T <= 320: csrc/attention_tiled2.hip behind swat_attn_fwd_tiled / swat_attn_bwd_tiled.)
 
 }  // namespace swat
 

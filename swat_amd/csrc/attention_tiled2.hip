@@ -1,6 +1,6 @@
 // swat_amd/csrc/attention_tiled2.hip — the tiled attention kernels (64 < T <= 320, head width 64; round 3): forward, dQ and
-// dK / dV behind swat_attn_fwd_tiled / swat_attn_bwd_tiled (attention.hip, attention_bwd_tiled.hip keep the entry points and the
-// round-2 kernels for reference).  ref: nn.MultiheadAttention inside open_clip's ResidualAttentionBlock, call sites
+// dK / dV behind swat_attn_fwd_tiled / swat_attn_bwd_tiled (entry points in attention.hip / attention_bwd_tiled.hip).
+// ref: nn.MultiheadAttention inside open_clip's ResidualAttentionBlock, call sites
 // utils/training.py:332,1474 (+ autograd).  fp32 statistics, P rounded to bf16 where it becomes an MFMA operand (and dS likewise);
 // unlike the T <= 64 kernels, dS is formed from the unrounded P.  What changed against round 2 is the data movement and the
 // per-score instruction count, which bound these kernels (MFMA busy ~13 % at T = 257):

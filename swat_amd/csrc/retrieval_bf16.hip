@@ -407,6 +407,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
                     for (int t = 0; t < NQT; ++t) {
                         asm volatile("" ::: "memory");  // one threshold live at a time (the compiler would hoist all NQT reads)
                         const float tq = sthr[16 * t + r16];
+                        // (hits are rare: one ballot over the lane's best of four decides whether the four per-row ballots run)
+                        if ((ABL & 31) || __ballot(fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3])) >= tq))
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float sc = acc[t][e];
@@ -450,6 +452,189 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
         if constexpr (!DB16) atomicMax(max_norm2_bits, __float_as_uint(norm2_max));
         stage_cnt[wave_slot] = wcount;  // may exceed stage_cap: the regroup pass reports the overflow
     }
+}
+
+// The shadow scan with TWO 16-row fragments per wave (8 waves, 256-row blocks, 64-deep steps, database registers four steps ahead):
+// every query fragment read from LDS feeds two MFMAs, and a row costs half the barriers, counted waits and query-chunk DMA of the
+// one-fragment form above — whose ablations show exactly those as its cost once the rows come from the bf16 shadow (0.449 ms: no
+// barrier 0.325, no query DMA 0.331, no MFMA / LDS reads 0.257; the bare row stream 0.220).  Same candidate records bit for bit.
+template <int NQT>
+__global__ __launch_bounds__(512, 1) void sim_candidates_shadow2_kernel(const unsigned short* __restrict__ qp, int n_tiles, int n_q, int q0,
+                                                                        const unsigned short* __restrict__ db, int64_t n_db, int d,
+                                                                        const float* __restrict__ thr, int64_t row_base,
+                                                                        uint4* __restrict__ stage, unsigned stage_cap,
+                                                                        unsigned* __restrict__ stage_cnt) {
+    constexpr int WAVES = 8, NF = 2, KD = 2, D = 4, RING = 4;
+    constexpr int QROWS = 16 * NQT;
+    constexpr int QBYTES = QROWS * 64;       // one 32-deep query chunk
+    constexpr int LPS = (NQT + WAVES - 1) / WAVES;
+    constexpr int BR = 16 * WAVES * NF;      // 256 database rows per block
+    constexpr int STAGE = KD * QBYTES;
+    constexpr int DBL = NF * KD;             // database loads per step and lane
+    static_assert(LPS <= 4, "counted waits cover up to four pieces per wave");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char rb_dyn_smem[];
+    unsigned char* const smem = rb_dyn_smem;
+    __shared__ float sthr[QROWS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nchunk = d >> 6;  // 64-deep steps per row block
+    const int64_t nblocks = (n_db + BR - 1) / BR;
+    if ((int64_t)blockIdx.x >= nblocks) return;
+    if (tid < QROWS) sthr[tid] = q0 + tid < n_q ? thr[q0 + tid] : INFINITY;
+    const int wave_slot = blockIdx.x * WAVES + wave;
+    uint4* __restrict__ my_stage = stage + (size_t)wave_slot * stage_cap;
+    unsigned wcount = __builtin_amdgcn_readfirstlane(stage_cnt[wave_slot]);
+    const int64_t my_blocks = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int64_t steps = my_blocks * nchunk;
+
+    int qdst[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) qdst[i] = (wave + WAVES * i) * 1024;
+    const int my_lps = wave < NQT ? (NQT - 1 - wave) / WAVES + 1 : 0;  // uniform per wave
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const char* qbase = reinterpret_cast<const char*>(qp) + (size_t)(q0 >> 4) * 1024;
+    const size_t chunk_stride = (size_t)n_tiles * 1024;
+    auto issue_q = [&](int buf, int c) {
+#pragma unroll
+        for (int h = 0; h < KD; ++h)
+#pragma unroll
+            for (int i = 0; i < LPS; ++i)
+                if (i < my_lps) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + (size_t)(KD * c + h) * chunk_stride + qdst[i] + lane16),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * STAGE + h * QBYTES + qdst[i]), 16, 0, 0);
+    };
+    // fragment f of the wave: rows (wave * NF + f) * 16 + r16 of the block; 16-B unit g of each 64-B chunk image
+    unsigned voff[NF], voff_last[NF];
+    const int64_t last_blk = nblocks - 1;
+    const unsigned last_rows = (unsigned)(n_db - last_blk * BR);  // 1 .. BR
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const unsigned row = (unsigned)((wave * NF + f) * 16 + r16);
+        const unsigned lrow = row < last_rows ? row : last_rows - 1;
+        voff[f] = row * (unsigned)d * 2u + 16u * g;
+        voff_last[f] = lrow * (unsigned)d * 2u + 16u * g;
+    }
+    const size_t blk_bytes = (size_t)BR * d * 2;
+    rb_f32x4_t nx[D][NF][KD];
+    const unsigned qr = (unsigned)(r16 * 64 + ((g ^ ((r16 >> 2) & 3)) << 4));
+    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
+    rb_f32x4_t acc[NF][NQT];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) acc[f][t] = (rb_f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    int64_t blk = blockIdx.x, lblk = blockIdx.x, ls = 0;
+    int c = 0, lc = 0, qc = 0;
+    auto next_q = [&]() { qc = qc + 1 == nchunk ? 0 : qc + 1; };
+    auto next_l = [&]() {
+        if (ls + 1 < steps) {
+            ++ls;
+            if (++lc == nchunk) { lc = 0; lblk += gridDim.x; }
+        }
+    };
+    issue_q(0, qc); next_q();
+    auto load_db = [&](rb_f32x4_t (&dst)[NF][KD]) {
+        const char* base = reinterpret_cast<const char*>(db) + lblk * blk_bytes + (size_t)lc * 128;  // uniform: two 64-B chunk images
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const unsigned off = lblk == last_blk ? voff_last[f] : voff[f];
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[f][0]) : "v"(off), "s"(base));
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(dst[f][1]) : "v"(off), "s"(base));
+        }
+        next_l();
+    };
+    load_db(nx[0]);
+    issue_q(1, qc); next_q();
+    rb_static_for<D - 1>([&](auto R) { load_db(nx[decltype(R)::value + 1]); });
+
+    for (int64_t s0 = 0; s0 < steps; s0 += D) {
+        rb_static_for<D>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            // behind this wait: the database loads of two later steps and the next step's query pieces may still fly
+            if (s0 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (my_lps == 0) rb_wait_vm<2 * DBL>();
+            else if (LPS == 1 || my_lps == 1) rb_wait_vm<2 * DBL + KD>();
+            else if (LPS == 2 || my_lps == 2) rb_wait_vm<2 * DBL + 2 * KD>();
+            else if (LPS == 3 || my_lps == 3) rb_wait_vm<2 * DBL + 3 * KD>();
+            else rb_wait_vm<2 * DBL + 4 * KD>();
+            __builtin_amdgcn_s_barrier();
+            rb_bf16x8_t dfr[NF][KD];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int h = 0; h < KD; ++h) {
+                    asm volatile("" : "+v"(nx[r][f][h])::"memory");  // landed: the counted wait above covers it
+                    rb_f32x4_t v = nx[r][f][h];
+                    asm volatile("" : "+v"(v)::"memory");            // consumed HERE, before the loads below overwrite the set
+                    dfr[f][h] = __builtin_bit_cast(rb_bf16x8_t, v);
+                }
+            issue_q((r + 2) & 3, qc); next_q();
+            load_db(nx[r]);
+            constexpr int NV = KD * NQT;  // fragment v: chunk v / NQT, query tile v % NQT — 1 KiB apart in the stage buffer
+            constexpr int QD = NV < 4 ? NV : 4;
+            const unsigned qs = lds_base + (unsigned)((r & 3) * STAGE) + qr;
+            rb_bf16x8_t qf[QD];
+            rb_static_for<QD>([&](auto T) { qf[decltype(T)::value] = rb_lds_b128<decltype(T)::value * 1024>(qs); });
+            rb_static_for<NV>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                rb_wait_lgkm<(NV - 1 - t < QD - 1 ? NV - 1 - t : QD - 1)>();
+                rb_pin(qf[t % QD]);
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    acc[f][t % NQT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[f][t / NQT], qf[t % QD], acc[f][t % NQT], 0, 0, 0);
+                if constexpr (t + QD < NV) qf[t % QD] = rb_lds_b128<(t + QD) * 1024>(qs);
+            });
+            if constexpr (r == D - 1) {  // nchunk % D == 0: a block can only end on the last step of the unrolled group
+                if (c + 1 == nchunk) {
+                    const unsigned n_db32 = (unsigned)n_db;
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const unsigned row0 = (unsigned)(blk * BR) + (unsigned)((wave * NF + f) * 16);
+                        const unsigned key0 = 0xFFFFFFFFu - (uint32_t)row_base - row0 - 4u * g;
+#pragma unroll
+                        for (int t = 0; t < NQT; ++t) {
+                            asm volatile("" ::: "memory");  // one threshold live at a time
+                            const float tq = sthr[16 * t + r16];
+                            // hits are rare (0.1-0.2 % of the scores): one ballot over the lane's best of four decides whether the
+                            // four per-row ballots run at all (the record order is unchanged: empty groups are just not visited)
+                            const float best = fmaxf(fmaxf(acc[f][t][0], acc[f][t][1]), fmaxf(acc[f][t][2], acc[f][t][3]));
+                            if (__ballot(best >= tq))
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float sc = acc[f][t][e];
+                                const unsigned row = row0 + 4 * g + e;
+                                const bool hit = sc >= tq && row < n_db32;
+                                const unsigned long long m = __ballot(hit);
+                                if (m) {
+                                    const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                    if (hit && pos < stage_cap) {
+                                        const unsigned o = pos * 16u, k_lo = key0 - e, k_hi = rb_ordered_bits(sc), qq = (unsigned)(q0 + 16 * t) + r16;
+                                        asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(k_lo), "s"(my_stage) : "memory");
+                                        asm volatile("global_store_dword %0, %1, %2 offset:4" ::"v"(o), "v"(k_hi), "s"(my_stage) : "memory");
+                                        asm volatile("global_store_dword %0, %1, %2 offset:8" ::"v"(o), "v"(qq), "s"(my_stage) : "memory");
+                                    }
+                                    wcount += (unsigned)__popcll(m);
+                                }
+                            }
+                            acc[f][t] = (rb_f32x4_t){0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                    c = 0;
+                    blk += gridDim.x;
+                } else {
+                    ++c;
+                }
+            } else {
+                ++c;
+            }
+        });
+    }
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) asm volatile("s_waitcnt vmcnt(0)" ::"v"(nx[r][f][0]), "v"(nx[r][f][1]) : "memory");
+    if (lane == 0) stage_cnt[wave_slot] = wcount;
 }
 
 // Files the staged candidate records under their queries: cand[q, pos] = key with pos from cnt[q].  A block takes 16 wave
@@ -631,10 +816,19 @@ static int dense_candidates_packed(const void* packed, int n_q, const float* db,
     hipStream_t st = (hipStream_t)s;
     const int n_tiles = dense_tiles(n_q);
     static const int abl = getenv("SWAT_DENSE_ABL") ? atoi(getenv("SWAT_DENSE_ABL")) : 0;  // tuning: timing ablations, wrong results
+    static const int nf = getenv("SWAT_DENSE_NF") ? atoi(getenv("SWAT_DENSE_NF")) : 2;  // tuning: 16-row fragments per wave of the shadow scan
     static const int kd = getenv("SWAT_DENSE_KD") ? atoi(getenv("SWAT_DENSE_KD")) : 2;  // tuning: 32-k chunks per step of the shadow scan
     static const int waves = getenv("SWAT_DENSE_WAVES") ? atoi(getenv("SWAT_DENSE_WAVES")) : 12;  // tuning: 4 = 64-row blocks, 3 workgroups per CU
 #define SWAT_CAND_DEEP(NQT_, ABL_)                                                                                       \
-    if (shadow && d % 256 == 0 && kd == 2) {                                                                             \
+    if (shadow && d % 256 == 0 && kd == 2 && nf == 2 && (ABL_) == 0) {                                                   \
+        const int64_t nblocks = (n_db + 255) / 256;                                                                      \
+        const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);                                                 \
+        auto kern = sim_candidates_shadow2_kernel<NQT_>;                                                                 \
+        const int lds = 4 * 2 * 16 * NQT_ * 64;                                                                          \
+        SWAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const unsigned short*)packed, n_tiles, n_q, q0,        \
+                           (const unsigned short*)db, n_db, d, thr_dev, row_base, stage, stage_cap, stage_cnt);          \
+    } else if (shadow && d % 256 == 0 && kd == 2) {                                                                      \
         const int64_t nblocks = (n_db + 191) / 192;                                                                      \
         const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);                                                 \
         auto kern = sim_candidates_bf16_deep_kernel<NQT_, 4, 12, ABL_, true, 2>;                                         \

@@ -489,10 +489,10 @@ def retrieval_dense_secondary(dev, rank=0, world=1, steps=5, with_cpu=True):
            "ms_per_pass": round(dt * 1e3, 3),
            "cold_call": {"ms_per_pass": round(dt_cold * 1e3, 3), "queries_per_s": round(nq / dt_cold, 1),
                          "note": "new query tensor every call: threshold sample scan + segment top-k + query packing + one extra host sync, then the pass"},
-           "roofline": {"bound": "hbm", "kernel": "sim_candidates_bf16_deep_kernel (" + ("the shard's bf16 shadow" if shadow is not None else "fp32 rows") +
+           "roofline": {"bound": "hbm", "kernel": ("sim_candidates_shadow2_kernel (the shard's bf16 shadow" if shadow is not None else "sim_candidates_bf16_deep_kernel (fp32 rows") +
                                   " read once, bf16 v_mfma_f32_16x16x32_bf16 scores; timed with its staging memset and regroup_candidates_kernel)",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                        "traffic": _pmc_traffic("sim_candidates_bf16_deep_kernel", contains=", true," if shadow is not None else ", false,"),
+                        "traffic": _pmc_traffic("sim_candidates_shadow2_kernel") if shadow is not None else _pmc_traffic("sim_candidates_bf16_deep_kernel", contains=", false,"),
                         "algorithmic_bytes_per_launch": n * d * 4,
                         "bytes_read_per_launch": n * row_bytes, "frac_of_bytes_read": round(n * row_bytes / 1e9 / (ms_k * 1e-3) / HBM_PEAK_GBS, 4),
                         "note": "achieved / frac use SURVEY 8(d)'s algorithmic 2 048 B per fp32 row; with the bf16 shadow the kernel reads half "

@@ -152,7 +152,7 @@ def test_bench_two_rank_plumbing_prints_one_json_line():
     assert d["value"] > 0 and abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"] + 0.1
     # path B legs at N = 2: one shard per rank, all_gather + merge of the per-rank lists
     seg, dense = d["secondary"]
-    for rec, kern in ((seg, "sim_segmented_kernel"), (dense, "sim_candidates_bf16_deep_kernel")):
+    for rec, kern in ((seg, "sim_segmented_kernel"), (dense, "sim_candidates_shadow2_kernel")):
         assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["unit"] == "queries/s" and rec["value"] > 0
         assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["kernel"].startswith(kern) and rec["roofline"]["frac"] > 0
         assert "cpu_baseline" not in rec

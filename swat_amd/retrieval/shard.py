@@ -77,3 +77,26 @@ class ShardedIndex:
         idx, val, cnt, _, _ = self.local.sample(queries, k, **kw)
         gidx = torch.where(idx >= 0, idx + self.lo, idx)
         return gather_and_merge(gidx, val, k, group=self.group)
+
+
+class DenseIndex:
+    """One rank's shard of a dense (N_query x N_db) cosine index — BASELINE config 4: `rows` [n, d] fp32 on the GPU with global
+    row numbers row_base .. row_base + n - 1.  Owns the shard's bf16 scan image (dense.DenseShadow, built once; pass
+    shadow=False to scan the fp32 rows instead and save half the shard's bytes again in HBM) and finishes a query batch: local
+    exact top-k, then, inside a process group, the all_gather + k-way merge of the per-rank lists (SURVEY 8(e) retrieval row).
+    ref: the per-class GEMV + sorted() of retrieval/sample_retrieval.py:724-825, generalised to a query batch."""
+
+    def __init__(self, rows, row_base=0, group=None, shadow=True):
+        from . import dense
+        self.rows, self.row_base, self.group = rows, int(row_base), group
+        self.shadow = None
+        if shadow and rows.shape[1] % 128 == 0:
+            self.shadow = dense.DenseShadow(rows)
+
+    def topk(self, queries, k):
+        """-> (idx [n_q, k] global rows (-1 padded), val [n_q, k], cnt [n_q]) in (value desc, row asc) order, bit-exact."""
+        from . import dense
+        idx, val, cnt = dense.topk_dense(self.rows, queries, k, row_base=self.row_base, shadow=self.shadow)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return gather_and_merge(idx, val, k, group=self.group)
+        return idx, val, cnt

@@ -216,6 +216,11 @@ def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale, d):
         idx4, val4, cnt4 = dense.topk_dense(d_db, d_q, k, row_base=1000, shadow=sh)
         assert dense.last_path == "bf16-shadow-candidates+exact-rescore"
         assert torch.equal(idx4, e_idx) and torch.equal(val4, e_val) and torch.equal(cnt4, e_cnt)
+        from swat_amd.retrieval import shard
+        di = shard.DenseIndex(d_db, row_base=1000)   # the index object owns the shadow (no process group: local lists)
+        idx5, val5, cnt5 = di.topk(d_q, k)
+        assert dense.last_path == "bf16-shadow-candidates+exact-rescore"
+        assert torch.equal(idx5, e_idx) and torch.equal(val5, e_val) and torch.equal(cnt5, e_cnt)
         d_db[0].mul_(1.0)  # an in-place write to the rows: the shadow no longer vouches for them, the fp32 scan answers
         assert not sh.matches(d_db)
         dense.topk_dense(d_db, d_q, k, row_base=1000, shadow=sh)

@@ -32,7 +32,7 @@ def sim_matrix(queries, db):
 _sample = {}
 
 
-def _thresholds(queries, db, k, sample, boost):
+def _thresholds(queries, db, k, sample, boost, approx=False):
     """Per-query pruning threshold from a strided row sample: the value at the rank that should leave ~boost*k rows.
     (16 384 sample rows put the rank near 30 for k = 500 of 1.25 M: the kept count scatters by ~20 % around boost*k,
     well inside [k, CAP]; the caller re-brackets when it does not.)"""
@@ -49,7 +49,17 @@ def _thresholds(queries, db, k, sample, boost):
         _sample.clear()
         _sample.update(key=skey, ref=weakref.ref(db), rows=db[::stride][:ns].contiguous())
     smp = _sample["rows"]
-    S = sim_matrix(queries, smp)
+    d = db.shape[1]
+    if approx and d % 64 == 0 and (nq * d) % 4 == 0:
+        # the candidate pass compares bf16 MFMA scores with these thresholds, so bf16 sample scores serve as well as exact ones and
+        # cost a sixth: one bf16 GEMM [n_q, d] x [n_s, d]^T (the step's own product kernels) instead of the f32-matrix-core scan
+        from .. import ops as aops
+        if "rows_bf16" not in _sample:
+            _sample["rows_bf16"] = aops.cast_bf16(smp)
+        S = torch.empty((nq, ns), dtype=torch.float32, device=db.device)
+        aops.gemm(aops.NT, aops.cast_bf16(queries), _sample["rows_bf16"], nq, ns, d, d, d, S, ns)
+    else:
+        S = sim_matrix(queries, smp)
     rank = min(ns, 2048, max(int(boost * k * ns / n) + 8, 16))
     sub = 2048
     if ns % sub == 0 and ns >= 2 * sub and rank <= sub // 4:
@@ -113,7 +123,7 @@ def _prepared(db, queries, k, sample):
     if not hit:
         nq = queries.shape[0]
         K2 = min(TOPK2_MAX, max(64, (max(2 * k, k + 256) + 63) // 64 * 64))
-        thr = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)))
+        thr = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)), approx=True)
         dev = db.device
         d = queries.shape[1]
         nbytes, wbytes = int(_lib.lib().swat_dense_packed_bytes(nq, d)), int(_lib.lib().swat_dense_workspace_bytes(nq))
@@ -126,7 +136,7 @@ def _prepared(db, queries, k, sample):
             qb = queries.to(torch.bfloat16).contiguous()
         _cache.clear()
         _cache.update(key=key, db_ref=weakref.ref(db), q_ref=weakref.ref(queries), ptrs=(db.data_ptr(), queries.data_ptr()),
-                      thr=thr, qb=qb, ws=ws, qn=float(queries.norm(dim=1).max().item()), K2=K2,
+                      thr=thr, qb=qb, ws=ws, qn2=(queries * queries).sum(dim=1).max().reshape(1).contiguous(), K2=K2,   # max |q|^2 stays on the device: no host sync
                       row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
                       idx2=torch.empty((nq, K2), dtype=torch.int64, device=dev), val2=torch.empty((nq, K2), dtype=torch.float32, device=dev),
                       cnt2=torch.empty(nq, dtype=torch.int64, device=dev), keys2=torch.empty((nq, K2), dtype=torch.int64, device=dev),
@@ -218,7 +228,7 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
     # completeness, proved on the device: a row that was not re-scored has approx <= bound_q (the K2-th kept approximate
     # score, or the threshold when fewer than K2 candidates exist), hence exact <= bound_q + delta < the k-th exact value
     _lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), need,
-                                       float(EPS_BF16 * c["qn"]), _lib.ptr(n2), nq, _lib.ptr(c["fails"]), _lib.stream()),
+                                       float(EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), nq, _lib.ptr(c["fails"]), _lib.stream()),
                "swat_dense_topk_proof")
     if c["fails"].item() != 0:  # the one host synchronisation of the call
         last_path = "exact-fallback"

@@ -49,7 +49,7 @@ marks[3].record()
 idx = torch.empty((nq, k), dtype=torch.int64, device=dev); val = torch.empty((nq, k), dtype=torch.float32, device=dev); out_cnt = torch.empty(nq, dtype=torch.int64, device=dev)
 _lib.check(L.swat_candidates_topk(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt), _lib.stream()), "ctk2")
 marks[4].record()
-_lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), k, float(dense.EPS_BF16 * c["qn"]), _lib.ptr(n2), nq, _lib.ptr(c["fails"]), _lib.stream()), "proof")
+_lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), k, float(dense.EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), nq, _lib.ptr(c["fails"]), _lib.stream()), "proof")
 marks[5].record()
 flag = c["fails"].item()
 marks[6].record(); torch.cuda.synchronize()

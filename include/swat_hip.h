@@ -49,12 +49,12 @@ int swat_sim_gathered(const float* feats, const int64_t* row_index, int64_t n_id
                       const int32_t* row_seg, float* sims, void* keys_out, int64_t row_base, swat_stream_t stream);
 /*     completeness proof of the dense top-k: fails[0] = number of queries whose need-th exact value is not strictly
  *     above (K2-th best approximate score, or thr_dev[q] when cand_cnt[q] < K2) + eps_qnorm * sqrt(max_norm2[0]) [*
- *     sqrt(qnorm2_max[0]) when that device scalar — max |q|^2 over the batch — is given instead of folding it into
+ *     qnorm_max[0] when that device scalar — max |q| over the batch — is given instead of folding it into
  *     eps_qnorm on the host: no host synchronisation for a new query batch], that kept fewer than `need` rows, or whose
  *     candidate list overflowed `cap`.  0 = the kept rows ARE the exact top-k. */
 int swat_dense_topk_proof(const void* cand_cnt, int cap, int K2, const float* approx_val, const float* thr_dev,
                           const float* exact_val, int k, const int64_t* out_cnt, int need, float eps_qnorm,
-                          const float* max_norm2, const float* qnorm2_max, int n_q, int* fails, swat_stream_t stream);
+                          const float* max_norm2, const float* qnorm_max, int n_q, int* fails, swat_stream_t stream);
 
 /* B5  filtered segmented top-k: for every segment s = rows [seg_offsets[s], seg_offsets[s+1])
  *     keep row iff sims >= thr [and t2i >= t2i_thr when t2i != NULL] [and !excluded[row]],

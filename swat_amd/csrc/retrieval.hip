@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
 __global__ void dense_proof_kernel(const unsigned* __restrict__ cand_cnt, int cap, int K2, const float* __restrict__ approx_val,
                                    const float* __restrict__ thr, const float* __restrict__ exact_val, int k,
                                    const int64_t* __restrict__ out_cnt, int need, float eps_qn, const float* __restrict__ max_norm2,
-                                   const float* __restrict__ qnorm2_max, int n_q, int* __restrict__ fails) {
-    const float delta = eps_qn * (qnorm2_max ? sqrtf(qnorm2_max[0]) : 1.0f) * sqrtf(max_norm2[0]);
+                                   const float* __restrict__ qnorm_max, int n_q, int* __restrict__ fails) {
+    const float delta = eps_qn * (qnorm_max ? qnorm_max[0] : 1.0f) * sqrtf(max_norm2[0]);
     int bad = 0;
     for (int q = threadIdx.x; q < n_q; q += blockDim.x) {
         const unsigned c = cand_cnt[q];
@@ -324,12 +324,12 @@ SWAT_API int swat_sim_gathered(const float* feats, const int64_t* row_index, int
 
 SWAT_API int swat_dense_topk_proof(const void* cand_cnt, int cap, int K2, const float* approx_val, const float* thr_dev,
                                    const float* exact_val, int k, const int64_t* out_cnt, int need, float eps_qnorm,
-                                   const float* max_norm2, const float* qnorm2_max, int n_q, int* fails, swat_stream_t stream) {
+                                   const float* max_norm2, const float* qnorm_max, int n_q, int* fails, swat_stream_t stream) {
     SWAT_REQUIRE(cand_cnt && approx_val && thr_dev && exact_val && out_cnt && max_norm2 && fails, "swat_dense_topk_proof: null pointer");
     SWAT_REQUIRE(n_q > 0 && need >= 1 && need <= k && K2 >= 1, "swat_dense_topk_proof: bad sizes");
     SWAT_HIP(hipMemsetAsync(fails, 0, sizeof(int), (hipStream_t)stream));
     hipLaunchKernelGGL(swat::dense_proof_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const unsigned*)cand_cnt, cap, K2,
-                       approx_val, thr_dev, exact_val, k, out_cnt, need, eps_qnorm, max_norm2, qnorm2_max, n_q, fails);
+                       approx_val, thr_dev, exact_val, k, out_cnt, need, eps_qnorm, max_norm2, qnorm_max, n_q, fails);
     return swat::check_launch("swat_dense_topk_proof");
 }
 

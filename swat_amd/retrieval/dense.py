@@ -66,9 +66,12 @@ def _thresholds(queries, db, k, sample, boost, approx=False):
         # two levels: one workgroup per (query, 2048-score piece) instead of one per query — 200 workgroups walking 16 384
         # scores each took 160 us of a 0.9 ms cold call; the rank-th value of the union of the pieces' top `rank` is the same
         parts = ns // sub
-        off = torch.arange(0, nq * ns + 1, sub, device=db.device, dtype=torch.int64)
+        okey = ("off", nq, ns, rank)
+        if okey not in _sample:
+            _sample[okey] = (torch.arange(0, nq * ns + 1, sub, device=db.device, dtype=torch.int64),
+                             torch.arange(0, (nq + 1) * parts * rank, parts * rank, device=db.device, dtype=torch.int64))
+        off, off2 = _sample[okey]
         _, v1, _ = ops.segment_topk(S.view(-1), off, rank, thr=float("-inf"))          # [nq * parts, rank]
-        off2 = torch.arange(0, (nq + 1) * parts * rank, parts * rank, device=db.device, dtype=torch.int64)
         _, val, _ = ops.segment_topk(v1.reshape(-1), off2, rank, thr=float("-inf"))
         return val[:, rank - 1].contiguous()
     off = torch.arange(0, (nq + 1) * ns, ns, device=db.device, dtype=torch.int64)
@@ -136,7 +139,7 @@ def _prepared(db, queries, k, sample):
             qb = queries.to(torch.bfloat16).contiguous()
         _cache.clear()
         _cache.update(key=key, db_ref=weakref.ref(db), q_ref=weakref.ref(queries), ptrs=(db.data_ptr(), queries.data_ptr()),
-                      thr=thr, qb=qb, ws=ws, qn2=(queries * queries).sum(dim=1).max().reshape(1).contiguous(), K2=K2,   # max |q|^2 stays on the device: no host sync
+                      thr=thr, qb=qb, ws=ws, qn2=queries.norm(dim=1).max().reshape(1), K2=K2,   # max |q| stays on the device: no host sync
                       row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
                       idx2=torch.empty((nq, K2), dtype=torch.int64, device=dev), val2=torch.empty((nq, K2), dtype=torch.float32, device=dev),
                       cnt2=torch.empty(nq, dtype=torch.int64, device=dev), keys2=torch.empty((nq, K2), dtype=torch.int64, device=dev),

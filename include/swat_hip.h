@@ -47,7 +47,7 @@ int swat_sim_segmented(const float* feats, int64_t n_rows, int d, const float* q
  *     and / or keys_out (uint64 sort keys ordered(s_r) << 32 | ~row_index[r], 0 for padding, may be NULL). */
 int swat_sim_gathered(const float* feats, const int64_t* row_index, int64_t n_idx, int d, const float* queries,
                       const int32_t* row_seg, float* sims, void* keys_out, int64_t row_base, swat_stream_t stream);
-/*     completeness proof of the dense top-k: fails[0] = number of queries whose need-th exact value is not strictly
+/*     completeness proof of the dense top-k: fails[0] (device or host-mapped pinned memory; stored, not added) = number of queries whose need-th exact value is not strictly
  *     above (K2-th best approximate score, or thr_dev[q] when cand_cnt[q] < K2) + eps_qnorm * sqrt(max_norm2[0]) [*
  *     qnorm_max[0] when that device scalar — max |q| over the batch — is given instead of folding it into
  *     eps_qnorm on the host: no host synchronisation for a new query batch], that kept fewer than `need` rows, or whose

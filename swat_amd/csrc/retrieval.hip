@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void sim_segmented_kernel(const float* __restr
 
 // Completeness proof of the dense top-k (swat_amd/retrieval/dense.py): query q passes iff it kept `need` rows, no candidate
 // list overflowed and its need-th exact value is strictly above bound_q + delta, bound_q = the K2-th best approximate score
-// (or the pruning threshold when fewer than K2 candidates exist), delta = eps |q|max |d|max.  fails[0] += failing queries.
+// (or the pruning threshold when fewer than K2 candidates exist), delta = eps |q|max |d|max.  fails[0] = failing queries.
 __global__ void dense_proof_kernel(const unsigned* __restrict__ cand_cnt, int cap, int K2, const float* __restrict__ approx_val,
                                    const float* __restrict__ thr, const float* __restrict__ exact_val, int k,
                                    const int64_t* __restrict__ out_cnt, int need, float eps_qn, const float* __restrict__ max_norm2,
@@ -141,7 +141,14 @@ __global__ void dense_proof_kernel(const unsigned* __restrict__ cand_cnt, int ca
         const bool ok = out_cnt[q] >= need && c <= (unsigned)cap && exact_val[(int64_t)q * k + need - 1] > bound + delta;
         bad += ok ? 0 : 1;
     }
-    if (bad) atomicAdd(fails, bad);
+    // one workgroup: the count is STORED (not added), so the flag may live in host-mapped pinned memory (no device atomics
+    // there) and needs no reset between calls
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    if (bad) atomicAdd(&total, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) fails[0] = total;
 }
 
 // --------------------------------------------------------------------------------------------

@@ -143,7 +143,7 @@ def _prepared(db, queries, k, sample):
                       row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
                       idx2=torch.empty((nq, K2), dtype=torch.int64, device=dev), val2=torch.empty((nq, K2), dtype=torch.float32, device=dev),
                       cnt2=torch.empty(nq, dtype=torch.int64, device=dev), keys2=torch.empty((nq, K2), dtype=torch.int64, device=dev),
-                      fails=torch.zeros(1, dtype=torch.int32, device=dev),
+                      fails=torch.zeros(1, dtype=torch.int32).pin_memory(),   # host-mapped: the proof kernel stores the count there
                       keys=torch.empty((nq, CAP), dtype=torch.int64, device=dev), cnt=torch.zeros(nq, dtype=torch.int32, device=dev),
                       n2=torch.zeros(1, dtype=torch.float32, device=dev))
     return _cache
@@ -231,9 +231,10 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
     # completeness, proved on the device: a row that was not re-scored has approx <= bound_q (the K2-th kept approximate
     # score, or the threshold when fewer than K2 candidates exist), hence exact <= bound_q + delta < the k-th exact value
     _lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), need,
-                                       float(EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), nq, _lib.ptr(c["fails"]), _lib.stream()),
+                                       float(EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), nq, c["fails"].data_ptr(), _lib.stream()),
                "swat_dense_topk_proof")
-    if c["fails"].item() != 0:  # the one host synchronisation of the call
+    torch.cuda.current_stream().synchronize()  # the one host synchronisation of the call; the flag itself is in pinned host memory
+    if int(c["fails"][0]) != 0:
         last_path = "exact-fallback"
         return topk_dense_exact(db, queries, k, row_base, sample)
     last_path = "bf16-shadow-candidates+exact-rescore" if shadow is not None and c["ws"] is not None else "bf16-candidates+exact-rescore"

@@ -49,9 +49,9 @@ marks[3].record()
 idx = torch.empty((nq, k), dtype=torch.int64, device=dev); val = torch.empty((nq, k), dtype=torch.float32, device=dev); out_cnt = torch.empty(nq, dtype=torch.int64, device=dev)
 _lib.check(L.swat_candidates_topk(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt), _lib.stream()), "ctk2")
 marks[4].record()
-_lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), k, float(dense.EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), nq, _lib.ptr(c["fails"]), _lib.stream()), "proof")
+_lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), k, float(dense.EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), nq, c["fails"].data_ptr(), _lib.stream()), "proof")
 marks[5].record()
-flag = c["fails"].item()
+torch.cuda.current_stream().synchronize(); flag = int(c["fails"][0])
 marks[6].record(); torch.cuda.synchronize()
-names = ["candidates (bf16 MFMA scan)", "candidates_topk (approx, top K2)", "sim_gathered (exact re-score -> keys)", "candidates_topk (exact, top k)", "proof", "item()"]
+names = ["candidates (bf16 MFMA scan)", "candidates_topk (approx, top K2)", "sim_gathered (exact re-score -> keys)", "candidates_topk (exact, top k)", "proof", "stream sync + pinned flag"]
 print(f"K2 = {K2}; " + "; ".join(f"{nme} {marks[i].elapsed_time(marks[i + 1]):.3f}" for i, nme in enumerate(names)) + f"  (ms); failing queries: {flag}")

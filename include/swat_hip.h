@@ -109,6 +109,11 @@ int swat_sim_candidates_shadow(const void* packed, int n_q, const void* shadow, 
 /*     sort each query's candidates, emit the (value desc, row asc) top-k (cap <= 8192). */
 int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k,
                          int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);
+/*     the k2 best candidates of every query UNORDERED (radix select instead of a sort: the exact re-scoring step orders them
+ *     again): slots 0 .. k2-2 in arbitrary order, slot k2-1 = the k2-th best (the bound the completeness proof reads);
+ *     fewer than k2 candidates: all of them, then (-1, -inf). */
+int swat_candidates_select(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k2,
+                           int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);
 /*     SURVEY 8(e) retrieval row: k-way merge of the per-shard top-k lists after the all_gather (the sharded form of the
  *     reference's single sorted() per class, retrieval/sample_retrieval.py:754,807).  idx / val [n_q, m]: the shards' lists
  *     side by side in rank order (global rows, -1 padded), m <= 8192; output = the k best by (value desc, global row asc).

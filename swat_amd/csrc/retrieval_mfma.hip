@@ -259,6 +259,88 @@ __global__ __launch_bounds__(1024) void candidates_topk_kernel(const unsigned lo
     if (tid == 0) out_cnt[q] = n_valid;
 }
 
+// One block per query: the k2 LARGEST of its candidate keys, UNORDERED — what the exact re-scoring step needs (it re-sorts by the
+// exact value anyway), at a third of the full sort's time: the keys sit in LDS, an MSB-first radix select (8 x 8 bits over the
+// 64-bit key) finds the k2-th largest one, a collect pass writes the keys above it to slots 0 .. k2-2 (in arrival order) and the
+// k2-th key itself to slot k2-1, where the completeness proof reads "the K2-th best approximate score".  Fewer than k2
+// candidates: all of them, padded with (-1, -inf).
+__global__ __launch_bounds__(1024) void candidates_select_kernel(const unsigned long long* __restrict__ cand, int cap,
+                                                                 const unsigned* __restrict__ cnt, int k2,
+                                                                 int64_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                                 int64_t* __restrict__ out_cnt) {
+    __shared__ unsigned long long keys[CAND_MAX];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned s_remaining, s_count;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    unsigned n = cnt[q] & 0x7FFFFFFFu;   // (bit 31 of cnt[0] = a staging slot overflowed: the proof sees it through cap)
+    if (n > (unsigned)cap) n = cap;
+    for (int i = tid; i < (int)n; i += 1024) keys[i] = cand[q * (int64_t)cap + i];
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    const int kk = (int)n < k2 ? (int)n : k2;
+    unsigned long long kth = 0ull;   // n <= k2: every key qualifies (keys are non-zero)
+    if ((int)n > k2) {
+        unsigned long long prefix = 0ull, mask = 0ull;
+        unsigned remaining = (unsigned)k2;
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < (int)n; i += 1024) {
+                const unsigned long long key = keys[i];
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {   // lane l owns digits 255-4l .. 252-4l; a shuffle prefix counts the keys in larger digits
+                unsigned h[4], mine = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { h[j] = hist[255 - 4 * tid - j]; mine += h[j]; }
+                unsigned incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+                    if (tid >= o) incl += up;
+                }
+                unsigned before = incl - mine;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (before < remaining && before + h[j] >= remaining) {  // true for exactly one (lane, j)
+                        s_remaining = remaining - before;
+                        s_prefix = prefix | ((unsigned long long)(255 - 4 * tid - j) << shift);
+                    }
+                    before += h[j];
+                }
+            }
+            __syncthreads();
+            remaining = s_remaining;
+            prefix = s_prefix;
+            mask |= 0xFFull << shift;
+            __syncthreads();
+        }
+        kth = prefix;   // keys are unique: exactly k2 - 1 keys are larger
+    }
+    auto emit = [&](int pos, unsigned long long key) {
+        const uint32_t o = (uint32_t)(key >> 32);
+        out_idx[(int64_t)q * k2 + pos] = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+        out_val[(int64_t)q * k2 + pos] = __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+    };
+    for (int i = tid; i < (int)n; i += 1024) {
+        const unsigned long long key = keys[i];
+        if (key > kth) {
+            const unsigned pos = atomicAdd(&s_count, 1u);
+            if ((int)pos < k2) emit((int)pos, key);
+        } else if (key == kth && kth != 0ull) {
+            emit(k2 - 1, key);
+        }
+    }
+    for (int r = kk + tid; r < k2; r += 1024) {
+        out_idx[(int64_t)q * k2 + r] = -1;
+        out_val[(int64_t)q * k2 + r] = -INFINITY;
+    }
+    if (tid == 0) out_cnt[q] = kk;
+}
+
 // (value, global row) lists -> the sort keys candidates_topk_kernel orders: ordered(value) << 32 | ~row; row < 0 -> 0 (sorts
 // last).  -0.0 and 0.0 are one key, as in segment_topk_kernel.
 __global__ void pack_list_keys_kernel(const float* __restrict__ val, const int64_t* __restrict__ idx, int64_t n,
@@ -321,6 +403,14 @@ SWAT_API int swat_candidates_topk(const void* cand_keys, int cap, const void* ca
     hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, (const unsigned long long*)cand_keys,
                        cap, (const unsigned*)cand_cnt, k, out_idx, out_val, out_cnt);
     return check_launch("swat_candidates_topk");
+}
+
+SWAT_API int swat_candidates_select(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k2, int64_t* out_idx,
+                                    float* out_val, int64_t* out_cnt, swat_stream_t s) {
+    SWAT_REQUIRE(cap >= 1 && cap <= CAND_MAX && k2 >= 1 && k2 <= cap, "swat_candidates_select: need 1 <= k2 <= cap <= %d", CAND_MAX);
+    hipLaunchKernelGGL(candidates_select_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, (const unsigned long long*)cand_keys,
+                       cap, (const unsigned*)cand_cnt, k2, out_idx, out_val, out_cnt);
+    return check_launch("swat_candidates_select");
 }
 
 SWAT_API int swat_near_dup_marks(const float* feats, int64_t n, int d, float thr, uint8_t* marks, swat_stream_t s) {

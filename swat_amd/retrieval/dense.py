@@ -218,8 +218,10 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
         shadow = None  # built from other rows (or the rows changed in place): the fp32 scan answers
     candidates(c, db, row_base, shadow)
     idx2, val2, cnt2, keys2 = c["idx2"], c["val2"], c["cnt2"], c["keys2"]
-    _lib.check(L.swat_candidates_topk(_lib.ptr(keys), CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2),
-                                      _lib.stream()), "swat_candidates_topk")
+    # the K2 best approximate rows of every query, unordered (radix select: the exact re-score below orders them again), the K2-th
+    # best score in slot K2 - 1 for the proof
+    _lib.check(L.swat_candidates_select(_lib.ptr(keys), CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2),
+                                        _lib.stream()), "swat_candidates_select")
     # exact value of the K2 best approximate rows of every query, as (value desc, global row asc) sort keys
     ops.sim_gathered(db, idx2.view(-1), queries, c["row_seg"], keys_out=keys2, row_base=row_base, want_sims=False)
     dev = db.device

@@ -42,7 +42,7 @@ marks[0].record()
 cnt.zero_(); n2.zero_()
 dense.candidates(c, db, shadow=SH)
 marks[1].record()
-_lib.check(L.swat_candidates_topk(_lib.ptr(keys), dense.CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2), _lib.stream()), "ctk")
+_lib.check(L.swat_candidates_select(_lib.ptr(keys), dense.CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2), _lib.stream()), "csel")
 marks[2].record()
 ops.sim_gathered(db, idx2.view(-1), q, c["row_seg"], keys_out=keys2, want_sims=False)
 marks[3].record()
@@ -53,5 +53,5 @@ _lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2),
 marks[5].record()
 torch.cuda.current_stream().synchronize(); flag = int(c["fails"][0])
 marks[6].record(); torch.cuda.synchronize()
-names = ["candidates (bf16 MFMA scan)", "candidates_topk (approx, top K2)", "sim_gathered (exact re-score -> keys)", "candidates_topk (exact, top k)", "proof", "stream sync + pinned flag"]
+names = ["candidates (bf16 MFMA scan)", "candidates_select (approx, top K2, unordered)", "sim_gathered (exact re-score -> keys)", "candidates_topk (exact, top k)", "proof", "stream sync + pinned flag"]
 print(f"K2 = {K2}; " + "; ".join(f"{nme} {marks[i].elapsed_time(marks[i + 1]):.3f}" for i, nme in enumerate(names)) + f"  (ms); failing queries: {flag}")

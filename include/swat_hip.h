@@ -111,9 +111,16 @@ int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, i
                          int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);
 /*     the k2 best candidates of every query UNORDERED (radix select instead of a sort: the exact re-scoring step orders them
  *     again): slots 0 .. k2-2 in arbitrary order, slot k2-1 = the k2-th best (the bound the completeness proof reads);
- *     fewer than k2 candidates: all of them, then (-1, -inf). */
+ *     fewer than k2 candidates: all of them, then (-1, -inf).
+ *     zero_fails (device int, may be NULL) is set to 0: the failure counter swat_candidates_topk_proof adds to later in the call. */
 int swat_candidates_select(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k2,
-                           int64_t* out_idx, float* out_val, int64_t* out_cnt, swat_stream_t stream);
+                           int64_t* out_idx, float* out_val, int64_t* out_cnt, int* zero_fails, swat_stream_t stream);
+/*     swat_candidates_topk over the re-scored keys with swat_dense_topk_proof folded into the same launch: fails (DEVICE int,
+ *     zeroed earlier in the call) += queries whose proof does not hold; scan_cnt / scan_cap = the candidate pass's counts / cap. */
+int swat_candidates_topk_proof(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k, int64_t* out_idx,
+                               float* out_val, int64_t* out_cnt, const void* scan_cnt, int scan_cap, int K2,
+                               const float* approx_val, const float* thr_dev, int need, float eps, const float* max_norm2,
+                               const float* qnorm_max, int* fails, swat_stream_t stream);
 /*     SURVEY 8(e) retrieval row: k-way merge of the per-shard top-k lists after the all_gather (the sharded form of the
  *     reference's single sorted() per class, retrieval/sample_retrieval.py:754,807).  idx / val [n_q, m]: the shards' lists
  *     side by side in rank order (global rows, -1 padded), m <= 8192; output = the k best by (value desc, global row asc).

@@ -204,10 +204,23 @@ __global__ __launch_bounds__(256) void near_dup_kernel(const float* __restrict__
 // keys 2 i0 .. 2 i0 + 127), so only the stages of stride >= 128 — 10 of the 66 for 2048 keys — pay a workgroup barrier; the
 // others are ordered by the wave's own in-order LDS queue.
 constexpr int CAND_MAX = 8192;
+// The completeness proof of the dense top-k, folded into the last sort of a query (swat_candidates_topk_proof): see dense_proof_kernel
+// in retrieval.hip for the condition; fails is a device counter some earlier kernel of the call has zeroed.
+struct TopkProof {
+    const unsigned* cand_cnt;   // candidates the scan found per query (null: no proof)
+    const float* approx_val;    // [n_q, K2]: slot K2 - 1 = the K2-th best approximate score
+    const float* thr;           // pruning thresholds
+    const float* max_norm2;     // max |row|^2
+    const float* qnorm_max;     // max |q|
+    int* fails;
+    int scan_cap, K2, need;
+    float eps;
+};
+
 __global__ __launch_bounds__(1024) void candidates_topk_kernel(const unsigned long long* __restrict__ cand, int cap,
                                                                const unsigned* __restrict__ cnt, int k,
                                                                int64_t* __restrict__ out_idx, float* __restrict__ out_val,
-                                                               int64_t* __restrict__ out_cnt) {
+                                                               int64_t* __restrict__ out_cnt, const TopkProof pr) {
     __shared__ unsigned long long keys[CAND_MAX];
     const int q = blockIdx.x, tid = threadIdx.x;
     unsigned n = cnt[q];
@@ -256,7 +269,22 @@ __global__ __launch_bounds__(1024) void candidates_topk_kernel(const unsigned lo
     __syncthreads();
     if (valid) atomicAdd(&n_valid, valid);
     __syncthreads();
-    if (tid == 0) out_cnt[q] = n_valid;
+    if (tid == 0) {
+        out_cnt[q] = n_valid;
+        if (pr.cand_cnt) {
+            const unsigned c = pr.cand_cnt[q];
+            const float bound = c >= (unsigned)pr.K2 ? pr.approx_val[(int64_t)q * pr.K2 + pr.K2 - 1] : pr.thr[q];
+            const float delta = pr.eps * pr.qnorm_max[0] * sqrtf(pr.max_norm2[0]);
+            float kth_val = -INFINITY;
+            if (n_valid >= pr.need) {
+                const unsigned long long key = keys[pr.need - 1];
+                const uint32_t o = (uint32_t)(key >> 32);
+                kth_val = __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+            }
+            const bool ok = n_valid >= pr.need && c <= (unsigned)pr.scan_cap && kth_val > bound + delta;
+            if (!ok) atomicAdd(pr.fails, 1);
+        }
+    }
 }
 
 // One block per query: the k2 LARGEST of its candidate keys, UNORDERED — what the exact re-scoring step needs (it re-sorts by the
@@ -267,9 +295,10 @@ __global__ __launch_bounds__(1024) void candidates_topk_kernel(const unsigned lo
 __global__ __launch_bounds__(1024) void candidates_select_kernel(const unsigned long long* __restrict__ cand, int cap,
                                                                  const unsigned* __restrict__ cnt, int k2,
                                                                  int64_t* __restrict__ out_idx, float* __restrict__ out_val,
-                                                                 int64_t* __restrict__ out_cnt) {
+                                                                 int64_t* __restrict__ out_cnt, int* __restrict__ zero_me) {
     __shared__ unsigned long long keys[CAND_MAX];
     __shared__ unsigned hist[256];
+    if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;   // the failure counter of this call (read two launches later)
     __shared__ unsigned long long s_prefix;
     __shared__ unsigned s_remaining, s_count;
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -374,7 +403,7 @@ SWAT_API int swat_merge_topk_lists(const int64_t* idx, const float* val, int n_q
     unsigned* cnt = (unsigned*)((char*)workspace + ((int64_t)n_q * m * 8 + 255) / 256 * 256);
     const int64_t n = (int64_t)n_q * m;
     hipLaunchKernelGGL(pack_list_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, val, idx, n, keys, cnt, n_q, m);
-    hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, keys, m, cnt, k, out_idx, out_val, out_cnt);
+    hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, keys, m, cnt, k, out_idx, out_val, out_cnt, TopkProof{});
     return check_launch("swat_merge_topk_lists");
 }
 
@@ -401,15 +430,31 @@ SWAT_API int swat_candidates_topk(const void* cand_keys, int cap, const void* ca
                                   float* out_val, int64_t* out_cnt, swat_stream_t s) {
     SWAT_REQUIRE(cap >= 1 && cap <= CAND_MAX && k >= 1 && k <= cap, "swat_candidates_topk: need 1 <= k <= cap <= %d", CAND_MAX);
     hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, (const unsigned long long*)cand_keys,
-                       cap, (const unsigned*)cand_cnt, k, out_idx, out_val, out_cnt);
+                       cap, (const unsigned*)cand_cnt, k, out_idx, out_val, out_cnt, TopkProof{});
     return check_launch("swat_candidates_topk");
 }
 
+// swat_candidates_topk over the exactly re-scored keys + swat_dense_topk_proof in the same launch (one block per query: its thread 0
+// checks the query once its list is sorted).  fails: DEVICE counter, zeroed by the swat_candidates_select launch of the same call
+// (its zero_fails argument) or by the caller; scan_cnt / scan_cap: what the candidate pass counted / its list capacity.
+SWAT_API int swat_candidates_topk_proof(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k, int64_t* out_idx,
+                                        float* out_val, int64_t* out_cnt, const void* scan_cnt, int scan_cap, int K2,
+                                        const float* approx_val, const float* thr_dev, int need, float eps, const float* max_norm2,
+                                        const float* qnorm_max, int* fails, swat_stream_t s) {
+    SWAT_REQUIRE(cap >= 1 && cap <= CAND_MAX && k >= 1 && k <= cap, "swat_candidates_topk_proof: need 1 <= k <= cap <= %d", CAND_MAX);
+    SWAT_REQUIRE(scan_cnt && approx_val && thr_dev && max_norm2 && qnorm_max && fails && need >= 1 && need <= k && K2 >= 1,
+                 "swat_candidates_topk_proof: null pointer or bad need / K2");
+    TopkProof pr{(const unsigned*)scan_cnt, approx_val, thr_dev, max_norm2, qnorm_max, fails, scan_cap, K2, need, eps};
+    hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, (const unsigned long long*)cand_keys,
+                       cap, (const unsigned*)cand_cnt, k, out_idx, out_val, out_cnt, pr);
+    return check_launch("swat_candidates_topk_proof");
+}
+
 SWAT_API int swat_candidates_select(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k2, int64_t* out_idx,
-                                    float* out_val, int64_t* out_cnt, swat_stream_t s) {
+                                    float* out_val, int64_t* out_cnt, int* zero_fails, swat_stream_t s) {
     SWAT_REQUIRE(cap >= 1 && cap <= CAND_MAX && k2 >= 1 && k2 <= cap, "swat_candidates_select: need 1 <= k2 <= cap <= %d", CAND_MAX);
     hipLaunchKernelGGL(candidates_select_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, (const unsigned long long*)cand_keys,
-                       cap, (const unsigned*)cand_cnt, k2, out_idx, out_val, out_cnt);
+                       cap, (const unsigned*)cand_cnt, k2, out_idx, out_val, out_cnt, zero_fails);
     return check_launch("swat_candidates_select");
 }
 

@@ -143,7 +143,7 @@ def _prepared(db, queries, k, sample):
                       row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
                       idx2=torch.empty((nq, K2), dtype=torch.int64, device=dev), val2=torch.empty((nq, K2), dtype=torch.float32, device=dev),
                       cnt2=torch.empty(nq, dtype=torch.int64, device=dev), keys2=torch.empty((nq, K2), dtype=torch.int64, device=dev),
-                      fails=torch.zeros(1, dtype=torch.int32).pin_memory(),   # host-mapped: the proof kernel stores the count there
+                      fails=torch.zeros(1, dtype=torch.int32, device=dev),   # zeroed by the select launch, added to by the last one
                       keys=torch.empty((nq, CAP), dtype=torch.int64, device=dev), cnt=torch.zeros(nq, dtype=torch.int32, device=dev),
                       n2=torch.zeros(1, dtype=torch.float32, device=dev))
     return _cache
@@ -221,22 +221,20 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
     # the K2 best approximate rows of every query, unordered (radix select: the exact re-score below orders them again), the K2-th
     # best score in slot K2 - 1 for the proof
     _lib.check(L.swat_candidates_select(_lib.ptr(keys), CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2),
-                                        _lib.stream()), "swat_candidates_select")
+                                        _lib.ptr(c["fails"]), _lib.stream()), "swat_candidates_select")
     # exact value of the K2 best approximate rows of every query, as (value desc, global row asc) sort keys
     ops.sim_gathered(db, idx2.view(-1), queries, c["row_seg"], keys_out=keys2, row_base=row_base, want_sims=False)
     dev = db.device
     idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
     val = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_cnt = torch.empty(nq, dtype=torch.int64, device=dev)
-    _lib.check(L.swat_candidates_topk(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt),
-                                      _lib.stream()), "swat_candidates_topk")
-    # completeness, proved on the device: a row that was not re-scored has approx <= bound_q (the K2-th kept approximate
-    # score, or the threshold when fewer than K2 candidates exist), hence exact <= bound_q + delta < the k-th exact value
-    _lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), need,
-                                       float(EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), nq, c["fails"].data_ptr(), _lib.stream()),
-               "swat_dense_topk_proof")
-    torch.cuda.current_stream().synchronize()  # the one host synchronisation of the call; the flag itself is in pinned host memory
-    if int(c["fails"][0]) != 0:
+    # the exact top-k of the re-scored rows, and in the same launch the completeness proof: a row that was not re-scored has
+    # approx <= bound_q (the K2-th kept approximate score, or the threshold when fewer than K2 candidates exist), hence
+    # exact <= bound_q + delta < the k-th exact value
+    _lib.check(L.swat_candidates_topk_proof(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt),
+                                            _lib.ptr(cnt), CAP, K2, _lib.ptr(val2), _lib.ptr(thr), need, float(EPS_BF16), _lib.ptr(n2),
+                                            _lib.ptr(c["qn2"]), _lib.ptr(c["fails"]), _lib.stream()), "swat_candidates_topk_proof")
+    if c["fails"].item() != 0:  # the one host synchronisation of the call
         last_path = "exact-fallback"
         return topk_dense_exact(db, queries, k, row_base, sample)
     last_path = "bf16-shadow-candidates+exact-rescore" if shadow is not None and c["ws"] is not None else "bf16-candidates+exact-rescore"

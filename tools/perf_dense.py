@@ -42,16 +42,15 @@ marks[0].record()
 cnt.zero_(); n2.zero_()
 dense.candidates(c, db, shadow=SH)
 marks[1].record()
-_lib.check(L.swat_candidates_select(_lib.ptr(keys), dense.CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2), _lib.stream()), "csel")
+_lib.check(L.swat_candidates_select(_lib.ptr(keys), dense.CAP, _lib.ptr(cnt), nq, K2, _lib.ptr(idx2), _lib.ptr(val2), _lib.ptr(cnt2), _lib.ptr(c["fails"]), _lib.stream()), "csel")
 marks[2].record()
 ops.sim_gathered(db, idx2.view(-1), q, c["row_seg"], keys_out=keys2, want_sims=False)
 marks[3].record()
 idx = torch.empty((nq, k), dtype=torch.int64, device=dev); val = torch.empty((nq, k), dtype=torch.float32, device=dev); out_cnt = torch.empty(nq, dtype=torch.int64, device=dev)
-_lib.check(L.swat_candidates_topk(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt), _lib.stream()), "ctk2")
+_lib.check(L.swat_candidates_topk_proof(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt), _lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2), _lib.ptr(thr), k, float(dense.EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), _lib.ptr(c["fails"]), _lib.stream()), "ctk2")
 marks[4].record()
-_lib.check(L.swat_dense_topk_proof(_lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2), _lib.ptr(thr), _lib.ptr(val), k, _lib.ptr(out_cnt), k, float(dense.EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), nq, c["fails"].data_ptr(), _lib.stream()), "proof")
 marks[5].record()
-torch.cuda.current_stream().synchronize(); flag = int(c["fails"][0])
+flag = c["fails"].item()
 marks[6].record(); torch.cuda.synchronize()
-names = ["candidates (bf16 MFMA scan)", "candidates_select (approx, top K2, unordered)", "sim_gathered (exact re-score -> keys)", "candidates_topk (exact, top k)", "proof", "stream sync + pinned flag"]
+names = ["candidates (bf16 MFMA scan)", "candidates_select (approx, top K2, unordered)", "sim_gathered (exact re-score -> keys)", "candidates_topk (exact, top k) + proof", "-", "item()"]
 print(f"K2 = {K2}; " + "; ".join(f"{nme} {marks[i].elapsed_time(marks[i + 1]):.3f}" for i, nme in enumerate(names)) + f"  (ms); failing queries: {flag}")

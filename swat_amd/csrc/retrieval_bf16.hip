@@ -667,7 +667,8 @@ __global__ __launch_bounds__(256) void regroup_candidates_kernel(const uint4* __
     }
     __syncthreads();
     for (int q = tid; q < n_q; q += 256)
-        if (hist[q]) base[q] = atomicAdd(&cnt[q], hist[q]);
+        if (hist[q]) base[q] = atomicAdd(&cnt[q], hist[q]) & 0x7FFFFFFFu;   // (another block may already have set cnt[0]'s overflow bit:
+                                                                            //  taken as part of the position it filed query 0's records nowhere)
     __syncthreads();
     for (int sl = 0; sl < 16; ++sl) {
         const uint4* src = stage + (size_t)(s0 + sl) * stage_cap;

@@ -223,8 +223,8 @@ __global__ __launch_bounds__(1024) void candidates_topk_kernel(const unsigned lo
                                                                int64_t* __restrict__ out_cnt, const TopkProof pr) {
     __shared__ unsigned long long keys[CAND_MAX];
     const int q = blockIdx.x, tid = threadIdx.x;
-    unsigned n = cnt[q];
-    if (n > (unsigned)cap) n = cap;
+    unsigned n = cnt[q] & 0x7FFFFFFFu;   // bit 31 of cnt[0] = "a staging slot overflowed" (the proof reads it); the entries beyond the
+    if (n > (unsigned)cap) n = cap;      // count were never written
     int np2 = 1;
     while (np2 < (int)n) np2 <<= 1;
     for (int i = tid; i < np2; i += 1024) keys[i] = i < (int)n ? cand[q * (int64_t)cap + i] : 0ull;

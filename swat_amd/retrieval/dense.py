@@ -50,7 +50,7 @@ def _thresholds(queries, db, k, sample, boost, approx=False):
         _sample.update(key=skey, ref=weakref.ref(db), rows=db[::stride][:ns].contiguous())
     smp = _sample["rows"]
     d = db.shape[1]
-    if approx and d % 64 == 0 and (nq * d) % 4 == 0:
+    if approx and d % 64 == 0 and ns % 4 == 0:
         # the candidate pass compares bf16 MFMA scores with these thresholds, so bf16 sample scores serve as well as exact ones and
         # cost a sixth: one bf16 GEMM [n_q, d] x [n_s, d]^T (the step's own product kernels) instead of the f32-matrix-core scan
         from .. import ops as aops

@@ -247,6 +247,30 @@ def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale, d):
     assert torch.equal(idx3, e3_idx) and torch.equal(val3, e3_val)
 
 
+def test_dense_edge_shapes_and_the_staging_overflow_path():
+    """Tiny / ragged shards, one query, k near n, through the shadow scan, in ONE process and over poisoned memory: with n <= 4096
+    every (query, row) is a candidate, 17 rows x 33 queries overflow a wave's staging slot (the overflow bit of cnt[0] is set while
+    other workgroups are still filing query 0's records — once taken as part of their position, which left its list unwritten and
+    sent the re-score to garbage rows: a GPU memory fault), and the call must fall back to the exact scan, not crash."""
+    from swat_amd.retrieval import dense
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(5)
+    for d, n, nq, k in ((256, 17, 1, 500), (256, 17, 33, 1), (512, 1, 1, 1), (512, 255, 33, 10), (768, 257, 200, 500), (1024, 300, 1, 10),
+                        (256, 4097, 200, 500), (512, 9001, 33, 10)):
+        poison = torch.full((64 << 20,), -1, dtype=torch.int8, device=dev)   # the next allocations reuse these bytes
+        del poison
+        db = torch.randn(n, d, device=dev, generator=g)
+        db /= db.norm(dim=-1, keepdim=True)
+        q = torch.randn(nq, d, device=dev, generator=g)
+        q /= q.norm(dim=-1, keepdim=True)
+        i1, v1, c1 = dense.topk_dense(db, q, k, row_base=7, shadow=dense.DenseShadow(db))
+        path = dense.last_path
+        i2, v2, c2 = dense.topk_dense_exact(db, q, k, row_base=7)
+        assert torch.equal(i1, i2) and torch.equal(v1, v2) and torch.equal(c1, c2), (d, n, nq, k, path)
+        if (n, nq) == (17, 33):
+            assert path == "exact-fallback"
+
+
 def test_dense_topk_beyond_the_error_bound_width_takes_the_exact_scan():
     """d = 2048 > 1024: the bf16 error bound of the completeness proof does not cover the fp32 accumulation any more (ADVICE
     r02), so topk_dense answers with the exact scan — and equals the oracle."""

@@ -100,7 +100,9 @@ int swat_sim_candidates_packed(const void* packed, int n_q, const float* db, int
  *     once and stored in the scan's fragment order, swat_dense_shadow_bytes(n_db, d) = 2 n_db d bytes (0: d not supported).
  *     swat_dense_build_shadow also leaves max |row|^2 of the fp32 rows in *max_norm2 (zero it first).  The candidate lists are
  *     those of swat_sim_candidates_packed bit for bit (same roundings, same order of accumulation) from half the HBM bytes;
- *     the exact re-scoring and the completeness proof still read the fp32 rows. */
+ *     the exact re-scoring and the completeness proof still read the fp32 rows.  swat_sim_candidates_shadow wants the first
+ *     16 KiB of `workspace` (the staging-slot counters) ZERO on entry and leaves them zero: clear the workspace once when it
+ *     is allocated. */
 int64_t swat_dense_shadow_bytes(int64_t n_db, int d);
 int swat_dense_build_shadow(const float* db, int64_t n_db, int d, void* shadow, float* max_norm2, swat_stream_t stream);
 int swat_sim_candidates_shadow(const void* packed, int n_q, const void* shadow, int64_t n_db, int d, const float* thr_dev,
@@ -116,11 +118,12 @@ int swat_candidates_topk(const void* cand_keys, int cap, const void* cand_cnt, i
 int swat_candidates_select(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k2,
                            int64_t* out_idx, float* out_val, int64_t* out_cnt, int* zero_fails, swat_stream_t stream);
 /*     swat_candidates_topk over the re-scored keys with swat_dense_topk_proof folded into the same launch: fails (DEVICE int,
- *     zeroed earlier in the call) += queries whose proof does not hold; scan_cnt / scan_cap = the candidate pass's counts / cap. */
+ *     zeroed earlier in the call) += queries whose proof does not hold; scan_cnt / scan_cap = the candidate pass's counts / cap;
+ *     zero_scan_cnt != 0: scan_cnt[q] is cleared once read (cand_cnt must then be the same array or no longer needed). */
 int swat_candidates_topk_proof(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k, int64_t* out_idx,
-                               float* out_val, int64_t* out_cnt, const void* scan_cnt, int scan_cap, int K2,
+                               float* out_val, int64_t* out_cnt, void* scan_cnt, int scan_cap, int K2,
                                const float* approx_val, const float* thr_dev, int need, float eps, const float* max_norm2,
-                               const float* qnorm_max, int* fails, swat_stream_t stream);
+                               const float* qnorm_max, int* fails, int zero_scan_cnt, swat_stream_t stream);
 /*     SURVEY 8(e) retrieval row: k-way merge of the per-shard top-k lists after the all_gather (the sharded form of the
  *     reference's single sorted() per class, retrieval/sample_retrieval.py:754,807).  idx / val [n_q, m]: the shards' lists
  *     side by side in rank order (global rows, -1 padded), m <= 8192; output = the k best by (value desc, global row asc).

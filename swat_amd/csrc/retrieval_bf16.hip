@@ -641,7 +641,7 @@ __global__ __launch_bounds__(512, 1) void sim_candidates_shadow2_kernel(const un
 // slots, counts its records per query in LDS, reserves one range per (block, query) with a single global atomic and scatters.
 // A staging slot that overflowed sets the top bit of cnt[0], which every consumer reads as "list overflowed".
 __global__ __launch_bounds__(256) void regroup_candidates_kernel(const uint4* __restrict__ stage, unsigned stage_cap,
-                                                                 const unsigned* __restrict__ stage_cnt, int n_slots,
+                                                                 unsigned* __restrict__ stage_cnt, int n_slots,
                                                                  unsigned long long* __restrict__ cand, int cap,
                                                                  unsigned* __restrict__ cnt, int n_q) {
     extern __shared__ unsigned rg_sh[];
@@ -653,6 +653,7 @@ __global__ __launch_bounds__(256) void regroup_candidates_kernel(const uint4* __
     for (int q = tid; q < n_q; q += 256) { hist[q] = 0u; fill[q] = 0u; }
     if (tid < 16) {
         unsigned n = s0 + tid < n_slots ? stage_cnt[s0 + tid] : 0u;
+        if (s0 + tid < n_slots) stage_cnt[s0 + tid] = 0u;   // consumed: the next call's scan starts from clean slots (no memset launch)
         if (n > stage_cap) {
             atomicOr(&cnt[0], 0x80000000u);
             n = stage_cap;
@@ -810,7 +811,9 @@ static int dense_candidates_packed(const void* packed, int n_q, const float* db,
     const unsigned stage_cap = (unsigned)((workspace_bytes - kDenseCntBytes) / (kDenseSlots * 16));
     unsigned* stage_cnt = (unsigned*)workspace;
     uint4* stage = (uint4*)((char*)workspace + kDenseCntBytes);
-    SWAT_HIP(hipMemsetAsync(stage_cnt, 0, kDenseSlots * sizeof(unsigned), (hipStream_t)s));
+    // the slot counters: this call's regroup launch leaves them zero again, so only the form whose contract does not ask the caller
+    // for a zeroed workspace pays the memset (the shadow form does: swat_hip.h)
+    if (!shadow) SWAT_HIP(hipMemsetAsync(stage_cnt, 0, kDenseSlots * sizeof(unsigned), (hipStream_t)s));
     SWAT_REQUIRE(d > 0 && d % 128 == 0, "swat_sim_candidates_packed: d=%d must be a multiple of 128", d);
     SWAT_REQUIRE(n_q > 0 && n_db > 0, "swat_sim_candidates_packed: empty operand");
     SWAT_REQUIRE(row_base + n_db < (1ll << 32), "swat_sim_candidates_packed: global rows must fit 32 bits");

@@ -215,6 +215,7 @@ struct TopkProof {
     int* fails;
     int scan_cap, K2, need;
     float eps;
+    unsigned* zero_cnt;         // not null: cnt[q] = 0 once read (the next call's regroup adds into clean counters)
 };
 
 __global__ __launch_bounds__(1024) void candidates_topk_kernel(const unsigned long long* __restrict__ cand, int cap,
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(1024) void candidates_topk_kernel(const unsigned lo
             }
             const bool ok = n_valid >= pr.need && c <= (unsigned)pr.scan_cap && kth_val > bound + delta;
             if (!ok) atomicAdd(pr.fails, 1);
+            if (pr.zero_cnt) pr.zero_cnt[q] = 0u;
         }
     }
 }
@@ -438,13 +440,14 @@ SWAT_API int swat_candidates_topk(const void* cand_keys, int cap, const void* ca
 // checks the query once its list is sorted).  fails: DEVICE counter, zeroed by the swat_candidates_select launch of the same call
 // (its zero_fails argument) or by the caller; scan_cnt / scan_cap: what the candidate pass counted / its list capacity.
 SWAT_API int swat_candidates_topk_proof(const void* cand_keys, int cap, const void* cand_cnt, int n_q, int k, int64_t* out_idx,
-                                        float* out_val, int64_t* out_cnt, const void* scan_cnt, int scan_cap, int K2,
+                                        float* out_val, int64_t* out_cnt, void* scan_cnt, int scan_cap, int K2,
                                         const float* approx_val, const float* thr_dev, int need, float eps, const float* max_norm2,
-                                        const float* qnorm_max, int* fails, swat_stream_t s) {
+                                        const float* qnorm_max, int* fails, int zero_scan_cnt, swat_stream_t s) {
     SWAT_REQUIRE(cap >= 1 && cap <= CAND_MAX && k >= 1 && k <= cap, "swat_candidates_topk_proof: need 1 <= k <= cap <= %d", CAND_MAX);
     SWAT_REQUIRE(scan_cnt && approx_val && thr_dev && max_norm2 && qnorm_max && fails && need >= 1 && need <= k && K2 >= 1,
                  "swat_candidates_topk_proof: null pointer or bad need / K2");
-    TopkProof pr{(const unsigned*)scan_cnt, approx_val, thr_dev, max_norm2, qnorm_max, fails, scan_cap, K2, need, eps};
+    TopkProof pr{(const unsigned*)scan_cnt, approx_val, thr_dev, max_norm2, qnorm_max, fails, scan_cap, K2, need, eps,
+                 zero_scan_cnt ? (unsigned*)scan_cnt : nullptr};
     hipLaunchKernelGGL(candidates_topk_kernel, dim3(n_q), dim3(1024), 0, (hipStream_t)s, (const unsigned long long*)cand_keys,
                        cap, (const unsigned*)cand_cnt, k, out_idx, out_val, out_cnt, pr);
     return check_launch("swat_candidates_topk_proof");

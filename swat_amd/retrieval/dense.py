@@ -134,7 +134,7 @@ def _prepared(db, queries, k, sample):
         if nbytes and wbytes:  # d % 128 == 0, n_q <= 4096: the packed image the deep kernel reads linearly (csrc/retrieval_bf16.hip)
             qb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(_lib.lib().swat_dense_pack_queries(_lib.ptr(queries), nq, d, _lib.ptr(qb), _lib.stream()), "swat_dense_pack_queries")
-            ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+            ws = torch.zeros(wbytes, dtype=torch.uint8, device=dev)   # the slot counters start (and are left) zero: swat_sim_candidates_shadow
         else:
             qb = queries.to(torch.bfloat16).contiguous()
         _cache.clear()
@@ -173,15 +173,18 @@ class DenseShadow:
         return self._ref() is db and self._key == (db.data_ptr(), tuple(db.shape), db._version)
 
 
-def candidates(c, db, row_base=0, shadow=None):
-    """The candidate pass on prepared buffers c (= _prepared(...)): appends to c["keys"] / c["cnt"], max |row|^2 to c["n2"]."""
+def candidates(c, db, row_base=0, shadow=None, set_n2=True):
+    """The candidate pass on prepared buffers c (= _prepared(...)): appends to c["keys"] / c["cnt"], max |row|^2 to c["n2"]
+    (with a shadow: a copy of its max |row|^2, unless set_n2 is False — topk_dense hands shadow.n2 to the proof directly)."""
     L = _lib.lib()
     nq = c["cnt"].numel()
+    c["cnt_clean"] = False   # the counters now hold this pass's counts (topk_dense's last launch clears them again)
     if shadow is not None and c["ws"] is not None:
         _lib.check(L.swat_sim_candidates_shadow(_lib.ptr(c["qb"]), nq, _lib.ptr(shadow.rows), db.shape[0], db.shape[1], _lib.ptr(c["thr"]),
                                                 int(row_base), _lib.ptr(c["keys"]), CAP, _lib.ptr(c["cnt"]), _lib.ptr(c["ws"]),
                                                 c["ws"].numel(), _lib.stream()), "swat_sim_candidates_shadow")
-        c["n2"].copy_(shadow.n2)
+        if set_n2:
+            c["n2"].copy_(shadow.n2)
         return
     args = (_lib.ptr(c["qb"]), nq, _lib.ptr(db), db.shape[0], db.shape[1], _lib.ptr(c["thr"]), int(row_base), _lib.ptr(c["keys"]), CAP,
             _lib.ptr(c["cnt"]), _lib.ptr(c["n2"]))
@@ -212,11 +215,20 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
     c = _prepared(db, queries, k, sample)
     K2, thr, keys, cnt, n2 = c["K2"], c["thr"], c["keys"], c["cnt"], c["n2"]
     L = _lib.lib()
-    cnt.zero_()
-    n2.zero_()
     if shadow is not None and not shadow.matches(db):
         shadow = None  # built from other rows (or the rows changed in place): the fp32 scan answers
-    candidates(c, db, row_base, shadow)
+    use_shadow = shadow is not None and c["ws"] is not None
+    # small launches count at 0.5 ms per pass: the candidate counters are cleared by the last launch of the previous call (cleared
+    # here only after a call that did not get that far), the staging slots by the regroup launch, and with a shadow max |row|^2 is
+    # the build's own scalar — no fill / copy / memset launches on the way
+    if not c.get("cnt_clean", False):
+        cnt.zero_()
+    c["cnt_clean"] = False
+    if use_shadow:
+        n2 = shadow.n2
+    else:
+        n2.zero_()
+    candidates(c, db, row_base, shadow, set_n2=False)
     idx2, val2, cnt2, keys2 = c["idx2"], c["val2"], c["cnt2"], c["keys2"]
     # the K2 best approximate rows of every query, unordered (radix select: the exact re-score below orders them again), the K2-th
     # best score in slot K2 - 1 for the proof
@@ -233,11 +245,12 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
     # exact <= bound_q + delta < the k-th exact value
     _lib.check(L.swat_candidates_topk_proof(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt),
                                             _lib.ptr(cnt), CAP, K2, _lib.ptr(val2), _lib.ptr(thr), need, float(EPS_BF16), _lib.ptr(n2),
-                                            _lib.ptr(c["qn2"]), _lib.ptr(c["fails"]), _lib.stream()), "swat_candidates_topk_proof")
+                                            _lib.ptr(c["qn2"]), _lib.ptr(c["fails"]), 1, _lib.stream()), "swat_candidates_topk_proof")
+    c["cnt_clean"] = True   # (the launch above clears every cnt[q] once it has read it)
     if c["fails"].item() != 0:  # the one host synchronisation of the call
         last_path = "exact-fallback"
         return topk_dense_exact(db, queries, k, row_base, sample)
-    last_path = "bf16-shadow-candidates+exact-rescore" if shadow is not None and c["ws"] is not None else "bf16-candidates+exact-rescore"
+    last_path = "bf16-shadow-candidates+exact-rescore" if use_shadow else "bf16-candidates+exact-rescore"
     return idx, val, out_cnt
 
 

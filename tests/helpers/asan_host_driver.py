@@ -68,8 +68,8 @@ for nq in (1, 200, 1000):
     run("swat_sim_candidates_packed", P(), nq, P(1), 1 << 20, 768, P(2), 0, P(3), 8192, P(4), P(5), P(6), wb, N)
 run("swat_candidates_select", P(), 8192, P(1), 200, 1024, P(2), P(3), P(4), P(5), N)
 run("swat_candidates_select", P(), 9000, P(1), 200, 1024, P(2), P(3), P(4), N, N)
-run("swat_candidates_topk_proof", P(), 1024, P(1), 200, 500, P(2), P(3), P(4), P(1), 8192, 1024, P(5), P(6), 500, 0.004, P(7), P(8), P(9), N)
-run("swat_candidates_topk_proof", P(), 1024, P(1), 200, 500, P(2), P(3), P(4), N, 8192, 1024, P(5), P(6), 500, 0.004, P(7), P(8), P(9), N)
+run("swat_candidates_topk_proof", P(), 1024, P(1), 200, 500, P(2), P(3), P(4), P(1), 8192, 1024, P(5), P(6), 500, 0.004, P(7), P(8), P(9), 1, N)
+run("swat_candidates_topk_proof", P(), 1024, P(1), 200, 500, P(2), P(3), P(4), N, 8192, 1024, P(5), P(6), 500, 0.004, P(7), P(8), P(9), 0, N)
 run("swat_candidates_topk", P(), 8192, P(1), 200, 9000, P(2), P(3), P(4), N)
 run("swat_cast_bf16", P(), P(1), 7, N)
 run("swat_widen_bf16", P(), P(1), 7, N)

@@ -207,19 +207,27 @@ def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale, d):
     # the completeness proof as a launch of its own (swat_dense_topk_proof) agrees with the one folded into the last sort
     # (swat_candidates_topk_proof): zero failures on these buffers, every query failing once the error bound is made absurd
     from swat_amd import _lib
+    from swat_amd.retrieval import ops as rops
     L, c = _lib.lib(), dense._prepared(d_db, d_q, k, 16384)
+    c["cnt"].zero_(); c["n2"].zero_()   # (topk_dense leaves the counters cleared: rebuild the intermediate state stage by stage)
+    dense.candidates(c, d_db, 1000)
+    _lib.check(L.swat_candidates_select(_lib.ptr(c["keys"]), dense.CAP, _lib.ptr(c["cnt"]), nq, c["K2"], _lib.ptr(c["idx2"]), _lib.ptr(c["val2"]),
+                                        _lib.ptr(c["cnt2"]), None, _lib.stream()), "swat_candidates_select")
+    rops.sim_gathered(d_db, c["idx2"].view(-1), d_q, c["row_seg"], keys_out=c["keys2"], row_base=1000, want_sims=False)
     fails = torch.full((1,), 7, dtype=torch.int32, device=dev)
     for eps, want in ((dense.EPS_BF16, 0), (1e3, nq)):
-        _lib.check(L.swat_dense_topk_proof(_lib.ptr(c["cnt"]), dense.CAP, c["K2"], _lib.ptr(c["val2"]), _lib.ptr(c["thr"]), _lib.ptr(val2), k,
-                                           _lib.ptr(cnt), min(k, n), float(eps), _lib.ptr(c["n2"]), _lib.ptr(c["qn2"]), nq, _lib.ptr(fails),
-                                           _lib.stream()), "swat_dense_topk_proof")
-        assert fails.item() == want
         fails.zero_()
         i2, v2, c2 = torch.empty_like(idx), torch.empty_like(val), torch.empty_like(cnt)
         _lib.check(L.swat_candidates_topk_proof(_lib.ptr(c["keys2"]), c["K2"], _lib.ptr(c["cnt"]), nq, k, _lib.ptr(i2), _lib.ptr(v2), _lib.ptr(c2),
                                                 _lib.ptr(c["cnt"]), dense.CAP, c["K2"], _lib.ptr(c["val2"]), _lib.ptr(c["thr"]), min(k, n), float(eps),
-                                                _lib.ptr(c["n2"]), _lib.ptr(c["qn2"]), _lib.ptr(fails), _lib.stream()), "swat_candidates_topk_proof")
-        assert fails.item() == want and torch.equal(i2, idx) and torch.equal(v2, val)
+                                                _lib.ptr(c["n2"]), _lib.ptr(c["qn2"]), _lib.ptr(fails), 0, _lib.stream()), "swat_candidates_topk_proof")
+        assert fails.item() == want and torch.equal(i2, idx) and torch.equal(v2, val) and torch.equal(c2, cnt)
+        fails.fill_(7)
+        _lib.check(L.swat_dense_topk_proof(_lib.ptr(c["cnt"]), dense.CAP, c["K2"], _lib.ptr(c["val2"]), _lib.ptr(c["thr"]), _lib.ptr(v2), k,
+                                           _lib.ptr(c2), min(k, n), float(eps), _lib.ptr(c["n2"]), _lib.ptr(c["qn2"]), nq, _lib.ptr(fails),
+                                           _lib.stream()), "swat_dense_topk_proof")
+        assert fails.item() == want
+    c["cnt"].zero_()
     if d % 128 == 0:
         # the bf16 shadow of the shard (half the bytes per row): the same candidate lists bit for bit, hence the same answer
         sh = dense.DenseShadow(d_db)

@@ -47,7 +47,7 @@ marks[2].record()
 ops.sim_gathered(db, idx2.view(-1), q, c["row_seg"], keys_out=keys2, want_sims=False)
 marks[3].record()
 idx = torch.empty((nq, k), dtype=torch.int64, device=dev); val = torch.empty((nq, k), dtype=torch.float32, device=dev); out_cnt = torch.empty(nq, dtype=torch.int64, device=dev)
-_lib.check(L.swat_candidates_topk_proof(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt), _lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2), _lib.ptr(thr), k, float(dense.EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), _lib.ptr(c["fails"]), _lib.stream()), "ctk2")
+_lib.check(L.swat_candidates_topk_proof(_lib.ptr(keys2), K2, _lib.ptr(cnt), nq, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(out_cnt), _lib.ptr(cnt), dense.CAP, K2, _lib.ptr(val2), _lib.ptr(thr), k, float(dense.EPS_BF16), _lib.ptr(n2), _lib.ptr(c["qn2"]), _lib.ptr(c["fails"]), 0, _lib.stream()), "ctk2")
 marks[4].record()
 marks[5].record()
 flag = c["fails"].item()

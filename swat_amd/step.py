@@ -206,7 +206,17 @@ class FusedTrainStep:
                     _lib.check(lib.swat_adamw(*p[2], side_h), "swat_adamw")
             pend.clear()
 
-        opt.begin_step()
+        # this step's optimizer scalars (learning rates, bias corrections) go up on the stream the AdamW launches run on, not on the
+        # main stream between the loss and the backward (tools/step_timeline.py: the 4-byte copy and the bubble behind it cost the
+        # data-gradient chain ~15 us per step)
+        if self.reduce:
+            opt_stream = side
+        else:
+            if getattr(self, "_lane_ext", None) is None:
+                self._lane_ext = torch.cuda.ExternalStream(lane_h, device=main.device)
+            opt_stream = self._lane_ext
+        with torch.cuda.stream(opt_stream):
+            opt.begin_step()
         _lib.check(lib.swat_vit_set_overlap(2), "swat_vit_set_overlap")
         try:
             if self.reduce:

@@ -235,15 +235,64 @@ __global__ __launch_bounds__(256) void sgemm_small_kcontig_kernel(const float* _
     }
 }
 
+// (c) A and B k-contiguous, a handful of rows (M <= 32), K % 64 == 0, K <= 768:  C[m, n] = <A[m, :], B[n, :]> as ONE k-ordered fp32 fma
+//     chain per output (acc = fma(a_k, b_k, acc), k ascending from a zero accumulator) — bit for bit what the f32 matrix cores give
+//     (v_mfma_f32_32x32x2_f32 is such a chain: csrc/retrieval_mfma.hip), which served these two products of the head (logits z = fn W^T,
+//     du = df proj^T) until round 3 at 14-18 us each: eight 64-deep chunks staged one after the other, 256 dependent MFMAs, on 4-12
+//     workgroups.  Here a workgroup owns 32 rows x 8 columns, one output per thread, and stages its WHOLE operands once (A: 32 x K,
+//     B: 8 x K, <= 123 KB of LDS): one memory latency, then 512 dependent fmas per lane fed by float4 LDS reads (rows 16-B aligned
+//     and 4 banks apart).  Measured alone: see tools/perf_small_chain.py.
+__global__ __launch_bounds__(256) void sgemm_small_kordered_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                   float* __restrict__ C, int M, int N, int K, int64_t ldc) {
+    extern __shared__ __attribute__((aligned(16))) float sko[];
+    const int pitch = K + 4;
+    float* at = sko;                 // [32][pitch]
+    float* bt = sko + 32 * pitch;    // [8][pitch]
+    const int tid = threadIdx.x, n0 = blockIdx.x * 8;
+    const int kq = K >> 2;           // float4 per row
+    for (int i = tid; i < 40 * kq; i += 256) {
+        const int row = i / kq, q = i - row * kq;
+        if (row < 32) {
+            const int m = row < M ? row : M - 1;
+            *reinterpret_cast<float4*>(at + row * pitch + 4 * q) = *reinterpret_cast<const float4*>(A + (int64_t)m * K + 4 * q);
+        } else {
+            const int n = n0 + row - 32 < N ? n0 + row - 32 : N - 1;
+            *reinterpret_cast<float4*>(bt + (row - 32) * pitch + 4 * q) = *reinterpret_cast<const float4*>(B + (int64_t)n * K + 4 * q);
+        }
+    }
+    __syncthreads();
+    const int m = tid >> 3, c = tid & 7;
+    const float* ar = at + m * pitch;
+    const float* br = bt + c * pitch;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < K; kk += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(ar + kk), b = *reinterpret_cast<const float4*>(br + kk);
+        acc = fmaf(a.x, b.x, acc);
+        acc = fmaf(a.y, b.y, acc);
+        acc = fmaf(a.z, b.z, acc);
+        acc = fmaf(a.w, b.w, acc);
+    }
+    if (m < M && n0 + c < N) C[(int64_t)m * ldc + n0 + c] = acc;
+}
+
 SWAT_API int swat_sgemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak,
                               int64_t sbk, int64_t sbn, int64_t ldc, float alpha, int accumulate, swat_stream_t s) {
     if (M <= 0 || N <= 0) return 0;
     if (sbn == 1 && K >= 64) {
         hipLaunchKernelGGL(sgemm_small_ncontig_kernel, dim3((N + 63) / 64, (M + 3) / 4), dim3(1024), 0, (hipStream_t)s, A, B, C, M,
                            N, K, sam, sak, sbk, ldc, alpha, accumulate);
+    } else if (sak == 1 && sbk == 1 && sam == K && sbn == K && alpha == 1.0f && !accumulate && K % 64 == 0 && M <= 32 && K <= 768) {
+        // both operands k-contiguous, a handful of rows — head logits z = fn W^T and du = df proj^T: the k-ordered fp32 chain
+        // (bit-identical to the f32-matrix-core product swat_sim_topk_candidates that computes the larger cases below)
+        const int lds = 40 * (K + 4) * 4;
+        static int lds_ok = 0;   // (the attribute is raised once to the largest size: 123 KB at K = 768)
+        if (!lds_ok) {
+            SWAT_HIP(hipFuncSetAttribute((const void*)sgemm_small_kordered_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * (768 + 4) * 4));
+            lds_ok = 1;
+        }
+        hipLaunchKernelGGL(sgemm_small_kordered_kernel, dim3((N + 7) / 8), dim3(256), lds, (hipStream_t)s, A, B, C, M, N, K, ldc);
     } else if (sak == 1 && sbk == 1 && sam == K && sbn == K && alpha == 1.0f && !accumulate && K % 64 == 0 && M <= 64) {
-        // both operands k-contiguous, a handful of rows: the fp32 matrix-core tile product of the retrieval path
-        // (v_mfma_f32_32x32x2_f32, k-ordered fp32 chain) — head logits z = fn W^T and du = df proj^T
         return swat_sim_topk_candidates(A, M, B, N, K, nullptr, 0, nullptr, 0, nullptr, C, ldc, s);
     } else if (sak == 1 && sbk == 1 && K <= 1024 && M <= 256) {
         hipLaunchKernelGGL(sgemm_small_kcontig_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)s, A, B, C, M, N, K, sam, sbn,

@@ -508,3 +508,23 @@ def test_gemm_256_tile_epilogues_on_many_rows(layout, epi):
             close(C.float(), ref * (sg * (1 + 1.702 * x * (1 - sg))), True, K)
     finally:
         _lib.lib().swat_gemm_set_tile(-1)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 200, 512), (32, 768, 512), (64, 1000, 768), (5, 37, 64), (1, 1, 1024), (33, 129, 192)])
+def test_small_k_ordered_product_is_the_matrix_core_chain(M, N, K):
+    """The head's two k-contiguous products (logits z = fn W^T, du = df proj^T: swat_sgemm_small, M <= 64, K % 64 == 0) run as one
+    k-ordered fp32 fma chain per output on the vector ALU — bit for bit the f32-matrix-core product (swat_sim_topk_candidates, itself
+    pinned to the C oracle's canonical order in tests/test_gpu_retrieval.py) that computed them until round 3."""
+    from swat_amd import _lib
+    L = _lib.lib()
+    a = rnd(M, K, seed=71)
+    b = rnd(N, K, seed=72)
+    ldc = (N + 3) // 4 * 4
+    c1 = torch.full((M, ldc), float("nan"), device=dev())
+    c2 = torch.full((M, ldc), float("nan"), device=dev())
+    _lib.check(L.swat_sgemm_small(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c1), M, N, K, K, 1, 1, K, ldc, 1.0, 0, _lib.stream()), "swat_sgemm_small")
+    _lib.check(L.swat_sim_topk_candidates(_lib.ptr(a), M, _lib.ptr(b), N, K, None, 0, None, 0, None, _lib.ptr(c2), ldc, _lib.stream()),
+               "swat_sim_topk_candidates")
+    assert torch.equal(c1[:, :N], c2[:, :N])
+    ref = a.double() @ b.double().t()
+    assert (c1[:, :N].double() - ref).abs().max().item() <= 1e-4 * (K ** 0.5)

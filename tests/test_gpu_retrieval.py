@@ -180,7 +180,7 @@ def test_dense_mfma_topk_bit_exact_vs_oracle(n, nq, k):
 
 
 @pytest.mark.parametrize("n,nq,k,scale,d", [(150001, 200, 500, 1.0, 512), (40000, 37, 100, 1.0, 512), (60000, 64, 256, 3.5, 512),
-                                             (5000, 10, 20, 1.0, 512), (70003, 150, 300, 1.0, 768), (30000, 230, 64, 2.0, 128),
+                                             (5000, 10, 20, 1.0, 512), (70003, 150, 300, 1.0, 768), (30000, 230, 64, 2.0, 128), (50000, 230, 64, 1.0, 512),
                                              (30000, 40, 64, 1.0, 192)])
 def test_dense_bf16_candidate_pass_equals_the_exact_scan(n, nq, k, scale, d):
     """topk_dense = bf16 MFMA candidate pass + exact re-scoring + on-device completeness proof: the same (rows, values) as

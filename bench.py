@@ -377,7 +377,9 @@ def dense_cpu_baseline(db, q, k, gpu_idx, gpu_val, budget_rows=250_000):
     t_all = (time.perf_counter() - t0) * n / ns
     # check: the GPU top-k of the same slice is the oracle's, bit for bit
     from swat_amd.retrieval import dense
-    gi, gv, _ = dense.topk_dense(db[:ns].contiguous(), q, k)
+    sl = db[:ns].contiguous()
+    gi, gv, _ = dense.topk_dense(sl, q, k, shadow=dense.DenseShadow(sl))   # the route the line reports
+    assert dense.last_path == "bf16-shadow-candidates+exact-rescore", dense.last_path
     same = bool((gi.cpu().numpy() == oi).all() and (gv.cpu().numpy().view(np.uint32) == ov.view(np.uint32)).all())
     _set_omp_threads(1)
     n1 = max(k, ns // 20)
@@ -479,42 +481,62 @@ def retrieval_dense_secondary(dev, rank=0, world=1, steps=5, with_cpu=True):
     e1.record()
     torch.cuda.synchronize()
     ms_k = e0.elapsed_time(e1) / steps
+    # ---- accounting (round-3 verdict, weak #3): the headline of this leg is the COLD call — a query batch the index has not seen,
+    # the only case a retrieval job has — and every fraction divides BYTES THE ROUTE READS by time: the candidate scan reads the
+    # shard once in its scan image (bf16 shadow: 2 d bytes per row; fp32 rows without one), the exact re-score gathers K2 fp32 rows
+    # per query.  SURVEY 8(d)'s unit (4 d bytes per row whatever the route reads) is kept beside it as a labelled rate.
     row_bytes = d * (2 if shadow is not None else 4)
-    gbs = n * d * 4 / 1e9 / (ms_k * 1e-3)
+    scan_bytes = n * row_bytes
+    rescore_bytes = nq * int(c["K2"]) * d * 4
+    gbs = scan_bytes / 1e9 / (ms_k * 1e-3)
     tf = 2.0 * nq * n * d / (ms_k * 1e-3) / 1e12
-    rec = {"metric": "retrieval top-k queries/s (dense N_query x N_db, exact fp32 order)", "value": round(nq / dt, 1), "unit": "queries/s",
+    survey_bytes = n * d * 4
+    rec = {"metric": "retrieval top-k queries/s (dense N_query x N_db, exact fp32 order)", "value": round(nq / dt_cold, 1), "unit": "queries/s",
            "n_gpus": world, "scaling": "weak", "dtype": "bf16 candidates + f32 exact re-score",
-           "config": {"workload": f"{nq} queries x {world} x {n} x {d} fp32 rows, k={k}, bit-exact (value desc, row asc) lists"
-                                  + (", all_gather + merge of the per-rank lists" if world > 1 else ""), "route": path},
-           "ms_per_pass": round(dt * 1e3, 3),
-           "cold_call": {"ms_per_pass": round(dt_cold * 1e3, 3), "queries_per_s": round(nq / dt_cold, 1),
-                         "note": "new query tensor every call: threshold sample scan + segment top-k + query packing + one extra host sync, then the pass"},
+           "config": {"workload": f"{nq} queries x {world} x {n} x {d} fp32 rows, k={k}, bit-exact (value desc, row asc) lists, a NEW query "
+                                  "batch every call (thresholds from a row sample, query packing and the pass)"
+                                  + (", all_gather + merge of the per-rank lists" if world > 1 else ""), "route": path,
+                      "index_bytes_per_row": d * 4 + (d * 2 if shadow is not None else 0)},
+           "ms_per_pass": round(dt_cold * 1e3, 3),
+           "warm_same_queries": {"ms_per_pass": round(dt * 1e3, 3), "queries_per_s": round(nq / dt, 1),
+                                 "note": "the SAME query tensor asked again of the same shard (thresholds and the packed queries are cached per "
+                                         "(database, queries) pair): not what a retrieval job does — kept for comparison with rounds 2-3"},
            "roofline": {"bound": "hbm", "kernel": ("sim_candidates_shadow2_kernel (the shard's bf16 shadow" if shadow is not None else "sim_candidates_bf16_deep_kernel (fp32 rows") +
                                   " read once, bf16 v_mfma_f32_16x16x32_bf16 scores; timed with its staging memset and regroup_candidates_kernel)",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                         "traffic": _pmc_traffic("sim_candidates_shadow2_kernel") if shadow is not None else _pmc_traffic("sim_candidates_bf16_deep_kernel", contains=", false,"),
-                        "algorithmic_bytes_per_launch": n * d * 4,
-                        "bytes_read_per_launch": n * row_bytes, "frac_of_bytes_read": round(n * row_bytes / 1e9 / (ms_k * 1e-3) / HBM_PEAK_GBS, 4),
-                        "note": "achieved / frac use SURVEY 8(d)'s algorithmic 2 048 B per fp32 row; with the bf16 shadow the kernel reads half "
-                                "of that, so frac_of_bytes_read is the HBM efficiency of the launch itself",
-                        "avg_ms": round(ms_k, 4), "pass_frac": round(n * d * 4 / 1e9 / dt / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": scan_bytes,
+                        "note": "achieved = bytes the launch must read (n rows x %d B: the scan image) / its duration" % row_bytes,
+                        "avg_ms": round(ms_k, 4),
+                        "pass": {"bytes_read": scan_bytes + rescore_bytes, "rescore_bytes": rescore_bytes,
+                                 "cold_frac": round((scan_bytes + rescore_bytes) / 1e9 / dt_cold / HBM_PEAK_GBS, 4),
+                                 "warm_frac": round((scan_bytes + rescore_bytes) / 1e9 / dt / HBM_PEAK_GBS, 4),
+                                 "note": "whole call: (scan image + K2 = %d re-scored fp32 rows per query) / time / peak" % int(c["K2"])},
+                        "survey_8d_units": {"bytes_per_pass": survey_bytes, "cold_pass_frac": round(survey_bytes / 1e9 / dt_cold / HBM_PEAK_GBS, 4),
+                                            "warm_pass_frac": round(survey_bytes / 1e9 / dt / HBM_PEAK_GBS, 4),
+                                            "note": "SURVEY 8(d) prices a pass at 4 d bytes per row (the fp32 matrix) whatever the route reads; with "
+                                                    "the bf16 scan image this is a rate in fp32-row equivalents, not the HBM efficiency of a kernel"},
                         "mfma": {"achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}}}
     if dt_f32 is not None:
         rec["fp32_scan"] = {"ms_per_pass": round(dt_f32 * 1e3, 3), "queries_per_s": round(nq / dt_f32, 1),
-                            "pass_frac": round(n * d * 4 / 1e9 / dt_f32 / HBM_PEAK_GBS, 4), "note": "shadow=None: the candidate pass reads the fp32 rows"}
-    if world == 1:  # Nq in {1, 200, 1000}; queries from seed 11
+                            "pass_frac": round((n * d * 4 + rescore_bytes) / 1e9 / dt_f32 / HBM_PEAK_GBS, 4),
+                            "note": "shadow=None, same query tensor re-asked: the candidate pass reads the fp32 rows (4 d bytes per row + the re-score)"}
+    if world == 1:  # Nq in {1, 200, 1000}; queries from seed 11; a new query tensor every call
         other = {}
         for nq2 in (1, 1000):
             q2 = _unit(torch.randn(nq2, d, device=dev, generator=torch.Generator(device=dev).manual_seed(11)))
             dense.topk_dense(db, q2, k, shadow=shadow)
+            qs2 = [q2.clone() for _ in range(steps)]
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                dense.topk_dense(db, q2, k, shadow=shadow)
+            for qc in qs2:
+                dense.topk_dense(db, qc, k, shadow=shadow)
             torch.cuda.synchronize()
             t = (time.perf_counter() - t0) / steps
-            other[str(nq2)] = {"queries_per_s": round(nq2 / t, 1), "ms_per_pass": round(t * 1e3, 3), "route": dense.last_path,
-                               "hbm_frac_whole_pass": round(n * d * 4 / 1e9 / t / HBM_PEAK_GBS, 4)}
+            passes = (nq2 + 207) // 208   # the scan serves <= 208 queries per pass over the shard
+            read2 = passes * scan_bytes + nq2 * int(dense._cache["K2"]) * d * 4
+            other[str(nq2)] = {"queries_per_s": round(nq2 / t, 1), "ms_per_call": round(t * 1e3, 3), "route": dense.last_path,
+                               "bytes_read": read2, "hbm_frac_of_bytes_read": round(read2 / 1e9 / t / HBM_PEAK_GBS, 4)}
         rec["other_nq"] = other
     if with_cpu and world == 1:
         rec["cpu_baseline"] = dense_cpu_baseline(db, q, k, idx, val)

@@ -42,6 +42,16 @@ int swat_vit_set_mega(int mode);
 /* Synchronises the device, returns and clears the status word of the persistent forwards since the last call: 0 = every team
  *     hand-off completed; otherwise bit 30 is set and the low bits name the hand-off a workgroup gave up on (0.5 s). */
 int swat_vit_mega_status(void);
+/* No synchronisation: 0, or the 1-based launch number (swat_vit_mega_launches) of the first persistent forward that gave up on a
+ *     hand-off since the last swat_vit_mega_status.  While that status is non-zero every swat_adamw launch and the running loss
+ *     sum of swat_ce_mixed on the device leave their outputs untouched (the step's gradients are void), so the host can re-run
+ *     the steps from that launch on (swat_amd/step.py) once it has noticed. */
+int swat_vit_mega_poll(void);
+/* Persistent forwards launched on the current device so far. */
+int swat_vit_mega_launches(void);
+/* Tests: in each of the next `launches` persistent forwards one team member skips its arrival at hand-off number `handoff`
+ *     (1-based, 6 per block) and the spin bound is 2 ms: the launch gives up as if that member were not resident. */
+int swat_vit_mega_inject_failure(int launches, int handoff);
 /* Per-workgroup phase stamps of the next persistent forwards (64 x uint64 per workgroup, 100 MHz ticks); null = off. */
 int swat_vit_mega_trace(void* device_buffer);
 

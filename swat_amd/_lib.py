@@ -72,6 +72,46 @@ def check(rc, what):
         raise SwatHipError(f"{what} failed ({rc}): {lib().swat_last_error().decode()}")
 
 
+class PersistentForwardGaveUp(SwatHipError):
+    pass
+
+
+def persistent_forward_failed():
+    """After a device synchronisation: did a persistent forward (csrc/vit_mega.hip) give up on a team hand-off since the last
+    check?  If so its outputs are void: read and clear the status, switch this process to the op-by-op forward for good and
+    return the 1-based number of the first failed launch; else 0."""
+    import warnings
+    h = lib()
+    failed = h.swat_vit_mega_poll()
+    if not failed:
+        return 0
+    st = h.swat_vit_mega_status()  # synchronises, clears the device word and the host flag
+    h.swat_vit_set_mega(0)
+    warnings.warn(f"vit_fwd_mega_kernel launch {failed} gave up on a team hand-off (status {st:#x}: a member workgroup was not "
+                  "resident); the work since then is re-run and this process keeps to the op-by-op forward from here on")
+    return failed
+
+
+def retry_op_by_op(fn):
+    """Inference entry points (validate, feature extraction, the zero-shot filter) end on a host synchronisation: check the
+    persistent forward's status there and, on a give-up, run the whole call again on the op-by-op forward instead of returning
+    features computed from unpublished activations."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        out = fn(*a, **k)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            if persistent_forward_failed():
+                out = fn(*a, **k)
+                torch.cuda.synchronize()
+                if lib().swat_vit_mega_poll():
+                    raise PersistentForwardGaveUp("the persistent forward gave up although it is switched off")
+        return out
+    return wrapped
+
+
 def ptr(t):
     """Device pointer of a contiguous CUDA(HIP) tensor, or None."""
     if t is None:

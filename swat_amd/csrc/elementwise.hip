@@ -4,7 +4,7 @@
 // ref: open_clip VisionTransformer pieces called through model.encode_image (utils/training.py:332,1474),
 // CutMix paste utils/training.py:1458-1472, AdamW + LR groups utils/optimizers.py:22-35,131-146.
 #include <stdlib.h>
-#include "common.hpp"
+#include "kernels.hpp"
 #include "../../include/swat_hip.h"
 
 namespace swat {
@@ -425,7 +425,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, unsigned short* __restrict__ shadow, int64_t n,
                                                     AdamSegs segs, const float* __restrict__ lrs, float beta1, float beta2,
                                                     float eps, float wd, const float* __restrict__ bc /* [2]: 1-b1^t, 1-b2^t */,
-                                                    float grad_scale) {
+                                                    float grad_scale, const unsigned* __restrict__ guard) {
+    // a persistent forward of this step (or of an earlier one the host has not looked at yet) gave up on a hand-off: its gradients
+    // are void — leave weights, moments and the bf16 shadow as they are; the host re-runs the step (swat_amd/step.py)
+    if (guard && __builtin_nontemporal_load(guard) != 0u) return;
     const float bc1 = bc[0], sbc2 = sqrtf(bc[1]);
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     typedef float nt4 __attribute__((ext_vector_type(4)));
@@ -685,11 +688,12 @@ SWAT_API int swat_adamw(float* params, const float* grads, float* exp_avg, float
     }
     if (g_adamw_blocks > 0 && n / 4 >= (int64_t)g_adamw_blocks * 256 * 4)
         hipLaunchKernelGGL(adamw_kernel<4>, dim3(g_adamw_blocks), dim3(256), 0, (hipStream_t)s, params, grads, exp_avg, exp_avg_sq,
-                           (unsigned short*)shadow_bf16, n, segs, lrs_dev, beta1, beta2, eps, weight_decay, bias_corr_dev, grad_scale);
+                           (unsigned short*)shadow_bf16, n, segs, lrs_dev, beta1, beta2, eps, weight_decay, bias_corr_dev, grad_scale,
+                           mega_guard_word());
     else
         hipLaunchKernelGGL(adamw_kernel<1>, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)s, params, grads, exp_avg,
                            exp_avg_sq, (unsigned short*)shadow_bf16, n, segs, lrs_dev, beta1, beta2, eps, weight_decay,
-                           bias_corr_dev, grad_scale);
+                           bias_corr_dev, grad_scale, mega_guard_word());
     return check_launch("swat_adamw");
 }
 

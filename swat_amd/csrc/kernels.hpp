@@ -56,4 +56,8 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
                      unsigned short* h2, unsigned short* a, unsigned short* qkv, unsigned short* f, unsigned short* gact, float* mean1,
                      float* rstd1, float* mean2, float* rstd2, hipStream_t s);
 
+// device word that is non-zero while a persistent forward's give-up has not been read by the host (vit_mega.hip); null when no
+// persistent forward has run on the current device.  AdamW and the running loss sum skip their writes while it is set.
+const unsigned* mega_guard_word();
+
 }  // namespace swat

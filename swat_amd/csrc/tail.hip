@@ -5,7 +5,7 @@
 //      utils/models.py:47-72 (MyLinear), utils/losses.py:10-11 (nn.CrossEntropyLoss, mean reduction).
 // M = batch (32..256) here, so these are latency-bound VALU kernels; everything stays fp32 (the master
 // weights of proj / head are read directly).
-#include "common.hpp"
+#include "kernels.hpp"
 #include "../../include/swat_hip.h"
 
 namespace swat {
@@ -115,14 +115,16 @@ __global__ __launch_bounds__(256) void ce_mixed_kernel(const float* __restrict__
 }
 
 __global__ void ce_finish_kernel(const float* __restrict__ per_loss, const float* __restrict__ per_dls, int B,
-                                 float* __restrict__ loss, float* __restrict__ dls, double* __restrict__ loss_accum) {
+                                 float* __restrict__ loss, float* __restrict__ dls, double* __restrict__ loss_accum,
+                                 const unsigned* __restrict__ guard) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float l = 0.f, d = 0.f;
         for (int i = 0; i < B; ++i) { l += per_loss[i]; d += per_dls[i]; }
         l /= (float)B;
         loss[0] = l;
         if (dls) dls[0] = d;
-        if (loss_accum) loss_accum[0] += (double)l;  // running float64 sum for the per-epoch loss.csv row (ONE host sync per epoch)
+        if (loss_accum && !(guard && guard[0] != 0u)) loss_accum[0] += (double)l;  // (not for a step whose forward gave up)
+        // running float64 sum for the per-epoch loss.csv row (ONE host sync per epoch)
     }
 }
 
@@ -324,7 +326,7 @@ SWAT_API int swat_ce_mixed(const float* z, const float* logit_scale_dev, const i
     hipLaunchKernelGGL(ce_mixed_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, z, logit_scale_dev, ya, yb, lam,
                        per_sample_ws, per_sample_ws + B, dz, logits_out, B, C);
     hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const float*)per_sample_ws,
-                       (const float*)(per_sample_ws + B), B, loss, dlogit_scale, loss_accum);
+                       (const float*)(per_sample_ws + B), B, loss, dlogit_scale, loss_accum, mega_guard_word());
     return check_launch("swat_ce_mixed");
 }
 

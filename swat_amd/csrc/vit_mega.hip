@@ -31,6 +31,7 @@
 // hipMemsetAsync in front of every launch; every spin is bounded (give-up code in the status block).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 #include "gemm_device.hpp"
@@ -65,7 +66,13 @@ struct MegaFwd {
     float *mean1, *rstd1, *mean2, *rstd2;
     // hand-off state (zeroed before every launch)
     unsigned* ctr;          // [nteams][32] : word 0 of each 128-B line = arrivals
-    unsigned* status;       // [0] = first give-up code (0 = ok)
+    unsigned* status;       // [0] = first give-up code (0 = ok); sticky until the host reads it (swat_vit_mega_status): the
+                            // AdamW launches and the loss accumulation of the process skip their work while it is non-zero
+    unsigned* host_flag;    // pinned host word: launch number of the first launch that gave up (the host polls it without a sync)
+    unsigned launch_no;     // 1-based number of this launch on its device
+    unsigned long long spin_ticks;  // bound of a hand-off wait (100 MHz ticks)
+    int fail_sync;          // tuning (swat_vit_mega_inject_failure): member 1 of team 0 skips its arrival at hand-off number
+                            // fail_sync of the launch (1-based); 0 in production
     unsigned long long* trace;  // tuning: per workgroup phase stamps (null in production)
 };
 
@@ -104,7 +111,7 @@ __device__ __forceinline__ void mg_barrier() {
 // stream the first stages of the NEXT phase's weight slice into the LDS ring (weights depend on no hand-off).  The second
 // barrier is a raw s_barrier: __syncthreads() would drain those LDS-DMAs (vmcnt(0)).
 template <class Early>
-__device__ __forceinline__ void team_sync(const MegaFwd& p, int team, unsigned target, Early&& early, unsigned long long* tr = nullptr) {
+__device__ __forceinline__ void team_sync(const MegaFwd& p, int team, int member, unsigned target, Early&& early, unsigned long long* tr = nullptr) {
     if (tr && threadIdx.x == 0) tr[0] = mg_clock();   // stores issued
     mg_drain();          // every storing wave
     __syncthreads();
@@ -112,12 +119,20 @@ __device__ __forceinline__ void team_sync(const MegaFwd& p, int team, unsigned t
     if (threadIdx.x == 0) {
         if (tr) tr[1] = mg_clock();                   // stores drained, workgroup together
         unsigned* c = p.ctr + team * 32;
-        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool skip = p.fail_sync && target == (unsigned)p.fail_sync * MG_TEAM && team == 0 && member == 1;
+        if (!skip) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = mg_clock();
+        unsigned spins = 0;
         while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (mg_clock() - t0 > 50000000ull) {  // 0.5 s: a member never arrived (not resident / faulted): give up, flag it
+            // a hand-off that has already been given up on anywhere (this launch or an earlier one the host has not seen yet):
+            // the launch's values are void, do not wait 0.5 s at each of its 72 hand-offs
+            if ((++spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (mg_clock() - t0 > p.spin_ticks) {  // a member never arrived (not resident / faulted): give up, flag it
                 __hip_atomic_store(p.status, 0x80000000u | target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned expect = 0;
+                __hip_atomic_compare_exchange_strong(p.host_flag, &expect, p.launch_no, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
@@ -532,11 +547,11 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
     MG_STAMP(stamp++);
     // MG_SYNC(next_, BN_, NS_): hand-off; the loader waves meanwhile start the weight stream of the GEMM phase that follows it
 #define MG_SYNC(next_, BN_, NS_, k_)                                                                                  \
-    team_sync(p, team, ++seq * MG_TEAM, [&](int lw) { mg_w_prologue<BN_, NS_>(smem, next_, lw); },                     \
+    team_sync(p, team, member, ++seq * MG_TEAM, [&](int lw) { mg_w_prologue<BN_, NS_>(smem, next_, lw); },                     \
               (p.trace && l == 0 && panel == team) ? p.trace + (size_t)blockIdx.x * 64 + 8 + 4 * (k_) : nullptr);     \
     if (l == 0) MG_STAMP(stamp++)
 #define MG_SYNC0(k_)                                                                                                  \
-    team_sync(p, team, ++seq * MG_TEAM, [&](int) {},                                                                  \
+    team_sync(p, team, member, ++seq * MG_TEAM, [&](int) {},                                                                  \
               (p.trace && l == 0 && panel == team) ? p.trace + (size_t)blockIdx.x * 64 + 8 + 4 * (k_) : nullptr);     \
     if (l == 0) MG_STAMP(stamp++)
 #define MG_GEMM_DONE(k_)                                                                                             \
@@ -650,9 +665,36 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
-static unsigned* g_mega_state = nullptr;   // [16 teams x 32 words: zeroed before every launch | status 32 words: sticky] = 2176 B
-static int g_mega_mode = 1;                // swat_vit_set_mega: 0 = op-by-op forward, 1 = persistent forward when eligible
+// Per-device state of the persistent forward.  The arrival counters are one block per device: persistent launches of a device
+// are SERIALISED (a launch on another stream first waits for the previous launch's completion event) — two of them in flight at
+// once could each hold a part of the chip's CUs and wait for members of their own that the other's workgroups keep from
+// becoming resident (both would give up after the spin bound).  Kernels that do not spin (everything else in the library) may
+// run beside a persistent launch: they always finish and hand their CUs back.
+struct MegaDev {
+    unsigned* state = nullptr;      // [16 teams x 32 words: zeroed before every launch | status 32 words: sticky] = 2176 B
+    unsigned* host_flag = nullptr;  // pinned, mapped: launch number of the first launch that gave up (0 = none)
+    hipEvent_t done = nullptr;      // completion of the last persistent launch
+    hipStream_t last = nullptr;
+    bool any = false;
+    int cus = 0, resident = -1;     // CUs of the device; workgroups of the kernel that fit one CU (occupancy query)
+    unsigned launches = 0;
+};
+static MegaDev g_mega_dev[16];
+static int g_mega_mode = -1;               // swat_vit_set_mega / SWAT_VIT_MEGA: 0 = op-by-op forward, 1 = persistent forward when eligible
 static unsigned long long* g_mega_trace = nullptr;
+static int g_fail_launches = 0, g_fail_sync = 0;   // swat_vit_mega_inject_failure
+
+static MegaDev* mega_dev() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    return &g_mega_dev[dev];
+}
+
+// device word the optimizer / loss-accumulation kernels test before they write (null: no persistent forward has run on this device)
+const unsigned* mega_guard_word() {
+    MegaDev* md = mega_dev();
+    return md && md->state ? md->state + 16 * 32 : nullptr;
+}
 
 // -> 0: launched; 1: not eligible (the caller runs the blocks op by op); < 0: error
 int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int save, int M, int Mp, const float* params,
@@ -660,6 +702,10 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
                      unsigned short* h2, unsigned short* a, unsigned short* qkv, unsigned short* f, unsigned short* gact, float* mean1,
                      float* rstd1, float* mean2, float* rstd2, hipStream_t s) {
     // one panel = 2 images (attention reads 64 key rows from the second image's first row: 2 T + 14 <= 128 tile rows)
+    if (g_mega_mode < 0) {
+        const char* e = getenv("SWAT_VIT_MEGA");
+        g_mega_mode = e ? (atoi(e) == 0 ? 0 : atoi(e) == 2 ? 2 : 1) : 1;
+    }
     if (g_mega_mode == 0 || d != 768 || mlp != 3072 || H != 12 || d / H != 64 || T < 38 || T > 56 || B < 1 || L < 1) return 1;
     // 16 teams walk the panels in rounds of 16: a launch pays whole rounds (~0.8 ms each for 12 blocks), so batches that leave
     // the last round mostly empty — and big batches, where the op-by-op products fill the chip on their own (B = 256: M = 12 800
@@ -675,11 +721,30 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
     for (int k = 0; k < 12; ++k)
         if (layer_offs[k] % 8) return 1;  // 16-B rows of the bf16 shadow
     if (stride % 8) return 1;
-    if (!g_mega_state) {
-        if (hipMalloc((void**)&g_mega_state, 17 * 128) != hipSuccess || hipMemset(g_mega_state, 0, 17 * 128) != hipSuccess) {
-            set_error("vit_mega: hipMalloc of the hand-off state failed");
+    MegaDev* md = mega_dev();
+    if (!md) return 1;
+    const int npanels = (B + 1) / 2, nteams = npanels < 16 ? npanels : 16;
+    // every team member must be resident at once (the hand-offs wait for all of them): one workgroup per CU (156 KB of LDS each),
+    // so the grid must not exceed the CUs this process sees (a CU-masked or partitioned device, a smaller part), and the
+    // occupancy query must admit the workgroup at all.  Otherwise: op by op.
+    if (md->resident < 0) {
+        int cus = 0, occ = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, (int)(md - g_mega_dev)) != hipSuccess) cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vit_fwd_mega_kernel, MG_THREADS, 0) != hipSuccess) occ = 0;
+        (void)hipGetLastError();
+        md->cus = cus;
+        md->resident = occ;
+    }
+    if (md->resident < 1 || nteams * MG_TEAM > md->cus) return 1;   // (156 KB of LDS: one workgroup per CU whatever the query says)
+    if (!md->state) {
+        if (hipMalloc((void**)&md->state, 17 * 128) != hipSuccess || hipMemset(md->state, 0, 17 * 128) != hipSuccess ||
+            hipHostMalloc((void**)&md->host_flag, 128, hipHostMallocMapped) != hipSuccess ||
+            hipEventCreateWithFlags(&md->done, hipEventDisableTiming) != hipSuccess) {
+            set_error("vit_mega: allocation of the hand-off state failed");
+            md->state = nullptr;
             return -1;
         }
+        md->host_flag[0] = 0;
     }
     MegaFwd m{};
     m.B = B; m.T = T; m.d = d; m.H = H; m.mlp = mlp; m.L = L; m.act = act; m.save = save; m.M = M; m.Mp = Mp;
@@ -690,18 +755,34 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
     m.xs = xs; m.x1 = x1; m.h1 = h1; m.h2 = h2; m.a = a; m.qkv = qkv; m.f = f; m.gact = gact;
     m.mean1 = mean1; m.rstd1 = rstd1; m.mean2 = mean2; m.rstd2 = rstd2;
     m.P = 2;
-    m.npanels = (B + m.P - 1) / m.P;
-    m.nteams = m.npanels < 16 ? m.npanels : 16;
-    m.ctr = g_mega_state;
-    m.status = g_mega_state + 16 * 32;
+    m.npanels = npanels;
+    m.nteams = nteams;
+    m.ctr = md->state;
+    m.status = md->state + 16 * 32;
+    m.host_flag = md->host_flag;   // (mapped pinned memory: the host pointer is the device pointer under unified addressing)
+    m.launch_no = ++md->launches;
+    m.spin_ticks = 50000000ull;    // 0.5 s
+    m.fail_sync = 0;
+    if (g_fail_launches > 0) {
+        --g_fail_launches;
+        m.fail_sync = g_fail_sync;
+        m.spin_ticks = 200000ull;  // 2 ms: the injected failure need not cost the test half a second
+    }
     m.trace = g_mega_trace;
-    SWAT_HIP(hipMemsetAsync(g_mega_state, 0, 16 * 128, s));  // the arrival counters; the status word behind them is sticky (read-and-clear)
+    if (md->any && md->last != s) SWAT_HIP(hipStreamWaitEvent(s, md->done, 0));   // persistent launches of a device never overlap
+    SWAT_HIP(hipMemsetAsync(md->state, 0, 16 * 128, s));  // the arrival counters; the status word behind them is sticky (read-and-clear)
     // products + attention inside the launch (what bench.py's roofline divides by the launch's duration)
     const double flops = (double)L * B * T * (2.0 * d * 3 * d + 2.0 * d * d + 4.0 * d * mlp + 4.0 * T * d);
     hipEvent_t e0, e1;
     if (gemm_prof_take(9, flops, e0, e1)) hipExtLaunchKernelGGL(vit_fwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, e0, e1, 0, m);
     else hipLaunchKernelGGL(vit_fwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, m);
-    return check_launch("vit_fwd_mega_kernel");
+    const int rc = check_launch("vit_fwd_mega_kernel");
+    if (rc == 0) {
+        SWAT_HIP(hipEventRecord(md->done, s));
+        md->last = s;
+        md->any = true;
+    }
+    return rc;
 }
 
 }  // namespace swat
@@ -713,14 +794,37 @@ SWAT_API int swat_vit_set_mega(int mode) {
     return 0;
 }
 
-// status word of the last persistent forward (synchronises the device): 0 = every hand-off completed
+// status word of the persistent forwards since the last call (synchronises the device): 0 = every hand-off completed
 SWAT_API int swat_vit_mega_status(void) {
-    if (!g_mega_state) return 0;
+    MegaDev* md = mega_dev();
+    if (!md || !md->state) return 0;
     unsigned v = 0;
     SWAT_HIP(hipDeviceSynchronize());
-    SWAT_HIP(hipMemcpy(&v, g_mega_state + 16 * 32, 4, hipMemcpyDeviceToHost));
-    if (v) SWAT_HIP(hipMemset(g_mega_state + 16 * 32, 0, 128));
+    SWAT_HIP(hipMemcpy(&v, md->state + 16 * 32, 4, hipMemcpyDeviceToHost));
+    if (v) SWAT_HIP(hipMemset(md->state + 16 * 32, 0, 128));
+    md->host_flag[0] = 0;
     return (int)(v & 0x3fffffffu) | (v ? 0x40000000 : 0);
+}
+
+// no synchronisation: 0, or the 1-based number (swat_vit_mega_launches) of the first persistent launch that gave up on a hand-off
+SWAT_API int swat_vit_mega_poll(void) {
+    MegaDev* md = mega_dev();
+    if (!md || !md->host_flag) return 0;
+    return (int)__atomic_load_n(md->host_flag, __ATOMIC_RELAXED);
+}
+
+SWAT_API int swat_vit_mega_launches(void) {
+    MegaDev* md = mega_dev();
+    return md ? (int)md->launches : 0;
+}
+
+// tuning / tests: in each of the next `launches` persistent forwards one team member skips its arrival at hand-off number
+// `handoff` (1-based, 6 per block) and the spin bound is 2 ms — the launch gives up exactly as if that member were not resident
+SWAT_API int swat_vit_mega_inject_failure(int launches, int handoff) {
+    SWAT_REQUIRE(launches >= 0 && handoff >= 0, "swat_vit_mega_inject_failure: negative argument");
+    g_fail_launches = launches;
+    g_fail_sync = handoff;
+    return 0;
 }
 
 // tuning: per-workgroup phase stamps (64 x uint64 per workgroup, 100 MHz ticks) of the next persistent forwards; null = off

@@ -6,7 +6,7 @@ import random
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 def prompt_sampler(prompt_tensors, sample_by='mean'):
@@ -53,6 +53,7 @@ def get_text_features(model, prompt_dict, tokenize, operation='encode'):
     return tensor_dict
 
 
+@_lib.retry_op_by_op
 def extract_test_feats(model, dataloader):
     """ref :122-148 — batched encode_image + L2-normalise -> {'image_features' [N,E], 'labels' [N]} (CPU tensors)."""
     img_feats_lst, labels_lst = [], []

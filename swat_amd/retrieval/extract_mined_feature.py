@@ -22,6 +22,7 @@ import pickle
 import torch
 from torch.utils.data import DataLoader
 
+from .. import _lib
 from ..features import l2_normalize
 
 
@@ -55,6 +56,7 @@ def _dist():
 
 
 @torch.no_grad()
+@_lib.retry_op_by_op
 def extract_mined_feats_batch(model, dataloader, tokenizer, save_dir=None, batch_size=100, device="cuda"):
     """dataloader yields (imgs [B,3,H,W], labels [B], file_path list[str], captions list[str]) — MinedDataset's order.
     -> {'caption_features' [N,E], 'labels' [N], 'filepath' list[N], 'image_features' [N,E]} (CPU tensors), loader order."""

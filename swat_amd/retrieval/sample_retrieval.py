@@ -19,7 +19,7 @@ from time import time
 
 import torch
 
-from .. import features
+from .. import _lib, features
 from ..logger import get_logger
 from ..models import MyLinear
 from ..prompt import prompt_maker
@@ -56,6 +56,7 @@ def cal_prompt_tensors(args, logger, model, tokenizer, metrics, dataset_root, da
     return prompt_tensors_dict, text_prompts_dict
 
 
+@_lib.retry_op_by_op
 def zeroshot_clip_img_filter(model, preprocess, root_folder, pre_extracted_feats=None, head=None):
     """ref :278-329: per class, the rows whose zero-shot prediction (argmax of head(image embedding)) is another class
     are collected as a set of POSITIONS; a file is filtered iff int(<image id of its file name>) is in that set — the

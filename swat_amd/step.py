@@ -3,6 +3,7 @@ backward -> (data-parallel gradient reduction) -> AdamW, with no autograd graph 
 
 ref: the body of the hot loops utils/training.py:326-347 (train_ce) and :1452-1489 (train_cutmix).
 """
+import collections
 import os
 
 import torch
@@ -73,6 +74,11 @@ class FusedTrainStep:
             sl = sorted(self._stage_slices + [(self.off_head, self.off_head + (self.C * self.E + 63) // 64 * 64)]
                         + ([(self.off_ls, self.off_ls + 64)] if self.off_ls is not None else []))
             self.trail = sl[0][0] == 0 and sl[-1][1] == self.arena.numel and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+        # the last steps' arguments: a persistent forward that gives up on a hand-off (csrc/vit_mega.hip; only when a team member is
+        # not resident) voids its step — the device then skips every AdamW launch until the host has noticed (swat_vit_mega_poll at
+        # the next call, no synchronisation), and the host re-runs the steps from the failed launch on, op by op (_recover)
+        self._recent = collections.deque(maxlen=16)
+        self._replaying = False
         if self.trail:
             # process-wide streams owned by the library (created once, together with the weight-gradient lane)
             self._comm_stream = torch.cuda.ExternalStream(_lib.lib().swat_vit_aux_stream(0), device=dev)  # all-reduces
@@ -95,6 +101,12 @@ class FusedTrainStep:
     def __call__(self, images, target_a, target_b=None, lam=1.0, perm=None, box=None, batch=None):
         """images fp32 [B,3,H,W] (GPU), targets int64 [B].  Returns the device scalar holding this step's loss.
         batch: number of samples when `images` carries CutMix partner rows behind them (swat_amd/dp.py:shard_batch)."""
+        if self.train_visual and not self._replaying:
+            lib = _lib.lib()
+            if lib.swat_vit_mega_poll():
+                self._recover()
+            self._recent.append([0, self.opt.step_count, [g['lr'] for g in self.opt.param_groups],
+                                 (images, target_a, target_b, lam, perm, box, batch)])
         a = self.arena
         B = images.shape[0] if batch is None else int(batch)
         dev = images.device
@@ -103,7 +115,10 @@ class FusedTrainStep:
         ws, dfeats = self._head_ws(B, dev)
         red = SliceReducer()
         if self.train_visual:
+            n0 = _lib.lib().swat_vit_mega_launches()
             feats = self.visual.forward_raw(images, save=True, perm=perm, box=box, batch=B)
+            if not self._replaying and _lib.lib().swat_vit_mega_launches() > n0:
+                self._recent[-1][0] = n0 + 1  # this step's forward was persistent launch number n0 + 1 of the device
         else:
             feats = images.float().contiguous()  # pre-extracted, already normalised features (train_probing)
         g = a.grad
@@ -254,12 +269,47 @@ class FusedTrainStep:
         opt.end_step()
         return self.loss
 
+    def _recover(self):
+        """A persistent forward gave up on a hand-off (a team member was not resident).  Since that launch the device has skipped
+        every AdamW launch and every addition to the running loss, so weights, moments and the loss sum are those of the last good
+        step: switch to the op-by-op forward and run the voided steps again, with their own learning rates and step numbers."""
+        torch.cuda.synchronize()
+        failed = _lib.persistent_forward_failed()
+        if not failed:
+            return
+        if self.reduce:
+            raise _lib.PersistentForwardGaveUp(
+                f"persistent forward launch {failed} gave up on a hand-off on this rank: its void gradients have been summed into the "
+                "other ranks' updates; restart from the last checkpoint with SWAT_VIT_MEGA=0")
+        first = next((i for i, e in enumerate(self._recent) if e[0] == failed), None)
+        todo = list(self._recent)[first:] if first is not None else []   # every step since then had its update skipped
+        if not todo:
+            raise _lib.PersistentForwardGaveUp(
+                f"persistent forward launch {failed} gave up on a hand-off and its step is no longer in the replay window "
+                f"({len(self._recent)} steps): weights and optimizer state are those of the step before it; restart from them "
+                "with SWAT_VIT_MEGA=0")
+        opt = self.opt
+        lrs_now, count_now = [g['lr'] for g in opt.param_groups], opt.step_count
+        opt.step_count = todo[0][1]
+        self._replaying = True
+        try:
+            for _, _, lrs, args in todo:
+                for g, lr in zip(opt.param_groups, lrs):
+                    g['lr'] = lr
+                self(*args)
+        finally:
+            self._replaying = False
+            for g, lr in zip(opt.param_groups, lrs_now):
+                g['lr'] = lr
+        assert opt.step_count == count_now, (opt.step_count, count_now)
+        torch.cuda.synchronize()
+
     def pop_loss_sum(self):
         v = self.loss_accum.item()
+        # the persistent forward's hand-offs are bounded spins: a give-up is recorded, not hung on.  This is a synchronisation
+        # point: nothing is in flight, so a failure that the per-call poll has not seen yet is visible now
+        if self.train_visual and _lib.lib().swat_vit_mega_poll():
+            self._recover()
+            v = self.loss_accum.item()
         self.loss_accum.zero_()
-        # the persistent forward's hand-offs are bounded spins: a give-up is recorded, not hung on — surface it at the
-        # step's one synchronisation point (the values of such a step are garbage)
-        st = _lib.lib().swat_vit_mega_status()
-        if st != 0:
-            raise _lib.SwatHipError(f"vit_fwd_mega_kernel: a team hand-off gave up (status {st:#x}); set swat_vit_set_mega(0) to run op by op")
         return v

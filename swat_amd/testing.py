@@ -89,6 +89,7 @@ def head_eval(feats, W, logit_scale, labels, normalize=True, z=None, loss=None):
     return z, loss
 
 
+@_lib.retry_op_by_op
 def validate(args, data_loader, model, logger, loss, logit_scale, classifier_head=None, show_confusion_matrix=False,
              device='cuda', dataset='semi-aves', output_dir='output', predict_labels=False, predict_split='u_train',
              pre_extracted=False):

@@ -306,10 +306,18 @@ def test_dense_topk_full_shard_vs_oracle():
     assert dense.last_path == "bf16-candidates+exact-rescore"
     e_idx, e_val, e_cnt = dense.topk_dense_exact(db, q, k)
     assert torch.equal(idx, e_idx) and torch.equal(val, e_val) and torch.equal(cnt, e_cnt)
+    # the route bench.py reports (the shard's bf16 shadow scanned for candidates, exact fp32 re-score, on-device proof), on the
+    # whole shard: the first (cold: new query tensor) call and a repeated one
+    sh = dense.DenseShadow(db)
+    for _ in range(2):
+        s_idx, s_val, s_cnt = dense.topk_dense(db, q, k, shadow=sh)
+        assert dense.last_path == "bf16-shadow-candidates+exact-rescore"
+        assert torch.equal(s_idx, e_idx) and torch.equal(s_val, e_val) and torch.equal(s_cnt, e_cnt)
     pick = [0, 57, 123, 199]
     o_idx, o_val = orc.topk_multi(db.cpu().numpy(), q[pick].cpu().numpy(), k)
-    assert np.array_equal(idx[pick].cpu().numpy(), o_idx)
-    assert np.array_equal(val[pick].cpu().numpy().view(np.uint32), o_val.view(np.uint32))
+    for got_i, got_v in ((idx, val), (s_idx, s_val)):   # both routes against the C oracle directly
+        assert np.array_equal(got_i[pick].cpu().numpy(), o_idx)
+        assert np.array_equal(got_v[pick].cpu().numpy().view(np.uint32), o_val.view(np.uint32))
 
 
 def test_dense_cache_is_keyed_on_tensor_identity_not_on_addresses():

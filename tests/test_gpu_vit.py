@@ -50,17 +50,26 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
 
 
-@pytest.mark.parametrize("cfg,B", [(TINY, 5), (TINY_GELU, 3), (B32, 4), (B16, 2), (L14, 2)])
+@pytest.mark.parametrize("cfg,B", [(TINY, 5), (TINY_GELU, 3), (B32, 4), (B32, 32), (B16, 2), (L14, 2)])
 def test_forward_backward_match_oracle(cfg, B):
+    """(B32, 32) is the benchmark's shape: the batch fills two rounds of 16 two-image panels, so the default mode runs all twelve
+    blocks of the forward as ONE persistent launch (csrc/vit_mega.hip) — held here to the same tolerances against the fp32 oracle
+    as the op-by-op path (ref call site utils/training.py:1474)."""
+    from swat_amd import _lib
     ref, mine = make_pair(cfg)
+    launches0 = _lib.lib().swat_vit_mega_launches()
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 3, cfg[0], cfg[0], generator=g)
     w = torch.randn(B, cfg[5], generator=g)
     f_ref = ref(x)
     (f_ref * w).sum().backward()
     f = mine.forward_raw(x.to(dev()), save=True)
+    persistent = _lib.lib().swat_vit_mega_launches() - launches0
+    assert persistent == (1 if (cfg, B) == (B32, 32) else 0), "which forward ran is part of what this case pins"
     assert (f.cpu() - f_ref.detach()).abs().max().item() <= EMB_TOL * f_ref.abs().max().item()
     mine.backward_raw(w.to(dev()).contiguous())
+    torch.cuda.synchronize()
+    assert _lib.lib().swat_vit_mega_poll() == 0
     arena = mine.arena()
     ref_params = dict(ref.named_parameters())
     worst = 0.0
@@ -122,11 +131,13 @@ class _Lg:
         pass
 
 
-@pytest.mark.parametrize("cfg,B,C", [(TINY, 8, 10), (B32, 8, 200)])
+@pytest.mark.parametrize("cfg,B,C", [(TINY, 8, 10), (B32, 8, 200), (B32, 32, 200)])
 def test_fused_steps_track_oracle_trajectory(cfg, B, C):
     """8 optimisation steps (CutMix on/off, 3 LR groups, warm-up schedule) vs the same steps on the fp32 oracle
-    with torch.optim.AdamW: per-step loss within 2e-2, final weights within 1e-3 relative."""
-    from swat_amd import optimizers
+    with torch.optim.AdamW: per-step loss within 2e-2, final weights within 1e-3 relative.  (B32, 32, 200) is bench.py's step:
+    every forward of it is the persistent launch (asserted)."""
+    from swat_amd import _lib, optimizers
+    launches0 = _lib.lib().swat_vit_mega_launches()
     from swat_amd.clip_model import CLIP
     from swat_amd.models import MyLinear
     from swat_amd.step import FusedTrainStep
@@ -180,6 +191,7 @@ def test_fused_steps_track_oracle_trajectory(cfg, B, C):
     assert rel(model.visual.proj, ref_clip.visual.proj) < 1e-3
     total_loss = step.pop_loss_sum()
     assert total_loss > 0
+    assert _lib.lib().swat_vit_mega_launches() - launches0 == (8 if (cfg, B) == (B32, 32) else 0)
 
 
 def test_validate_matches_oracle_eval():
@@ -438,4 +450,99 @@ def test_persistent_forward_equals_the_op_by_op_forward_and_ignores_history(B):
         assert torch.equal(vis._ws[(B, True)], w2) and torch.equal(f3, f2)
     finally:
         L.swat_vit_set_mega(1)
-    assert ((g1 - g0).norm() / g0.norm()).item() < 2e-2
+    # gradients behind the persistent forward vs behind the op-by-op forward: per tensor, within the oracle tolerance (the two
+    # forwards differ in the k order of a few products only; the oracle itself is compared at B = 32 in
+    # test_forward_backward_match_oracle[cfg3-32])
+    arena = vis.arena()
+    for n, p in vis.named_parameters():
+        o = arena.offset_of(p)
+        r = ((g1[o:o + p.numel()] - g0[o:o + p.numel()]).norm() / (g0[o:o + p.numel()].norm() + 1e-12)).item()
+        assert r < GRAD_TOL, f"{n}: {r}"
+
+
+def _b32_step(seed=0, C=200):
+    from swat_amd import optimizers
+    from swat_amd.clip_model import CLIP
+    from swat_amd.models import MyLinear
+    from swat_amd.step import FusedTrainStep
+    torch.manual_seed(seed)
+    model = CLIP("ViT-B-32-quickgelu").to(dev())
+    W = torch.randn(C, 512)
+    W /= W.norm(dim=-1, keepdim=True)
+    head = MyLinear(weights=W).to(dev())
+    args = _args()
+    params, ls = optimizers.set_params(args, model, head, _Lg())
+    opt, sched, _ = optimizers.set_optimizer(args, params, [None] * 100)
+    return model, head, opt, sched, FusedTrainStep(model, head, ls, opt, world_size=1)
+
+
+def test_persistent_forward_give_up_is_detected_and_the_step_is_re_run_op_by_op():
+    """Hardening of csrc/vit_mega.hip (round-3 advisor finding): a team member that never arrives (here injected: it skips one
+    arrival, spin bound 2 ms) must not cost the job its weights.  The launch flags the give-up on the device and in a pinned host
+    word; every AdamW launch and the running loss sum skip their writes while the flag stands; the next call of the step notices
+    (no synchronisation needed), switches the process to the op-by-op forward and runs the voided steps again.  The trajectory
+    must equal a run that never used the persistent forward."""
+    from swat_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    data = [(torch.randn(32, 3, 224, 224, generator=g).to(dev()), torch.randint(0, 200, (32,), generator=g).to(dev())) for _ in range(4)]
+
+    def run(inject):
+        model, head, opt, sched, step = _b32_step()
+        losses = []
+        for it, (x, y) in enumerate(data):
+            if inject and it == 1:
+                L.swat_vit_mega_inject_failure(1, 9)   # the 2nd step's forward: member 1 of team 0 misses hand-off 9 (block 2)
+            step(x, y, y.flip(0), 0.7, perm=torch.arange(31, -1, -1, device=dev()), box=(10, 20, 120, 200))
+            sched.step()
+            losses.append(step.loss.clone())
+        total = step.pop_loss_sum()
+        return torch.stack(losses).cpu(), total, opt.arena.flat.clone(), opt.arena.exp_avg_sq.clone(), opt.step_count
+
+    try:
+        L.swat_vit_set_mega(0)
+        want = run(False)
+        L.swat_vit_set_mega(1)
+        n0 = L.swat_vit_mega_launches()
+        with pytest.warns(UserWarning, match="gave up on a team hand-off"):
+            got = run(True)
+        assert L.swat_vit_mega_launches() - n0 >= 2, "the first two steps ran the persistent forward"
+        assert L.swat_vit_mega_poll() == 0 and L.swat_vit_mega_status() == 0
+    finally:
+        L.swat_vit_mega_inject_failure(0, 0)
+        L.swat_vit_set_mega(1)
+    assert got[4] == want[4] == 4
+    assert abs(got[1] - want[1]) < 1e-2 * abs(want[1])          # the loss sum holds each step once (no void step in it)
+    # step 1 ran the persistent forward, steps 2-4 op by op after the recovery: same weights as the all-op-by-op run up to
+    # the persistent forward's k order in step 1
+    # (the second moments tell a lost or doubled step apart from rounding: one step is >= 25 % of them after four steps)
+    assert rel(got[2], want[2]) < 1e-5 and rel(got[3], want[3]) < 5e-2
+    assert abs(got[0][0].item() - want[0][0].item()) < 2e-2
+
+
+def test_two_towers_on_two_streams_run_the_persistent_forward_without_sharing_hand_off_state():
+    """WiSE-FT / zero-shot + fine-tuned towers, or two host threads: persistent forwards issued on two streams at once.  The
+    library serialises persistent launches per device (two of them in flight could each hold part of the chip and wait for
+    members the other keeps from becoming resident) — results must equal the one-stream results and no hand-off may give up."""
+    from swat_amd import _lib
+    from swat_amd.clip_model import CLIP
+    L = _lib.lib()
+    torch.manual_seed(1)
+    va, vb = CLIP("ViT-B-32-quickgelu").to(dev()).visual, CLIP("ViT-B-32-quickgelu").to(dev()).visual
+    xa, xb = torch.randn(32, 3, 224, 224, device=dev()), torch.randn(32, 3, 224, 224, device=dev())
+    want_a, want_b = va.forward_raw(xa).clone(), vb.forward_raw(xb).clone()
+    torch.cuda.synchronize()
+    n0 = L.swat_vit_mega_launches()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for it in range(6):
+        with torch.cuda.stream(sa):
+            fa = va.forward_raw(xa)
+        with torch.cuda.stream(sb):
+            fb = vb.forward_raw(xb)
+        outs.append((fa, fb))
+    torch.cuda.synchronize()
+    assert L.swat_vit_mega_launches() - n0 == 12 and L.swat_vit_mega_poll() == 0
+    for fa, fb in outs:
+        assert torch.equal(fa, want_a) and torch.equal(fb, want_b)
+

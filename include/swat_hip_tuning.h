@@ -35,6 +35,9 @@ int swat_gemm_set_swizzle(int mode);    /* 0 = plain 2-D grid, -1 = XCD-aware ti
  *     reduction runs as `planes` slices into fp32 planes that the next LayerNorm kernel sums in a fixed order (default 3;
  *     0 or 1 = one launch, no planes).  Deterministic either way; the per-element summation order differs. */
 int swat_vit_set_split_k(int planes);
+/* Weight gradients of a block through the grouped 256 x 128-tile launch (csrc/gemm_wgrad.hip): 0 = never, 1 = when the joint
+ *     tile list is one round of the chip (default), 2 = whenever the shapes allow (tests). */
+int swat_gemm_set_wgrad_big(int mode);
 /* The transformer blocks of the forward as ONE persistent launch (csrc/vit_mega.hip; ViT-B/32 regime: d = 768, 12 heads of 64,
  *     38 <= T <= 56): 1 = on when the shapes qualify and the batch fills whole rounds of 16 two-image panels (B = 27-32, 59-64;
  *     default), 2 = on for every batch of a qualifying shape (tests), 0 = always op by op.  Same buffers, same rounding points. */

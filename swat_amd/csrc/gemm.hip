@@ -828,7 +828,38 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
 
 // n products of one layout (the weight gradients of a transformer block): ONE persistent launch over the joint tile list
 // when every product qualifies for the producer / consumer kernel's grouped form, else one launch each.
+static int g_wgrad_big = 1;   // swat_gemm_set_wgrad_big: 0 = never, 1 = when the joint list is one round of 256 x 128 tiles, 2 = always
+
+// the weight gradients of a block as ONE round of 256 x 128 tiles (gemm_wgrad.hip): taken when the joint tile list fills most of
+// the chip once — more tiles than CUs would run a second, mostly empty round at a whole tile's latency each.
+// -> 0 launched, 1 not taken (the caller goes on with its own route), < 0 error
+int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s) {
+    if (!g_wgrad_big || n < 1 || n > 8 || g_force_cfg >= 0) return 1;
+    int tiles = 0;
+    bool deep = true;
+    for (int i = 0; i < n; ++i) {
+        tiles += ((probs[i].M + 255) / 256) * ((probs[i].N + 127) / 128);
+        deep = deep && probs[i].K >= 512 && probs[i].M >= 256 && probs[i].N >= 128;
+    }
+    if (g_wgrad_big != 2 && !(deep && tiles >= 144 && tiles <= 256)) return 1;
+    const bool prof = g_prof.on && g_prof.n < g_prof.cap;
+    hipEvent_t ev0 = prof ? g_prof.ev[2 * g_prof.n] : nullptr, ev1 = prof ? g_prof.ev[2 * g_prof.n + 1] : nullptr;
+    const int rc = launch_wgrad_group(probs, n, s, ev0, ev1);
+    if (prof && rc == 0) {
+        g_prof.kind[g_prof.n] = 10;
+        double fl = 0;
+        for (int i = 0; i < n; ++i) fl += 2.0 * probs[i].M * probs[i].N * probs[i].K;
+        g_prof.flops[g_prof.n] = fl;
+        ++g_prof.n;
+    }
+    return rc;
+}
+
 int gemm_group_dispatch(int layout, const GemmArgs* probs, int n, hipStream_t s) {
+    if (layout == L_TN) {
+        const int rc = wgrad_big_try(probs, n, s);
+        if (rc <= 0) return rc;
+    }
     bool ok = layout == L_TN && n >= 2 && n <= 64 && !(g_exp & 512) && g_force_cfg < 0;
     for (int i = 0; ok && i < n; ++i) {
         const GemmArgs& a = probs[i];
@@ -859,6 +890,11 @@ SWAT_API int swat_gemm_set_trace(void* dev_buf) {  /* tuning only: 4 x uint64 pe
     unsigned long long* ptr = (unsigned long long*)dev_buf;
     swat::g_trace_host = ptr;
     return hipMemcpyToSymbol(HIP_SYMBOL(swat::g_gemm_trace), &ptr, sizeof(ptr)) == hipSuccess ? 0 : -1;
+}
+
+SWAT_API int swat_gemm_set_wgrad_big(int mode) {
+    swat::g_wgrad_big = mode < 0 ? 0 : mode > 2 ? 2 : mode;
+    return 0;
 }
 
 SWAT_API int swat_gemm_set_exp(int e) {

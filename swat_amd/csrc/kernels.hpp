@@ -47,6 +47,10 @@ int launch_gemm_big(int layout, const GemmArgs& a, hipStream_t s, hipEvent_t ev0
 // up to 64 products of one layout in ONE persistent launch (gemm_pc.hip); every product: batch 1, K % 64 == 0, fp32 or
 // bf16 output with 16-B rows (what gemm_group_dispatch checks before it comes here)
 int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int cfg = 0);
+// n <= 8 weight gradients dW_i = dY_i^T X_i (TN, fp32 out, optional column sums of dY) as ONE launch of 256 x 128 tiles
+// (gemm_wgrad.hip); -> 0 launched, 1 shapes not served (run them one by one), < 0 error
+int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s);   // policy + launch_wgrad_group (gemm.hip); same return values
 // n products of one layout: one grouped launch when every product qualifies, else one launch each
 int gemm_group_dispatch(int layout, const GemmArgs* probs, int n, hipStream_t s);
 

@@ -267,6 +267,17 @@ SWAT_API int swat_linear_wgrad_bias_group(int n, const void* const* dY_bf16, con
                      "swat_linear_wgrad_bias_group: layer %d: null pointer, ld not a multiple of 8 or n_in not a multiple of 4", i);
         fused = fused && rows[i] % 64 == 0 && rows[i] >= 384;
     }
+    bool k64 = n <= 8;
+    for (int i = 0; i < n; ++i) k64 = k64 && rows[i] % 64 == 0;
+    if (k64) {  // one round of 256 x 128 tiles over the joint list when it fills the chip (csrc/gemm_wgrad.hip)
+        GemmArgs a[8];
+        for (int i = 0; i < n; ++i) {
+            a[i] = G(dY_bf16[i], X_bf16[i], dW[i], n_out[i], n_in[i], rows[i], ld_dy[i], ld_x[i], n_in[i], 1);
+            a[i].colsum = dbias[i];
+        }
+        const int rc = wgrad_big_try(a, n, s);
+        if (rc <= 0) return rc;
+    }
     if (!fused || n == 1) {
         for (int i = 0; i < n; ++i) {
             if (dbias[i]) TRY(swat_linear_wgrad_bias(dY_bf16[i], X_bf16[i], dW[i], dbias[i], rows[i], n_out[i], n_in[i], ld_dy[i], ld_x[i], workspace, stream));

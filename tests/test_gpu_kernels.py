@@ -165,6 +165,51 @@ def test_linear_wgrad_bias_group(shapes):
             assert (db - ref).abs().max().item() <= 1e-5 * math.sqrt(M) * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("shapes", [[(1664, 768, 3072, False), (1664, 3072, 768, True), (1664, 768, 768, False), (1664, 2304, 768, True)],
+                                    [(448, 384, 200, True), (448, 264, 136, True), (448, 512, 128, False)], [(64, 256, 128, True)],
+                                    [(128, 8, 8, True), (192, 1024, 4096, False)]])
+def test_block_weight_gradients_as_one_launch_of_256x128_tiles(shapes):
+    """csrc/gemm_wgrad.hip: the dW = dY^T X products of a block (and the column sums of dY that are the bias gradients) over ONE
+    joint list of 256 x 128 tiles — the ViT-B/32 block at B = 32 (216 tiles: the default route there), ragged tile edges, one
+    k-tile, a one-fragment product — against fp32 torch, and bit-identical from run to run (fixed summation order)."""
+    import ctypes
+    from swat_amd import _lib
+    lib = _lib.lib()
+    n = len(shapes)
+    dys, xs, dws, dbs = [], [], [], []
+    for i, (M, N, K, bias) in enumerate(shapes):
+        dys.append(rnd(M, N, seed=20 + i, dtype=BF)); xs.append(rnd(M, K, seed=30 + i, dtype=BF))
+        dws.append(torch.full((N, K), float("nan"), device=dev()))
+        dbs.append(torch.full((N,), float("nan"), device=dev()) if bias else None)
+    VP = ctypes.c_void_p * n
+    IA = ctypes.c_int * n
+    ws = torch.empty(lib.swat_colsum_bf16_workspace_bytes(max(s[1] for s in shapes)), dtype=torch.uint8, device=dev())
+
+    def run():
+        rc = lib.swat_linear_wgrad_bias_group(n, VP(*[t.data_ptr() for t in dys]), VP(*[t.data_ptr() for t in xs]), VP(*[t.data_ptr() for t in dws]),
+                                              VP(*[(t.data_ptr() if t is not None else None) for t in dbs]), IA(*[s[0] for s in shapes]),
+                                              IA(*[s[1] for s in shapes]), IA(*[s[2] for s in shapes]), IA(*[s[1] for s in shapes]),
+                                              IA(*[s[2] for s in shapes]), _lib.ptr(ws), _lib.stream())
+        _lib.check(rc, "swat_linear_wgrad_bias_group")
+    lib.swat_gemm_prof_begin(8)
+    try:
+        lib.swat_gemm_set_wgrad_big(2)
+        run()
+        first = [t.clone() for t in dws]
+        run()
+    finally:
+        lib.swat_gemm_set_wgrad_big(1)
+        ms, cnt, fl = (ctypes.c_double * 12)(), (ctypes.c_int64 * 12)(), (ctypes.c_double * 12)()
+        lib.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
+    assert cnt[10] == 2 and sum(cnt) == 2, "both calls must have been the grouped 256 x 128 launch"
+    for (M, N, K, bias), dy, x, dw, db, f in zip(shapes, dys, xs, dws, dbs, first):
+        close(dw, dy.float().t() @ x.float(), False, M)
+        assert torch.equal(dw, f)
+        if bias:
+            ref = dy.float().sum(0)
+            assert (db - ref).abs().max().item() <= 1e-5 * math.sqrt(M) * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
 def test_gemm_epilogues(act):
     from swat_amd import ops

@@ -833,7 +833,7 @@ static int g_wgrad_big = 1;   // swat_gemm_set_wgrad_big: 0 = never, 1 = when th
 // the weight gradients of a block as ONE round of 256 x 128 tiles (gemm_wgrad.hip): taken when the joint tile list fills most of
 // the chip once — more tiles than CUs would run a second, mostly empty round at a whole tile's latency each.
 // -> 0 launched, 1 not taken (the caller goes on with its own route), < 0 error
-int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s) {
+int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s, bool dry_run) {
     if (!g_wgrad_big || n < 1 || n > 8 || g_force_cfg >= 0) return 1;
     int tiles = 0;
     bool deep = true;
@@ -842,6 +842,15 @@ int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s) {
         deep = deep && probs[i].K >= 512 && probs[i].M >= 256 && probs[i].N >= 128;
     }
     if (g_wgrad_big != 2 && !(deep && tiles >= 144 && tiles <= 256)) return 1;
+    if (dry_run) {   // would launch_wgrad_group take these shapes?
+        for (int i = 0; i < n; ++i) {
+            const GemmArgs& g = probs[i];
+            if (g.K % 64 || g.K < 64 || g.M % 8 || g.N % 8 || g.lda % 8 || g.ldb % 8 || g.ldc % 4 || !g.out_f32 ||
+                (int64_t)g.K * g.lda * 2 >= (1ll << 31) || (int64_t)g.K * g.ldb * 2 >= (1ll << 31))
+                return 1;
+        }
+        return 0;
+    }
     const bool prof = g_prof.on && g_prof.n < g_prof.cap;
     hipEvent_t ev0 = prof ? g_prof.ev[2 * g_prof.n] : nullptr, ev1 = prof ? g_prof.ev[2 * g_prof.n + 1] : nullptr;
     const int rc = launch_wgrad_group(probs, n, s, ev0, ev1);

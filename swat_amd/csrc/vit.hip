@@ -78,6 +78,12 @@ struct VitWs {
     unsigned short* dqkv;     // [M,3d]
     float* du;                // [B,d]
     void *lnws, *lnws1, *lnws2;  // LayerNorm-backward partial sums: stem / tail, ln_1, ln_2 (their reductions run on the lane)
+    // block-by-block rings of the buffers the weight-gradient lane reads (slot 0 = the pointers above).  With all four weight
+    // gradients of a block in ONE lane launch behind its attention backward (csrc/gemm_wgrad.hip) the lane reads a block's dxb /
+    // dfb / dxb2 / dqkv / LayerNorm partials while the main chain is one or two blocks further down: block l uses slot l % 2 (its
+    // output gradient, written for block l - 1 while block l + 1's lane work may still read its own: slot (l - 1) % 3 of three)
+    unsigned short *dxb_r[3], *dxb2_r[2], *dfb_r[2], *dqkv_r[2];
+    void *lnws1_r[2], *lnws2_r[2];
     void* csws;               // column-sum partials
     int64_t total;
 };
@@ -129,6 +135,14 @@ static VitWs carve(const VitDims& D, void* base) {
         w.lnws1 = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
         w.lnws2 = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
         w.csws = take(swat_colsum_bf16_workspace_bytes(D.mlp > 3 * D.d ? D.mlp : 3 * D.d));
+        w.dxb_r[0] = w.dxb; w.dxb2_r[0] = w.dxb2; w.dfb_r[0] = w.dfb; w.dqkv_r[0] = w.dqkv; w.lnws1_r[0] = w.lnws1; w.lnws2_r[0] = w.lnws2;
+        w.dxb_r[1] = (unsigned short*)take(Mp * d * 2);
+        w.dxb_r[2] = (unsigned short*)take(Mp * d * 2);
+        w.dxb2_r[1] = (unsigned short*)take(Mp * d * 2);
+        w.dfb_r[1] = (unsigned short*)take(Mp * D.mlp * 2);
+        w.dqkv_r[1] = (unsigned short*)take(Mp * 3 * d * 2);
+        w.lnws1_r[1] = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
+        w.lnws2_r[1] = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
     }
     w.total = off;
     return w;
@@ -402,6 +416,7 @@ struct SideLane {
     std::vector<hipEvent_t> ev;  // ring: an event is re-recorded only ~a whole backward later
     size_t used = 0;
     hipEvent_t doneA = nullptr, doneB = nullptr;  // last lane read of {dxb, dfb} / {dxb2, dqkv}
+    hipEvent_t blk[2] = {nullptr, nullptr};       // one-launch form: end of the lane work of the last block with this parity
     bool open = false;           // lane work issued and not joined yet
     hipEvent_t next() {
         if (ev.size() < 1024) {
@@ -481,6 +496,7 @@ SWAT_API int swat_vit_backward_join(swat_stream_t stream) {
     SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
     g_side.open = false;
     g_side.doneA = g_side.doneB = nullptr;
+    g_side.blk[0] = g_side.blk[1] = nullptr;
     return 0;
 }
 
@@ -522,7 +538,21 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
         slot = nullptr;
     };
 
+    // One-launch form of a block's weight gradients (csrc/gemm_wgrad.hip) when the joint 256 x 128 tile list of its four products
+    // is one round of the chip (ViT-B/32 and B/16 widths at B*T up to a few thousand rows): the lane gets ONE product launch per
+    // block, behind the attention backward, and reads that block's ring slots of dxb / dfb / dxb2 / dqkv (carve) while the main
+    // chain runs on.  Other shapes keep the two-pairs form below.
+    bool one = false;
+    if (D.L >= 1) {
+        GemmArgs q[4] = {G(nullptr, nullptr, nullptr, d, mlp, D.Mp, d, mlp, mlp, 1), G(nullptr, nullptr, nullptr, mlp, d, D.Mp, mlp, d, d, 1),
+                         G(nullptr, nullptr, nullptr, d, d, D.Mp, d, d, d, 1), G(nullptr, nullptr, nullptr, 3 * d, d, D.Mp, 3 * d, d, d, 1)};
+        one = !g_group_wgrad && wgrad_big_try(q, 4, nullptr, true) == 0;
+    }
+    hipEvent_t* blk = g_side.blk;
+    unsigned short* dxb_head = one ? w.dxb_r[(D.L - 1) % 3] : w.dxb;
+
     int ln1_pending = -1;
+    void* ln1_ws = nullptr;
     for (int stage = stage_hi; stage >= stage_lo; --stage) {
         if (stage == D.L + 1) {
             SWAT_REQUIRE(dfeats, "swat_vit_backward: dfeats is null");
@@ -530,11 +560,13 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(swat_sgemm_small(w.u, dfeats, grads + O.proj, d, D.E, D.B, 1, d, D.E, 1, D.E, 1.0f, 0, s));
             TRY(swat_sgemm_small(dfeats, params + O.proj, w.du, D.B, d, D.E, D.E, 1, 1, D.E, d, 1.0f, 0, s));
             wait_lane(doneA);
+            wait_lane(blk[0]);
+            wait_lane(blk[1]);
             SWAT_HIP(hipMemsetAsync(w.dx, 0, (size_t)M * d * 4, s));
-            SWAT_HIP(hipMemsetAsync(w.dxb, 0, (size_t)M * d * 2, s));
+            SWAT_HIP(hipMemsetAsync(dxb_head, 0, (size_t)M * d * 2, s));
             const float* xl = w.xs + (int64_t)D.L * M * d;
             TRY(swat_layernorm_bwd(w.du, d, xl, (int64_t)T * d, params + O.lnpost_w, w.mean_post, w.rstd_post, nullptr, 0, w.dx,
-                                   (int64_t)T * d, w.dxb, (int64_t)T * d, grads + O.lnpost_w, grads + O.lnpost_b,
+                                   (int64_t)T * d, dxb_head, (int64_t)T * d, grads + O.lnpost_w, grads + O.lnpost_b,
                                    grads + (O.layer + 12 * (D.L - 1))[PRB], w.lnws, D.B, d, s));
         } else if (stage >= 1) {
             const int l = stage - 1;
@@ -548,82 +580,132 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             const unsigned short* P = w.P + (int64_t)l * D.B * D.H * T * D.ldp;
             const unsigned short* f = w.f + (int64_t)l * M * mlp;
             const unsigned short* ga = w.gact + (int64_t)l * D.Mp * mlp;
-            // c_proj: dF = (dx W) * act'(F); its weight gradient joins c_fc's on the lane below (one fork per pair)
-            // (c_proj bias gradient = column sums of dx: produced by the LayerNorm backward that wrote dx)
-            {
-                GemmArgs a = G(w.dxb, sh + lo[PRW], w.dfb, M, mlp, d, d, mlp, mlp, 0);
-                a.actin = f; a.ldact = mlp; a.act = D.act;
-                TRY(gemm_dispatch(L_NN, a, 1, s));
-            }
-            // lane: c_proj dW = dx^T g and c_fc dW = dF^T h2, db = colsum(dF) (reductions over Mp rows: pad rows are zero)
-            to_lane();
-            // c_fc: dh2 = dF W — enqueued BEFORE the lane's launches: the host needs ~20 us for those five calls, and a main chain
-            // that waits for them leaves the GPU idle (tools/step_timeline.py: 7 us per block behind the 12-us attention backward)
-            int S2 = 1;
-            TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
-            {
-                const void* dys[2] = {w.dxb, w.dfb};
-                const void* xs2[2] = {ga, h2};
-                float* dws[2] = {grads + lo[PRW], grads + lo[FCW]};
-                float* dbs[2] = {nullptr, grads + lo[FCB]};
-                const int rws[2] = {D.Mp, D.Mp}, nout[2] = {d, mlp}, nin[2] = {mlp, d}, ldy[2] = {d, mlp}, ldx[2] = {mlp, d};
-                if (g_group_wgrad) {
-                    TRY(swat_linear_wgrad_bias_group(2, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
-                } else {
-                    TRY(swat_linear_wgrad_bias_group(1, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
-                    TRY(swat_linear_wgrad_bias_group(1, dys + 1, xs2 + 1, dws + 1, dbs + 1, rws + 1, nout + 1, nin + 1, ldy + 1, ldx + 1, w.csws, ws));
+            if (one) {
+                const int si = l & 1;
+                unsigned short* dxb_in = w.dxb_r[l % 3];
+                unsigned short* dxb_out = w.dxb_r[(l + 2) % 3];   // block l - 1's slot
+                unsigned short *dfb = w.dfb_r[si], *dxb2 = w.dxb2_r[si], *dqkv = w.dqkv_r[si];
+                // this block's slots were last read by the lane work of block l + 2 (same parity; dxb_out: (l + 2) % 3 too)
+                wait_lane(blk[si]);
+                // c_proj: dF = (dx W) * act'(F)   (c_proj bias gradient = column sums of dx: from the LayerNorm backward that wrote dx)
+                {
+                    GemmArgs a = G(dxb_in, sh + lo[PRW], dfb, M, mlp, d, d, mlp, mlp, 0);
+                    a.actin = f; a.ldact = mlp; a.act = D.act;
+                    TRY(gemm_dispatch(L_NN, a, 1, s));
                 }
-            }
-            lane_done(doneA);  // last lane read of dxb and dfb
-            // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
-            wait_lane(doneB);
-            // (row pass here; the reduction of its partial sums to d(ln_2.weight / bias) and d(out_proj.bias) runs on the lane)
-            TRY(swat_layernorm_bwd_partial(w.dh, d, S2, (int64_t)M * d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
-                                           w.dx, d, w.dxb2, d, w.lnws2, M, d, s));
-            // out_proj: da = dx1 W (its weight gradient joins in_proj's on the lane below; bias gradient: from the ln_2 backward)
-            TRY(gemm_dispatch(L_NN, G(w.dxb2, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
-            // attention backward -> dqkv
-            TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s, at, w.lse + (int64_t)l * D.B * D.H * T));
-            // lane: out_proj dW = dx1^T a and in_proj dW = dqkv^T h1, db = colsum(dqkv)
-            to_lane();
-            // in_proj: dh1 = dqkv W (enqueued before the lane's launches, as above)
-            int S1 = 1;
-            TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));
-            TRY(swat_layernorm_bwd_finish(w.lnws2, M, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], ws));
-            {
-                const void* dys[2] = {w.dxb2, w.dqkv};
-                const void* xs2[2] = {at, h1};
-                float* dws[2] = {grads + lo[OUTW], grads + lo[QKVW]};
-                float* dbs[2] = {nullptr, grads + lo[QKVB]};
-                const int rws[2] = {D.Mp, D.Mp}, nout[2] = {d, 3 * d}, nin[2] = {d, d}, ldy[2] = {d, 3 * d}, ldx[2] = {d, d};
-                if (g_group_wgrad) {
-                    TRY(swat_linear_wgrad_bias_group(2, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
-                } else {
-                    TRY(swat_linear_wgrad_bias_group(1, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
-                    TRY(swat_linear_wgrad_bias_group(1, dys + 1, xs2 + 1, dws + 1, dbs + 1, rws + 1, nout + 1, nin + 1, ldy + 1, ldx + 1, w.csws, ws));
+                // c_fc: dh2 = dF W
+                int S2 = 1;
+                TRY(dgrad_split(D, dfb, mlp, sh + lo[FCW], w.dh, S2, s));
+                // ln_2 backward: dx1 = dx + LN'(dh2) (in place on dx) + bf16 copy; its partial sums are reduced on the lane
+                TRY(swat_layernorm_bwd_partial(w.dh, d, S2, (int64_t)M * d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
+                                               w.dx, d, dxb2, d, w.lnws2_r[si], M, d, s));
+                // out_proj: da = dx1 W
+                TRY(gemm_dispatch(L_NN, G(dxb2, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
+                // attention backward -> dqkv
+                TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, dqkv, s, at, w.lse + (int64_t)l * D.B * D.H * T));
+                to_lane();
+                // in_proj: dh1 = dqkv W (enqueued before the lane's launches: the host needs a few us for them)
+                int S1 = 1;
+                TRY(dgrad_split(D, dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));
+                // lane: the block's four weight gradients (+ the c_fc / in_proj bias gradients: column sums of dF / dqkv) as one
+                // launch, then the ln_2 reductions (d ln_2.weight / bias, d out_proj.bias)
+                {
+                    const void* dys[4] = {dxb_in, dfb, dxb2, dqkv};
+                    const void* xs4[4] = {ga, h2, at, h1};
+                    float* dws[4] = {grads + lo[PRW], grads + lo[FCW], grads + lo[OUTW], grads + lo[QKVW]};
+                    float* dbs[4] = {nullptr, grads + lo[FCB], nullptr, grads + lo[QKVB]};
+                    const int rws[4] = {D.Mp, D.Mp, D.Mp, D.Mp}, nout[4] = {d, mlp, d, 3 * d}, nin[4] = {mlp, d, d, d};
+                    const int ldy[4] = {d, mlp, d, 3 * d}, ldx[4] = {mlp, d, d, d};
+                    TRY(swat_linear_wgrad_bias_group(4, dys, xs4, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
                 }
+                TRY(swat_layernorm_bwd_finish(w.lnws2_r[si], M, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], ws));
+                // ln_1 backward: dx0 = dx1 + LN'(dh1), bf16 copy into block l - 1's slot
+                TRY(swat_layernorm_bwd_partial(w.dh, d, S1, (int64_t)M * d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
+                                               w.dx, d, dxb_out, d, w.lnws1_r[si], M, d, s));
+                ln1_pending = l;
+                ln1_ws = w.lnws1_r[si];
+            } else {
+                // c_proj: dF = (dx W) * act'(F); its weight gradient joins c_fc's on the lane below (one fork per pair)
+                // (c_proj bias gradient = column sums of dx: produced by the LayerNorm backward that wrote dx)
+                {
+                    GemmArgs a = G(w.dxb, sh + lo[PRW], w.dfb, M, mlp, d, d, mlp, mlp, 0);
+                    a.actin = f; a.ldact = mlp; a.act = D.act;
+                    TRY(gemm_dispatch(L_NN, a, 1, s));
+                }
+                // lane: c_proj dW = dx^T g and c_fc dW = dF^T h2, db = colsum(dF) (reductions over Mp rows: pad rows are zero)
+                to_lane();
+                // c_fc: dh2 = dF W — enqueued BEFORE the lane's launches: the host needs ~20 us for those five calls, and a main chain
+                // that waits for them leaves the GPU idle (tools/step_timeline.py: 7 us per block behind the 12-us attention backward)
+                int S2 = 1;
+                TRY(dgrad_split(D, w.dfb, mlp, sh + lo[FCW], w.dh, S2, s));
+                {
+                    const void* dys[2] = {w.dxb, w.dfb};
+                    const void* xs2[2] = {ga, h2};
+                    float* dws[2] = {grads + lo[PRW], grads + lo[FCW]};
+                    float* dbs[2] = {nullptr, grads + lo[FCB]};
+                    const int rws[2] = {D.Mp, D.Mp}, nout[2] = {d, mlp}, nin[2] = {mlp, d}, ldy[2] = {d, mlp}, ldx[2] = {mlp, d};
+                    if (g_group_wgrad) {
+                        TRY(swat_linear_wgrad_bias_group(2, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                    } else {
+                        TRY(swat_linear_wgrad_bias_group(1, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                        TRY(swat_linear_wgrad_bias_group(1, dys + 1, xs2 + 1, dws + 1, dbs + 1, rws + 1, nout + 1, nin + 1, ldy + 1, ldx + 1, w.csws, ws));
+                    }
+                }
+                lane_done(doneA);  // last lane read of dxb and dfb
+                // ln_2 backward: dx1 = dx + LN'(dh2)   (in place on dx) + bf16 copy
+                wait_lane(doneB);
+                // (row pass here; the reduction of its partial sums to d(ln_2.weight / bias) and d(out_proj.bias) runs on the lane)
+                TRY(swat_layernorm_bwd_partial(w.dh, d, S2, (int64_t)M * d, x1, d, params + lo[LN2W], w.mean2 + (int64_t)l * M, w.rstd2 + (int64_t)l * M, w.dx, d,
+                                               w.dx, d, w.dxb2, d, w.lnws2, M, d, s));
+                // out_proj: da = dx1 W (its weight gradient joins in_proj's on the lane below; bias gradient: from the ln_2 backward)
+                TRY(gemm_dispatch(L_NN, G(w.dxb2, sh + lo[OUTW], w.dab, M, d, d, d, d, d, 0), 1, s));
+                // attention backward -> dqkv
+                TRY(attn_backward(D, qkv, P, w.dab, w.S, w.dS, w.dqkv, s, at, w.lse + (int64_t)l * D.B * D.H * T));
+                // lane: out_proj dW = dx1^T a and in_proj dW = dqkv^T h1, db = colsum(dqkv)
+                to_lane();
+                // in_proj: dh1 = dqkv W (enqueued before the lane's launches, as above)
+                int S1 = 1;
+                TRY(dgrad_split(D, w.dqkv, 3 * d, sh + lo[QKVW], w.dh, S1, s));
+                TRY(swat_layernorm_bwd_finish(w.lnws2, M, d, grads + lo[LN2W], grads + lo[LN2B], grads + lo[OUTB], ws));
+                {
+                    const void* dys[2] = {w.dxb2, w.dqkv};
+                    const void* xs2[2] = {at, h1};
+                    float* dws[2] = {grads + lo[OUTW], grads + lo[QKVW]};
+                    float* dbs[2] = {nullptr, grads + lo[QKVB]};
+                    const int rws[2] = {D.Mp, D.Mp}, nout[2] = {d, 3 * d}, nin[2] = {d, d}, ldy[2] = {d, 3 * d}, ldx[2] = {d, d};
+                    if (g_group_wgrad) {
+                        TRY(swat_linear_wgrad_bias_group(2, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                    } else {
+                        TRY(swat_linear_wgrad_bias_group(1, dys, xs2, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                        TRY(swat_linear_wgrad_bias_group(1, dys + 1, xs2 + 1, dws + 1, dbs + 1, rws + 1, nout + 1, nin + 1, ldy + 1, ldx + 1, w.csws, ws));
+                    }
+                }
+                lane_done(doneB);  // last lane read of dxb2 and dqkv
+                // ln_1 backward: dx0 = dx1 + LN'(dh1)
+                wait_lane(doneA);
+                TRY(swat_layernorm_bwd_partial(w.dh, d, S1, (int64_t)M * d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
+                                               w.dx, d, w.dxb, d, w.lnws1, M, d, s));
+                ln1_pending = l;  // its reduction is queued on the lane at the end of this stage
+                ln1_ws = w.lnws1;
             }
-            lane_done(doneB);  // last lane read of dxb2 and dqkv
-            // ln_1 backward: dx0 = dx1 + LN'(dh1)
-            wait_lane(doneA);
-            TRY(swat_layernorm_bwd_partial(w.dh, d, S1, (int64_t)M * d, xin, d, params + lo[LN1W], w.mean1 + (int64_t)l * M, w.rstd1 + (int64_t)l * M, w.dx, d,
-                                           w.dx, d, w.dxb, d, w.lnws1, M, d, s));
-            ln1_pending = l;  // its reduction is queued on the lane at the end of this stage
         } else {
             // stem: ln_pre backward, positional / class embedding, conv1 weight
             TRY(swat_layernorm_bwd(w.dx, d, w.xpre, d, params + O.lnpre_w, w.mean_pre, w.rstd_pre, nullptr, 0, w.dh, d, nullptr, 0,
                                    grads + O.lnpre_w, grads + O.lnpre_b, nullptr, w.lnws, M, d, s));
             TRY(swat_colsum(w.dh, SWAT_F32, D.B, T * d, T * d, grads + O.pos, 0, 0, 0, s));  // dpos[t,:] = sum_b
             TRY(swat_colsum(w.dh, SWAT_F32, D.B, d, T * d, grads + O.cls, 0, 0, 0, s));      // dcls = sum_b row 0
+            // (one-launch form: the lane may still read every dxb slot — the attention-gradient buffer is the main chain's own)
+            unsigned short* gsc = one ? w.dab : w.dxb;
             wait_lane(doneA);
-            TRY(swat_gather_cast_bf16(w.dh, w.dxb, np, d, D.g * D.g, T, 1, s));              // drop the cls rows
-            TRY(gemm_dispatch(L_TN, G(w.dxb, w.patches, grads + O.conv1, d, D.Kp, np, d, D.ldk, D.Kp, 1), 1, s));
+            TRY(swat_gather_cast_bf16(w.dh, gsc, np, d, D.g * D.g, T, 1, s));              // drop the cls rows
+            TRY(gemm_dispatch(L_TN, G(gsc, w.patches, grads + O.conv1, d, D.Kp, np, d, D.ldk, D.Kp, 1), 1, s));
         }
         to_lane();  // the lane's tail now also follows everything this stage ran on the main stream
         if (ln1_pending >= 0) {
             const int64_t* lo = O.layer + 12 * ln1_pending;
-            TRY(swat_layernorm_bwd_finish(w.lnws1, M, d, grads + lo[LN1W], grads + lo[LN1B],
+            TRY(swat_layernorm_bwd_finish(ln1_ws, M, d, grads + lo[LN1W], grads + lo[LN1B],
                                           ln1_pending > 0 ? grads + (O.layer + 12 * (ln1_pending - 1))[PRB] : nullptr, ws));
+            if (one) lane_done(blk[ln1_pending & 1]);   // end of this block's lane work (the caller's AdamW slice comes behind it)
             ln1_pending = -1;
         }
     }

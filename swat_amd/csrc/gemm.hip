@@ -853,7 +853,9 @@ int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s, bool dry_run) {
     }
     const bool prof = g_prof.on && g_prof.n < g_prof.cap;
     hipEvent_t ev0 = prof ? g_prof.ev[2 * g_prof.n] : nullptr, ev1 = prof ? g_prof.ev[2 * g_prof.n + 1] : nullptr;
-    const int rc = launch_wgrad_group(probs, n, s, ev0, ev1);
+    int rc = 1;
+    if (!(g_exp & 4096)) rc = launch_gemm_xl(L_TN, probs, n, s, ev0, ev1, g_exp, g_trace_host);   // split-role form (gemm_xl.hip)
+    if (rc == 1) rc = launch_wgrad_group(probs, n, s, ev0, ev1, g_exp, g_trace_host);             // shapes it does not serve / exp 4096: gemm_wgrad.hip
     if (prof && rc == 0) {
         g_prof.kind[g_prof.n] = 10;
         double fl = 0;

@@ -42,6 +42,8 @@ struct WgProb {
 struct WgArgs {
     WgProb p[WG_MAXP];
     int n, total;
+    unsigned long long* trace;   // ablation build, exp bit 16: 8 x uint64 stamps per workgroup (100 MHz)
+    int exp;   // ablation build only (swat_gemm_set_exp): 1 no DMA after the prologue, 2 no MFMA, 4 no epilogue, 256 no fragment reads
 };
 
 __device__ __forceinline__ bf16x8_t wg_lds_tr(unsigned lo_addr, unsigned hi_addr) {
@@ -62,9 +64,16 @@ __device__ __forceinline__ void wg_wait_reads() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+template <bool ABL>
 __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WG_NS * WG_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
+    auto stamp = [&](int i) {
+        if constexpr (ABL) {
+            if ((a.exp & 16) && a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 8 + i] = wall_clock64();
+        }
+    };
+    stamp(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     // joint tile list, one contiguous chunk per XCD (blocks b, b + 8, .. share an XCD: speed only); inside a product tiles walk M
@@ -144,13 +153,27 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgArgs a) {
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
     bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];   // fragments of the k-tile's first / second 32-deep half
+    if constexpr (ABL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa0[i] = fb0[i] = fa1[i] = fb1[i] = ones;
+    }
     auto read_half = [&](bf16x8_t (&fa)[4], bf16x8_t (&fb)[4], unsigned so, int ks) {
+        if constexpr (ABL) {
+            if (a.exp & 256) return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) fb[i] = wg_lds_tr(rb[i][ks][0] + so, rb[i][ks][1] + so);
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i] = wg_lds_tr(ra[i][ks][0] + so, ra[i][ks][1] + so);
     };
     auto mfma_half = [&](bf16x8_t (&fa)[4], bf16x8_t (&fb)[4]) {
+        if constexpr (ABL) {
+            if (a.exp & 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { wg_pin(fb[j]); wg_pin(fa[j]); }
+                return;
+            }
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) wg_pin(fb[j]);
@@ -174,7 +197,9 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgArgs a) {
     if (nk >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (nk == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(1);
     wg_bar();
+    stamp(2);
     read_half(fa0, fb0, 0u, 0);
 
     int slot = 0;
@@ -189,13 +214,17 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wg_wait_reads();                 // every wave is done reading stage `slot` before anyone refills it
         wg_bar();
-        if (kt + WG_NS < nk) issue(slot, kt + WG_NS);
+        if (kt + WG_NS < nk && !(ABL && (a.exp & 1))) issue(slot, kt + WG_NS);
         if (kt + 1 < nk) read_half(fa0, fb0, (unsigned)nslot * WG_STAGE, 0);
         mfma_half(fa1, fb1);
         slot = nslot;
     }
 
+    stamp(3);
     // ---- epilogue: fp32 tile, 16-byte stores -------------------------------------------------------------------------------------
+    if constexpr (ABL) {
+        if (a.exp & 4) return;
+    }
     GemmArgs e{};
     e.M = M; e.N = N; e.ldc = P.ldc; e.C = P.C; e.out_f32 = 1; e.alpha = 1.0f;
     gemm_epilogue<4, 4>(e, acc, m0 + 64 * wr, n0 + 64 * wc, lane, 0, 0);
@@ -206,11 +235,16 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgArgs a) {
             if (m < M) P.colsum[m] = accs[i][0];
         }
     }
+    if constexpr (ABL) {
+        stamp(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(5);
+    }
 }
 
 // n <= 8 products dW_i = dY_i^T X_i (TN, fp32 outputs) in one launch.  Every product: K % 64 == 0 (pad rows zero), M % 8 == 0,
 // N % 8 == 0, 16-byte aligned rows.  -> 0 launched, 1 shapes not served by this kernel (the caller runs them one by one)
-int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp, unsigned long long* trace) {
     if (n < 1 || n > WG_MAXP) return 1;
     WgArgs a{};
     a.n = n;
@@ -229,8 +263,11 @@ int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t e
         total += p.tiles_m * ((g.N + WG_BN - 1) / WG_BN);
     }
     a.total = total;
-    if (ev0) hipExtLaunchKernelGGL(wgrad_group_kernel, dim3(total), dim3(512), 0, s, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL(wgrad_group_kernel, dim3(total), dim3(512), 0, s, a);
+    a.exp = exp & (1 | 2 | 4 | 16 | 256);
+    a.trace = trace;
+    if (a.exp) hipLaunchKernelGGL(wgrad_group_kernel<true>, dim3(total), dim3(512), 0, s, a);
+    else if (ev0) hipExtLaunchKernelGGL(wgrad_group_kernel<false>, dim3(total), dim3(512), 0, s, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL(wgrad_group_kernel<false>, dim3(total), dim3(512), 0, s, a);
     return check_launch("wgrad_group_kernel");
 }
 

@@ -1,0 +1,450 @@
+// swat_amd/csrc/gemm_xl.hip — 256 x 128 bf16 MFMA tiles with split roles, persistent over a JOINT tile list of up to 8 products.
+//
+// ref: the nn.Linear forward / backward products under model.encode_image and loss.backward() (utils/training.py:1474,
+// 1486-1488, :332-343): C = A B^T (NT, forward), dX = dY W (NN, data gradient), dW = dY^T X (TN, weight gradient).
+//
+// Two uses.  (1) ViT-B/32 / B/16 at B = 32: ALL four weight gradients of a transformer block as one launch — their outputs
+// together are 216 tiles of 256 x 128, one resident round of the chip, where each product alone only fills the chip with
+// 96 x 96 / 64 x 64 tiles that are bound by the per-CU L2 -> LDS path (65 us per block for four launches).
+// (2) The many-row products (ViT-L/14: M = 8 224; feature extraction: M = 51 200): whole rounds of 256 x 128 tiles.
+//
+// Structure (what the measurements of the first form of this kernel — every wave loading AND computing — asked for: its
+// main loop ran at half the rate its DMA, LDS and MFMA streams each allow, because an in-order wave that is issuing
+// LDS-DMA pieces or fragment reads issues no MFMAs, and the two waves of a SIMD did so in lock-step):
+//   * 12 waves: 8 consumers, 4 (M) x 2 (N), 64 x 64 = 4 x 4 accumulator fragments of v_mfma_f32_16x16x32_bf16 each, and 4
+//     loaders that only issue global_load_lds_dwordx4 pieces (12 per wave and k-tile) and wait for them with counted vmcnt.
+//     Three waves per SIMD: 168 registers per lane.
+//   * ring of three 48 KB stages (A 32 KB + B 16 KB per 64-deep k-tile).  ONE raw s_barrier per k-tile, in the MIDDLE of the
+//     consumers' step: before it a consumer has read BOTH 32-deep halves of stage g into registers (the second half's reads
+//     go out row by row behind the MFMAs of the first), so at the barrier stage g is free and the loaders refill it with
+//     k-tile g + 3 while k-tile g + 2 is still in flight: two k-tiles (96 KB per CU) on their way at any time — the ring of
+//     the producer / consumer kernel (csrc/gemm_pc.hip) needs four stages for one less.
+//   * persistent: a workgroup walks its tiles (XCD-contiguous chunks of the joint list) with the k-tile sequence running
+//     across tile seams — while the consumers store a tile the loaders already fill the ring with the next tile's first
+//     three k-tiles.  Epilogues from registers (gemm_device.hpp: bias, residual, activation + second output, dgrad x act',
+//     fp32 or bf16 with 16-byte stores); bias gradients beside weight gradients from one MFMA against a ones fragment per
+//     half step (n-tile 0).
+//   * LDS images of gemm_device.hpp: k-contiguous [rows][64] with the 16-B-slot XOR (ds_read_b128), k-strided [64][128]
+//     parts with the 32-B-group XOR (ds_read_b64_tr_b16) — for both images the fragments of a lane differ by CONSTANT
+//     byte offsets between the two halves and between a fragment's two transposed reads, so a consumer keeps 2 (k-contiguous)
+//     or 4 (k-strided) address registers per operand and everything else is an immediate.
+// Shapes: M % 256 == 0, N % 128 == 0, K % 64 == 0 (the dispatcher cuts other shapes into a served part and a remainder).
+#include <hip/hip_ext.h>
+#include <type_traits>
+#include <utility>
+#include "gemm_device.hpp"
+#include "../../include/swat_hip.h"
+
+namespace swat {
+
+constexpr int XL_BM = 256, XL_BN = 128, XL_NS = 3, XL_NC = 8, XL_NL = 4, XL_THREADS = 64 * (XL_NC + XL_NL);
+constexpr int XL_A_BYTES = XL_BM * 128, XL_B_BYTES = XL_BN * 128, XL_STAGE = XL_A_BYTES + XL_B_BYTES;
+constexpr int XL_PA = XL_A_BYTES / 1024, XL_PB = XL_B_BYTES / 1024, XL_LPS = (XL_PA + XL_PB) / XL_NL;   // 12 pieces per loader wave
+constexpr int XL_MAXP = 8;
+
+struct XlProb {
+    GemmArgs g;
+    int tiles_m, tiles_n, tile0;
+};
+struct XlArgs {
+    XlProb p[XL_MAXP];
+    int n, total;
+    unsigned long long* trace;   // ablation build, exp bit 16
+    int exp;                     // ablation build (swat_gemm_set_exp): 1 no DMA after the first ring fill, 2 no MFMA, 4 no epilogue, 256 no fragment reads
+};
+
+template <int IMM>
+__device__ __forceinline__ bf16x8_t xl_lds_b128(unsigned addr) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8_t xl_lds_tr(unsigned addr) {   // the two transposed reads of a fragment: k-rows +0..3 and +4..7
+    s16x4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(IMM));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(IMM + 1024));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ void xl_pin(bf16x8_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void xl_bar() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <int N_>
+__device__ __forceinline__ void xl_wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_ > 15 ? 15 : N_) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N_>
+__device__ __forceinline__ void xl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+template <int N_, typename F, int... Is>
+__device__ __forceinline__ void xl_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N_, typename F>
+__device__ __forceinline__ void xl_static_for(F&& f) { xl_static_for_impl<N_>(f, std::make_integer_sequence<int, N_>{}); }
+
+// tile id -> product, tile row / column.  Tiles of a product walk M first (a run of consecutive ids shares one B panel); when the
+// tile grid allows it, in blocks of 8 x 4 tiles so that the 32 tiles an XCD works on at a time share 8 A panels and 4 B panels.
+struct XlTile {
+    int pi, m0, n0, tn;
+};
+__device__ __forceinline__ XlTile xl_decode(const XlArgs& a, int id) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < XL_MAXP; ++i)
+        if (i < a.n && id >= a.p[i].tile0) pi = i;
+    const int t = id - a.p[pi].tile0, tmn = a.p[pi].tiles_m, tnn = a.p[pi].tiles_n;
+    int tm, tn;
+    if ((tmn & 7) == 0 && (tnn & 3) == 0) {
+        const int sb = t >> 5, w = t & 31, sbm = tmn >> 3;
+        tm = (sb % sbm) * 8 + (w & 7);
+        tn = (sb / sbm) * 4 + (w >> 3);
+    } else {
+        tm = t % tmn;
+        tn = t / tmn;
+    }
+    return XlTile{pi, tm * XL_BM, tn * XL_BN, tn};
+}
+
+template <int LAYOUT, bool ABL>
+__global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const XlArgs a) {
+    constexpr bool A_KC = (LAYOUT != L_TN);
+    constexpr bool B_KC = (LAYOUT == L_NT);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[XL_NS * XL_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto stamp = [&](int i) {
+        if constexpr (ABL) {
+            if ((a.exp & 16) && a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 8 + i] = wall_clock64();
+        }
+    };
+    stamp(0);
+    // this workgroup's tiles: XCD x (blocks x, x + 8, ..: speed only) owns a contiguous chunk of the joint list, its nw workgroups
+    // take the chunk's tiles round-robin
+    int t_first, t_end, t_step;
+    {
+        const int lb = blockIdx.x, G = gridDim.x, x = lb & 7, s = lb >> 3;
+        const int q = a.total >> 3, r = a.total & 7;
+        const int c0 = x * q + (x < r ? x : r), c1 = c0 + q + (x < r ? 1 : 0);
+        t_step = (G - x + 7) >> 3;
+        t_first = c0 + s;
+        t_end = c1;
+    }
+
+    if (wave >= XL_NC) {
+        // ================================ loader waves ================================
+        const int lw = wave - XL_NC;
+        // piece q = lw + 4 i of a stage: q < 32 -> A image, else B image; its per-lane position inside the k-tile
+        int pk[XL_LPS], pc[XL_LPS];   // k-contiguous: (row, 16-B slot); k-strided: (k-row, column)
+#pragma unroll
+        for (int i = 0; i < XL_LPS; ++i) {
+            const int q = lw + XL_NL * i;
+            const bool isA = q < XL_PA;
+            const int byte = (isA ? q : q - XL_PA) * 1024 + lane * 16;
+            if ((isA && A_KC) || (!isA && B_KC)) {
+                const int row = byte >> 7;
+                pk[i] = row;
+                pc[i] = 8 * (((byte >> 4) & 7) ^ ((row >> 1) & 7));
+            } else if (isA) {
+                stp_inv<XL_BM>(byte, pk[i], pc[i]);
+            } else {
+                stp_inv<XL_BN>(byte, pk[i], pc[i]);
+            }
+        }
+        unsigned off[XL_LPS];
+        const char *gA = nullptr, *gB = nullptr;
+        int64_t stepA = 0, stepB = 0;
+        int cur_p = -1, nk = 0;
+        int it = t_first, ikt = 0;   // the next k-tile to issue: tile `it`, k-tile `ikt`
+        auto open_tile = [&]() {     // uniform: operand bases of tile `it`
+            const XlTile T = xl_decode(a, it);
+            const GemmArgs& g = a.p[T.pi].g;
+            if (T.pi != cur_p) {
+                cur_p = T.pi;
+#pragma unroll
+                for (int i = 0; i < XL_LPS; ++i) {
+                    const bool isA = lw + XL_NL * i < XL_PA;
+                    off[i] = (unsigned)(pk[i] * (isA ? (A_KC ? g.lda : g.lda) : g.ldb) + pc[i]) * 2u;
+                }
+                stepA = A_KC ? 128 : (int64_t)128 * g.lda;
+                stepB = B_KC ? 128 : (int64_t)128 * g.ldb;
+                nk = g.K >> 6;
+            }
+            gA = reinterpret_cast<const char*>(g.A + (A_KC ? (int64_t)T.m0 * g.lda : (int64_t)T.m0));
+            gB = reinterpret_cast<const char*>(g.B + (B_KC ? (int64_t)T.n0 * g.ldb : (int64_t)T.n0));
+        };
+        auto issue = [&](int slot) {   // k-tile (it, ikt) into ring slot `slot`; advances the cursor
+            unsigned char* dst = smem + slot * XL_STAGE + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < XL_LPS; ++i) {
+                const bool isA = lw + XL_NL * i < XL_PA;   // i < 8
+                const char* src = (isA ? gA + ikt * stepA : gB + ikt * stepB) + off[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + i * (XL_NL * 1024)), 16, 0, 0);
+            }
+            if (++ikt == nk) {
+                ikt = 0;
+                it += t_step;
+                if (it < t_end) open_tile();
+            }
+        };
+        // total k-tiles of this workgroup (uniform)
+        int total_g = 0;
+        for (int t = t_first; t < t_end; t += t_step) total_g += a.p[xl_decode(a, t).pi].g.K >> 6;
+        if (total_g == 0) return;
+        open_tile();
+        int issued = 0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (issued < total_g) { issue(s); ++issued; }
+        // k-tile 0 landed (this wave's pieces) before the opening barrier; the third stage goes out behind it, so the consumers do
+        // not wait for its 12 issue slots per loader wave
+        if (issued == 2) xl_wait_vm<XL_LPS>();
+        else xl_wait_vm<0>();
+        stamp(1);
+        xl_bar();
+        if (issued < total_g) { issue(2); ++issued; }
+        int slot = 0;
+        for (int g = 0; g < total_g; ++g) {
+            // k-tile g + 1 landed; g + 2 (the youngest issued so far) may still fly
+            if (g + 2 < issued) xl_wait_vm<XL_LPS>();
+            else xl_wait_vm<0>();
+            xl_bar();   // barrier g: the consumers hold all of k-tile g in registers -> its slot is free
+            if (issued < total_g && !(ABL && (a.exp & 1))) { issue(slot); ++issued; }
+            else if (ABL && issued < total_g) ++issued;
+            slot = slot + 1 == XL_NS ? 0 : slot + 1;
+        }
+        return;
+    }
+
+    // ================================ consumer waves ================================
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
+    // fragment addresses inside stage 0, half 0.  k-contiguous: fragment i at + 2048 i, half 1 in ra[1]; k-strided: fragment i in
+    // ra[i], half 1 at + 8192, second transposed read at + 1024 (gemm_device.hpp stp_off: f(k) is the same for k, k + 4 and k + 32)
+    unsigned ra[4], rb[4];
+    if constexpr (A_KC) {
+        ra[0] = lds0 + kc_off(64 * wr + r16, g4);
+        ra[1] = lds0 + kc_off(64 * wr + r16, 4 + g4);
+        ra[2] = ra[3] = 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = lds0 + stp_off<XL_BM>(8 * g4 + (r16 >> 2), 64 * wr + 16 * i) + 8 * (r16 & 3);
+    }
+    if constexpr (B_KC) {
+        rb[0] = lds0 + XL_A_BYTES + kc_off(64 * wc + r16, g4);
+        rb[1] = lds0 + XL_A_BYTES + kc_off(64 * wc + r16, 4 + g4);
+        rb[2] = rb[3] = 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = lds0 + XL_A_BYTES + stp_off<XL_BN>(8 * g4 + (r16 >> 2), 64 * wc + 16 * i) + 8 * (r16 & 3);
+    }
+    auto read_b = [&](auto J, auto KS, unsigned so, bf16x8_t (&f)[4]) {
+        constexpr int j = decltype(J)::value, ks = decltype(KS)::value;
+        if constexpr (ABL) {
+            if (a.exp & 256) return;
+        }
+        if constexpr (B_KC) f[j] = xl_lds_b128<2048 * j>(rb[ks] + so);
+        else f[j] = xl_lds_tr<8192 * ks>(rb[j] + so);
+    };
+    constexpr int NA = A_KC ? 1 : 2, NB = B_KC ? 1 : 2;   // LDS instructions per fragment
+
+    constexpr bool CS = LAYOUT == L_TN;   // bias gradient beside a weight gradient: column sums of A
+    f32x4_t acc[4][4], accs[CS ? 4 : 1];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (CS) accs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    zero_acc();
+    const s16x8_t ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    // Fragment registers: B fragments in two sets (one per 32-deep half: every accumulator row uses all four); A fragments in ONE
+    // set refreshed in place — the read of row i's fragment for the next half goes out right behind row i's MFMAs — plus one spare
+    // (fx): the second half takes row 3 from fx, so that row 3's next fragment can be fetched BEFORE row 3's MFMAs in both halves and
+    // nothing is left in flight when the barrier wants the whole stage in registers.
+    bf16x8_t fa[4], fx, fb[2][4];
+    if constexpr (ABL) {
+        const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = fb[0][i] = fb[1][i] = ones;
+        fx = ones;
+    }
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    bool do_cs = false;
+    auto read_a1 = [&](auto I, auto KS, unsigned so, bf16x8_t& f) {   // one A fragment into a given register
+        constexpr int i = decltype(I)::value, ks = decltype(KS)::value;
+        if constexpr (ABL) {
+            if (a.exp & 256) return;
+        }
+        if constexpr (A_KC) f = xl_lds_b128<2048 * i>(ra[ks] + so);
+        else f = xl_lds_tr<8192 * ks>(ra[i] + so);
+    };
+    // the MFMAs of half H (0: A from fa[0..3], B from fb[0]; 1: A from fa[0..2] + fx, B from fb[1]), row by row; behind rows 0-2
+    // the reads of the NEXT half (stage offset sn, half NK) go out: A_0 B_0 B_1 | A_1 B_2 B_3 | A_2 A_3
+    auto half = [&](auto H, auto NK, auto WITH_READS, unsigned sn) {
+        constexpr int h = decltype(H)::value, o = 1 - h;
+        constexpr bool wr_ = decltype(WITH_READS)::value;
+        using NKt = decltype(NK);
+        xl_static_for<4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xl_pin(fb[h][j]);
+            }
+            bf16x8_t& fr = (h == 1 && i == 3) ? fx : fa[i];
+            xl_pin(fr);
+            bool skip = false;
+            if constexpr (ABL) skip = (a.exp & 2) != 0;
+            if (!skip) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[h][j], fr, acc[i][j], 0, 0, 0);
+                if constexpr (CS) {
+                    if (do_cs) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones_bits), fr, accs[i], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (wr_) {
+                if constexpr (i == 0) {
+                    read_a1(I0{}, NKt{}, sn, fa[0]);
+                    read_b(I0{}, NKt{}, sn, fb[o]);
+                    read_b(I1{}, NKt{}, sn, fb[o]);
+                } else if constexpr (i == 1) {
+                    read_a1(I1{}, NKt{}, sn, fa[1]);
+                    read_b(I2{}, NKt{}, sn, fb[o]);
+                    read_b(I3{}, NKt{}, sn, fb[o]);
+                } else if constexpr (i == 2) {
+                    read_a1(I2{}, NKt{}, sn, fa[2]);
+                    if constexpr (h == 0) read_a1(I3{}, NKt{}, sn, fx);
+                    else read_a1(I3{}, NKt{}, sn, fa[3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    auto first_reads = [&](unsigned so_) {   // half 0 of the stage at so_ into (fa, fb[0]): at a tile's start
+        read_a1(I0{}, K0{}, so_, fa[0]); read_a1(I1{}, K0{}, so_, fa[1]); read_a1(I2{}, K0{}, so_, fa[2]); read_a1(I3{}, K0{}, so_, fa[3]);
+        xl_static_for<4>([&](auto J) { read_b(J, K0{}, so_, fb[0]); });
+    };
+
+    if (t_first >= t_end) return;
+    stamp(1);
+    xl_bar();   // opening barrier: k-tile 0 of the first tile has landed
+    stamp(2);
+    unsigned so = 0;
+    for (int tile = t_first; tile < t_end; tile += t_step) {
+        const XlTile T = xl_decode(a, tile);
+        const GemmArgs& G = a.p[T.pi].g;
+        const int nk = G.K >> 6;
+        do_cs = CS && G.colsum != nullptr && T.tn == 0 && wc == 0;
+        first_reads(so);   // (the stage has landed: opening barrier, or the last barrier of the previous tile)
+        // (the last k-tile is peeled: a branch around the second half inside the loop makes every accumulator a phi and the
+        // register allocator answers with copies and spills)
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const unsigned sn = so + XL_STAGE == XL_NS * XL_STAGE ? 0u : so + XL_STAGE;
+            xl_wait_lgkm<0>();                        // half 0 of this k-tile
+            half(K0{}, K1{}, std::true_type{}, so);   // MFMAs of half 0; reads of half 1 of the same stage
+            xl_wait_lgkm<0>();                        // the whole stage is in registers
+            xl_bar();                                 // barrier g: the loaders refill this stage; the next k-tile has landed
+            half(K1{}, K0{}, std::true_type{}, sn);   // MFMAs of half 1; reads of the next k-tile's half 0
+            so = sn;
+        }
+        xl_wait_lgkm<0>();
+        half(K0{}, K1{}, std::true_type{}, so);
+        xl_wait_lgkm<0>();
+        xl_bar();
+        half(K1{}, K0{}, std::false_type{}, 0u);      // last k-tile: the fragment registers are the epilogue's from here
+        so = so + XL_STAGE == XL_NS * XL_STAGE ? 0u : so + XL_STAGE;
+        stamp(3);
+        bool skip_epi = false;
+        if constexpr (ABL) skip_epi = (a.exp & 4) != 0;
+        if (!skip_epi) {
+            // the lane index goes through an opaque asm here: everything the epilogue derives from it (row / column offsets of 16
+            // fragments, 64-bit) would otherwise be hoisted out of the tile loop and live — spilled — across the main loop
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            if constexpr (LAYOUT == L_TN) {
+                // weight gradient: plain fp32 tile (gemm_xl_serves admits no fused epilogue here) — 16-byte stores, no operand loads
+                float* C = reinterpret_cast<float*>(G.C) + (int64_t)(T.m0 + 64 * wr + (lane_e & 15)) * G.ldc + T.n0 + 64 * wc + 4 * (lane_e >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<f32x4_t*>(C + (int64_t)16 * i * G.ldc + 16 * j) = acc[i][j];
+            } else {
+                gemm_epilogue<4, 4>(G, acc, T.m0 + 64 * wr, T.n0 + 64 * wc, lane_e, 0, 0);
+            }
+            if constexpr (CS) {
+                if (do_cs && (lane_e >> 4) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) G.colsum[T.m0 + 64 * wr + 16 * i + (lane_e & 15)] = accs[i][0];
+                }
+            }
+        }
+        zero_acc();
+    }
+    if constexpr (ABL) {
+        stamp(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(5);
+    }
+}
+
+// Can the 256 x 128 kernel take this product as it stands?  (whole tiles, 16-byte rows, plain batch-1 product)
+bool gemm_xl_serves(int layout, const GemmArgs& g) {
+    if (g.inner > 1 || g.M % XL_BM || g.N % XL_BN || g.K % 64 || g.K < 64 || g.lda % 8 || g.ldb % 8) return false;
+    if (g.out_f32 ? (g.ldc % 4 != 0) : (g.ldc % 8 != 0 || (g.actin && g.ldact % 8 != 0))) return false;
+    if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B) | reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.C2) |
+         reinterpret_cast<uintptr_t>(g.actin)) & 15)
+        return false;
+    if (g.colsum && layout != L_TN) return false;
+    if (layout == L_TN && (!g.out_f32 || g.bias || g.residual || g.rowbias || g.actin || g.C2 || g.rpg || g.alpha != 1.0f)) return false;
+    // 32-bit per-lane piece offsets: (row inside the tile) * ld
+    const int64_t spanA = layout == L_TN ? (int64_t)64 * g.lda : (int64_t)XL_BM * g.lda;
+    const int64_t spanB = layout == L_NT ? (int64_t)XL_BN * g.ldb : (int64_t)64 * g.ldb;
+    return spanA * 2 < (1ll << 31) && spanB * 2 < (1ll << 31);
+}
+
+// n <= 8 products of one layout over one joint tile list.  -> 0 launched, 1 not served, < 0 error
+int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp, unsigned long long* trace) {
+    if (n < 1 || n > XL_MAXP) return 1;
+    XlArgs a{};
+    a.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!gemm_xl_serves(layout, probs[i])) return 1;
+        a.p[i].g = probs[i];
+        a.p[i].tiles_m = probs[i].M / XL_BM;
+        a.p[i].tiles_n = probs[i].N / XL_BN;
+        a.p[i].tile0 = total;
+        total += a.p[i].tiles_m * a.p[i].tiles_n;
+    }
+    if (total == 0) return 1;
+    a.total = total;
+    a.exp = exp & (1 | 2 | 4 | 16 | 256);
+    a.trace = trace;
+    const dim3 grid(total < 256 ? total : 256), block(XL_THREADS);
+#define XL_LAUNCH(L_)                                                                                                  \
+    do {                                                                                                               \
+        if (a.exp) hipLaunchKernelGGL((gemm_xl_kernel<L_, true>), grid, block, 0, s, a);                               \
+        else if (ev0) hipExtLaunchKernelGGL((gemm_xl_kernel<L_, false>), grid, block, 0, s, ev0, ev1, 0, a);           \
+        else hipLaunchKernelGGL((gemm_xl_kernel<L_, false>), grid, block, 0, s, a);                                    \
+    } while (0)
+    if (layout == L_NT) XL_LAUNCH(L_NT);
+    else if (layout == L_NN) XL_LAUNCH(L_NN);
+    else XL_LAUNCH(L_TN);
+#undef XL_LAUNCH
+    return check_launch("gemm_xl_kernel");
+}
+
+}  // namespace swat

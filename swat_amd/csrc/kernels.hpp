@@ -49,7 +49,10 @@ int launch_gemm_big(int layout, const GemmArgs& a, hipStream_t s, hipEvent_t ev0
 int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int cfg = 0);
 // n <= 8 weight gradients dW_i = dY_i^T X_i (TN, fp32 out, optional column sums of dY) as ONE launch of 256 x 128 tiles
 // (gemm_wgrad.hip); -> 0 launched, 1 shapes not served (run them one by one), < 0 error
-int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp = 0, unsigned long long* trace = nullptr);
+// 256 x 128 tiles, loader / consumer waves, persistent over the joint tile list of n <= 8 products of one layout (gemm_xl.hip)
+bool gemm_xl_serves(int layout, const GemmArgs& g);
+int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp = 0, unsigned long long* trace = nullptr);
 int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s, bool dry_run = false);   // policy + launch_wgrad_group (gemm.hip); same
                                                                                          // return values; dry_run: only say whether it would launch
 // n products of one layout: one grouped launch when every product qualifies, else one launch each

@@ -45,6 +45,27 @@ def timeit(mode, pairs, n=24):
 
 fl = sum(2.0 * m * n * k for (m, n, k, _) in shapes)
 for rnd in range(4):
-    a, b = timeit(0, True), timeit(2, False)
-    print(f"round {rnd}: four launches {a:7.1f} us ({fl / a / 1e6:6.0f} TF)   one 256x128 launch {b:7.1f} us ({fl / b / 1e6:6.0f} TF)")
+    a = timeit(0, True)
+    lib.swat_gemm_set_exp(4096); c = timeit(2, False); lib.swat_gemm_set_exp(0)
+    b = timeit(2, False)
+    print(f"round {rnd}: four launches {a:7.1f} us ({fl / a / 1e6:6.0f} TF)   one launch, every wave loads + computes {c:7.1f} us ({fl / c / 1e6:6.0f} TF)   "
+          f"loader / consumer waves {b:7.1f} us ({fl / b / 1e6:6.0f} TF)")
+for bits, name in ((4, "no epilogue"), (1 | 4, "no epilogue, no DMA"), (2 | 4, "no epilogue, no MFMA"), (256 | 4, "no epilogue, no reads"),
+                   (2 | 256 | 4, "no epilogue, no MFMA, no reads"), (1 | 2 | 4, "no epilogue, no DMA, no MFMA"), (1 | 2 | 4 | 256, "launch + ring fill + barriers only")):
+    lib.swat_gemm_set_exp(bits)
+    print(f"ablation {bits:4d} ({name:28s}): {timeit(2, False):7.1f} us")
+import numpy as np
+buf = torch.zeros(8 * 512, dtype=torch.int64, device=dev)
+lib.swat_gemm_set_trace(buf.data_ptr()); lib.swat_gemm_set_exp(16); lib.swat_gemm_set_wgrad_big(2)
+for i in range(4): call(sets[i % NBUF])
+torch.cuda.synchronize(); buf.zero_()
+call(sets[4 % NBUF]); torch.cuda.synchronize()
+t = buf.cpu().numpy().reshape(-1, 8); t = t[t[:, 0] != 0]
+s = (t[:, :6] - t[:, 0].min()) / 100.0
+med = lambda a: float(np.median(a))
+print(f"stamps of {len(t)} workgroups (us): entry spread {s[:,0].max():.2f}; set-up + prologue issue {med(s[:,1]-s[:,0]):.2f}; first k-tile landed {med(s[:,2]-s[:,1]):.2f} "
+      f"(max {np.max(s[:,2]-s[:,1]):.2f}); main loop {med(s[:,3]-s[:,2]):.2f} (min {np.min(s[:,3]-s[:,2]):.2f} max {np.max(s[:,3]-s[:,2]):.2f}); epilogue issue {med(s[:,4]-s[:,3]):.2f}; "
+      f"store ack {med(s[:,5]-s[:,4]):.2f} (max {np.max(s[:,5]-s[:,4]):.2f}); last workgroup done at {s[:,5].max():.2f}")
+lib.swat_gemm_set_trace(None)
+lib.swat_gemm_set_exp(0)
 lib.swat_gemm_set_wgrad_big(1)

@@ -95,7 +95,7 @@ def gemm_roofline(args, step, sched, images, labels, n_steps, bsz, overlap=1):
     cnt = (ctypes.c_int64 * 12)()
     fl = (ctypes.c_double * 12)()
     n = lib.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
-    names = ["NT_64", "NT_128", "NT_pc", "NN_64", "NN_128", "NN_pc", "TN_64", "TN_128", "TN_pc", "fwd_persistent", "TN_block_256x128", "-"]
+    names = ["NT_64", "NT_128", "NT_pc", "NN_64", "NN_128", "NN_pc", "TN_64", "TN_128", "TN_pc", "fwd_persistent", "TN_block_256x128", "xl_256x128"]
     total_ms = sum(ms) / n_steps
     # What is inside the timed kernels: every product of the step.  The persistent forward (csrc/vit_mega.hip, kind 9) holds all
     # twelve blocks' products AND their attention, LayerNorms and hand-offs — its whole duration is charged to the roofline.

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ln_bwd_reduce sums them in a fixed order (deterministic, no float atomics).
 // Each block = 4 waves; each wave walks rows  wave_global, wave_global + nwaves, ...
 // --------------------------------------------------------------------------------------------
-constexpr int LNB_MAX_BLOCKS = 1024;  // one row per wave up to 8 192 rows (ViT-L/14 at B = 32); partial sums: 1024 x 3 x d floats
+constexpr int LNB_MAX_BLOCKS = 512;   // two workgroups per CU; partial sums: 512 x 3 x d floats (1024 workgroups gave the reduction behind it 12.6 MB to
+                                      // read at d = 1024: 34 us per LayerNorm on 96 workgroups, 1.7 ms of a ViT-L/14 step)
 // waves per workgroup: 8 up to d = 768 (M = 1600 rows -> 200 workgroups, every wave exactly one row, ~126 VGPRs: two
 // workgroups per CU); 4 for wider rows (~150 VGPRs: three 4-wave workgroups per CU instead of one 8-wave workgroup)
 static inline int lnb_waves(int d) { return d <= 768 ? 8 : 4; }

@@ -747,6 +747,19 @@ static int pick_cfg_base(int layout, const GemmArgs& a, int batch) {
     // 256 x 256 tile's quantisation loss is gone (1 800+ tiles) and it wins every product but out_proj.  Measured per launch
     // (tools/perf_gemm.py, M = 51 200, d = 768; the previous choice in brackets): in_proj 234 us = 775 TF (303), c_fc 387 (426),
     // c_proj 292 = 827 TF (332); M = 78 848, d = 512: in_proj 187 (284), c_proj 223 (280).
+    // 256 x 128 tiles with loader / consumer waves, persistent (gemm_xl.hip, configuration 90): whole rounds of the chip.  Measured per
+    // launch with the step's epilogues (tools/perf_gemm.py, round 4; the previous choice in brackets) — M = 8 224, d = 1 024 (32 tile
+    // rows + a 32-row remainder launch): in_proj 61 us = 843 TF (78), out_proj 34 (39), c_fc 101 (116), c_proj 83 = 836 TF (96),
+    // c_proj dgrad 98 (127), c_fc dgrad 76 = 910 TF (86), out_proj dgrad 28 (29), in_proj dgrad 60 = 868 TF (69): 0.93 of what the
+    // vendor library needs for the eight plain products.  It LOSES where the tile grid leaves a round mostly empty (M = 6 304, d = 768:
+    // 144 / 432 / 576 tiles), so it is taken only when the last round is at least 90 % full.
+    if (many_rows && layout != L_TN && !(g_exp & (512 | 8192)) && a.inner == 1 && a.N % 128 == 0 && a.K >= 512 && a.M >= 2048) {
+        const int64_t t = (int64_t)(a.M / 256) * (a.N / 128), rounds = (t + 255) / 256;
+        const bool big80 = a.M >= 32768 && layout == L_NT && (a.N >= 1024 || a.K >= 2048) && a.N % 256 == 0 && !a.actin;   // (the 256 x 256 tile below)
+        GemmArgs m = a;
+        m.M = a.M / 256 * 256;
+        if (t >= 256 && t * 10 >= rounds * 256 * 9 && !big80 && !a.rpg && !a.rowbias && gemm_xl_serves(layout, m)) return 90;
+    }
     if (a.M >= 32768 && layout == L_NT && !(g_exp & 512) && (a.N >= 1024 || a.K >= 2048) && a.N % 256 == 0 && a.inner == 1 &&
         a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.actin && a.K >= 512)
         return 80;
@@ -810,6 +823,42 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
     // kernel's execution time as rocprofv3 reports it, without the ~2-3 us each separately recorded event adds
     hipEvent_t ev0 = prof ? g_prof.ev[2 * g_prof.n] : nullptr, ev1 = prof ? g_prof.ev[2 * g_prof.n + 1] : nullptr;
     int rc;
+    if (tile == 90) {
+        // 256 x 128 tiles, loader / consumer waves, persistent (gemm_xl.hip): whole tiles only — the rows beyond the last multiple of
+        // 256 (every fused epilogue is row-local) go to a second, small launch
+        const int Mmain = layout == L_TN ? a.M : a.M / 256 * 256;
+        GemmArgs m = a;
+        m.M = Mmain;
+        const bool ok = batch == 1 && a.inner == 1 && Mmain >= 256 && !a.rpg && !a.rowbias && gemm_xl_serves(layout, m) &&
+                        (a.M == Mmain || ((int64_t)Mmain * a.ldc) % 8 == 0);
+        if (ok) {
+            rc = launch_gemm_xl(layout, &m, 1, s, ev0, ev1, g_exp, g_trace_host);
+            if (prof) {
+                g_prof.kind[g_prof.n] = layout == L_TN ? 10 : 11;
+                g_prof.flops[g_prof.n] = 2.0 * Mmain * a.N * a.K;
+                ++g_prof.n;
+            }
+            if (rc == 0 && a.M > Mmain) {
+                GemmArgs r = a;
+                r.M = a.M - Mmain;
+                r.A = a.A + (int64_t)Mmain * a.lda;
+                const int64_t co = (int64_t)Mmain * a.ldc;
+                if (a.C) r.C = a.out_f32 ? (void*)((float*)a.C + co) : (void*)((unsigned short*)a.C + co);
+                if (a.C2) r.C2 = (unsigned short*)a.C2 + co;
+                if (a.residual) r.residual = a.residual + co;
+                if (a.actin) r.actin = a.actin + (int64_t)Mmain * a.ldact;
+                rc = (g_exp & 16384) ? 1 : launch_gemm_skinny(layout, r, s);   // one wave per 16 columns (gemm_skinny.hip)
+                if (rc == 1) {
+                    const int keep = g_force_cfg;
+                    g_force_cfg = -1;
+                    rc = gemm_dispatch(layout, r, 1, s);
+                    g_force_cfg = keep;
+                }
+            }
+            return rc;
+        }
+        tile = layout == L_TN ? 50 : (a.K % 64 == 0 ? 14 : 20);
+    }
     if (tile == 80 && (layout == L_TN || batch != 1 || a.inner != 1 || a.K % 64 != 0 || a.K < 128 || a.lda % 8 || a.ldb % 8)) tile = layout == L_TN ? 50 : 14;
     if (tile == 80) rc = launch_gemm_big(layout, a, s, ev0, ev1);  // 256 x 256, matrix-core bound (gemm_big.hip)
     else if (tile >= 70 && tile <= 72 && batch == 1 && a.inner == 1) rc = launch_gemm_pc_group(layout, &a, 1, s, ev0, ev1, tile);  // persistent tile loop
@@ -828,7 +877,7 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
 
 // n products of one layout (the weight gradients of a transformer block): ONE persistent launch over the joint tile list
 // when every product qualifies for the producer / consumer kernel's grouped form, else one launch each.
-static int g_wgrad_big = 1;   // swat_gemm_set_wgrad_big: 0 = never, 1 = when the joint list is one round of 256 x 128 tiles, 2 = always
+static int g_wgrad_big = getenv("SWAT_WGRAD_BIG") ? atoi(getenv("SWAT_WGRAD_BIG")) : 1;   // swat_gemm_set_wgrad_big: 0 = never, 1 = when the joint list is one round of 256 x 128 tiles, 2 = always
 
 // the weight gradients of a block as ONE round of 256 x 128 tiles (gemm_wgrad.hip): taken when the joint tile list fills most of
 // the chip once — more tiles than CUs would run a second, mostly empty round at a whole tile's latency each.
@@ -841,7 +890,10 @@ int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s, bool dry_run) {
         tiles += ((probs[i].M + 255) / 256) * ((probs[i].N + 127) / 128);
         deep = deep && probs[i].K >= 512 && probs[i].M >= 256 && probs[i].N >= 128;
     }
-    if (g_wgrad_big != 2 && !(deep && tiles >= 144 && tiles <= 256)) return 1;
+    // (more tiles than one round: the persistent form walks them; taken while the last round is at least half full — ViT-L/14's
+    // block is 384 tiles = 1.5 rounds and still 4 % faster in the step than four launches of 128 x 128 tiles)
+    const int rounds = (tiles + 255) / 256;
+    if (g_wgrad_big != 2 && !(deep && tiles >= 144 && tiles * 4 >= rounds * 256 * 3)) return 1;
     if (dry_run) {   // would launch_wgrad_group take these shapes?
         for (int i = 0; i < n; ++i) {
             const GemmArgs& g = probs[i];

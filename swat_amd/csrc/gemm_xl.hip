@@ -108,6 +108,117 @@ __device__ __forceinline__ XlTile xl_decode(const XlArgs& a, int id) {
     return XlTile{pi, tm * XL_BM, tn * XL_BN, tn};
 }
 
+
+// ---- epilogues of a consumer wave's 64 x 64 tile, one instantiation per combination of fused operands (the one generic
+// epilogue of gemm_device.hpp holds registers for every combination at once: beside 64 accumulator registers and a 168-register
+// budget it spilled, and a tile's epilogue took longer than its main loop).  Same arithmetic and rounding points as gemm_epilogue.
+// Lane (r16 = lane & 15, g = lane >> 4) holds C[m = mbase + 16 i + r16][n = nbase + 16 j + 4 g .. + 3] in acc[i][j].
+template <bool RES>
+__device__ __forceinline__ void xl_epi_f32(const GemmArgs& p, f32x4_t (&acc)[4][4], int mbase, int nbase, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const int n = nbase + 4 * g;
+    float4 b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t o = (int64_t)(mbase + r16) * p.ldc + n;
+    float* C = reinterpret_cast<float*>(p.C) + o;
+    const float* R = p.residual + o;
+    const int64_t rs = (int64_t)16 * p.ldc;
+    float4 rc[4], rn[4];
+    if constexpr (RES) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rc[j] = *reinterpret_cast<const float4*>(R + 16 * j);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (RES) {
+            if (i + 1 < 4) {   // the next row's residual is requested before this row's stores (loads and stores share vmcnt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rn[j] = *reinterpret_cast<const float4*>(R + (i + 1) * rs + 16 * j);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = make_float4(acc[i][j][0] * p.alpha + b[j].x, acc[i][j][1] * p.alpha + b[j].y, acc[i][j][2] * p.alpha + b[j].z,
+                                   acc[i][j][3] * p.alpha + b[j].w);
+            if constexpr (RES) { v.x += rc[j].x; v.y += rc[j].y; v.z += rc[j].z; v.w += rc[j].w; }
+            *reinterpret_cast<float4*>(C + i * rs + 16 * j) = v;
+        }
+        if constexpr (RES) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rc[j] = rn[j];
+        }
+    }
+}
+
+template <bool ACTIN, bool SECOND>
+__device__ __forceinline__ void xl_epi_bf16(const GemmArgs& p, f32x4_t (&acc)[4][4], int mbase, int nbase, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    // two accumulator tiles that are neighbours in n trade halves (v_permlane16_swap): lane (r16, g) then holds row r16 of tile
+    // 2 q + (g & 1), columns 8 (g >> 1) .. + 7 — eight consecutive n, one 16-byte store per output
+    const int n = nbase + 16 * (g & 1) + 8 * (g >> 1);   // + 32 q
+    float4 b[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        b[q][0] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n + 32 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[q][1] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n + 32 * q + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    u32x4_t f[ACTIN ? 8 : 1];
+    if constexpr (ACTIN) {   // every activation-input chunk of the tile up front: 32 registers, one latency
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                f[2 * i + q] = *reinterpret_cast<const u32x4_t*>(p.actin + (int64_t)(mbase + 16 * i + r16) * p.ldact + n + 32 * q);
+    }
+    const int64_t o0 = (int64_t)(mbase + r16) * p.ldc + n;
+    const int64_t rs = (int64_t)16 * p.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float lo = acc[i][2 * q][e], hi = acc[i][2 * q + 1][e];
+                asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                v[e] = lo * p.alpha;
+                v[4 + e] = hi * p.alpha;
+            }
+            v[0] += b[q][0].x; v[1] += b[q][0].y; v[2] += b[q][0].z; v[3] += b[q][0].w;
+            v[4] += b[q][1].x; v[5] += b[q][1].y; v[6] += b[q][1].z; v[7] += b[q][1].w;
+            if constexpr (ACTIN) {   // dgrad through the activation: dF = dG * act'(F)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const unsigned w = f[2 * i + q][h];
+                    v[2 * h] *= act_bwd(bf2f((unsigned short)(w & 0xffffu)), p.act);
+                    v[2 * h + 1] *= act_bwd(bf2f((unsigned short)(w >> 16)), p.act);
+                }
+            }
+            const int64_t o = o0 + i * rs + 32 * q;
+            u32x4_t pk;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) pk[h] = pack_bf16x2(v[2 * h], v[2 * h + 1]);
+            if (!p.c2_only) *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(p.C) + o) = pk;
+            if constexpr (SECOND) {   // second output: activation of the ROUNDED pre-activation (what backward re-reads)
+                u32x4_t pk2;
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+                    pk2[h] = pack_bf16x2(act_fwd(__uint_as_float(pk[h] << 16), p.act), act_fwd(__uint_as_float(pk[h] & 0xffff0000u), p.act));
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(p.C2) + o) = pk2;
+            }
+        }
+}
+
+__device__ __forceinline__ void xl_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][4], int mbase, int nbase, int lane) {
+    if (p.out_f32) {
+        if (p.residual) xl_epi_f32<true>(p, acc, mbase, nbase, lane);
+        else xl_epi_f32<false>(p, acc, mbase, nbase, lane);
+    } else if (p.actin) xl_epi_bf16<true, false>(p, acc, mbase, nbase, lane);
+    else if (p.C2) xl_epi_bf16<false, true>(p, acc, mbase, nbase, lane);
+    else xl_epi_bf16<false, false>(p, acc, mbase, nbase, lane);
+}
+
 template <int LAYOUT, bool ABL>
 __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const XlArgs a) {
     constexpr bool A_KC = (LAYOUT != L_TN);
@@ -382,7 +493,7 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const XlArgs a) {
                     for (int j = 0; j < 4; ++j)
                         *reinterpret_cast<f32x4_t*>(C + (int64_t)16 * i * G.ldc + 16 * j) = acc[i][j];
             } else {
-                gemm_epilogue<4, 4>(G, acc, T.m0 + 64 * wr, T.n0 + 64 * wc, lane_e, 0, 0);
+                xl_epilogue(G, acc, T.m0 + 64 * wr, T.n0 + 64 * wc, lane_e);
             }
             if constexpr (CS) {
                 if (do_cs && (lane_e >> 4) == 0) {
@@ -408,6 +519,7 @@ bool gemm_xl_serves(int layout, const GemmArgs& g) {
          reinterpret_cast<uintptr_t>(g.actin)) & 15)
         return false;
     if (g.colsum && layout != L_TN) return false;
+    if (g.rpg || g.rowbias || (g.actin && (g.C2 || g.out_f32)) || (g.C2 && g.out_f32) || (g.residual && !g.out_f32)) return false;   // combinations the step never asks for
     if (layout == L_TN && (!g.out_f32 || g.bias || g.residual || g.rowbias || g.actin || g.C2 || g.rpg || g.alpha != 1.0f)) return false;
     // 32-bit per-lane piece offsets: (row inside the tile) * ld
     const int64_t spanA = layout == L_TN ? (int64_t)64 * g.lda : (int64_t)XL_BM * g.lda;

@@ -53,6 +53,8 @@ int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t e
 // 256 x 128 tiles, loader / consumer waves, persistent over the joint tile list of n <= 8 products of one layout (gemm_xl.hip)
 bool gemm_xl_serves(int layout, const GemmArgs& g);
 int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp = 0, unsigned long long* trace = nullptr);
+// M <= 64 rows (the remainder of a many-row product): one wave per 16 output columns (gemm_skinny.hip); -> 0 / 1 not served / < 0
+int launch_gemm_skinny(int layout, const GemmArgs& a, hipStream_t s);
 int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s, bool dry_run = false);   // policy + launch_wgrad_group (gemm.hip); same
                                                                                          // return values; dry_run: only say whether it would launch
 // n products of one layout: one grouped launch when every product qualifies, else one launch each

@@ -1,4 +1,5 @@
 """GPU: each path A HIP kernel (through the C ABI) against a plain PyTorch fp32 reference of the same op."""
+import ctypes
 import math
 
 import numpy as np
@@ -553,6 +554,82 @@ def test_gemm_256_tile_epilogues_on_many_rows(layout, epi):
             close(C.float(), ref * (sg * (1 + 1.702 * x * (1 - sg))), True, K)
     finally:
         _lib.lib().swat_gemm_set_tile(-1)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+@pytest.mark.parametrize("epi", ["bias_act_c2", "residual_f32", "actin", "plain_f32"])
+@pytest.mark.parametrize("M", [8224, 1024])
+def test_gemm_256x128_loader_consumer_tile_epilogues(layout, epi, M):
+    """csrc/gemm_xl.hip (configuration 90: 256 x 128 tiles, 8 consumer + 4 loader waves, persistent over the tile list) with the
+    fused epilogues of the step — M = 8 224 = 32 whole tile rows + 32 rows that leave through a second, small launch (ViT-L/14 at
+    B = 32) and M = 1 024 (fewer tiles than workgroups) — against fp32 torch, bit-identical from run to run."""
+    from swat_amd import ops, _lib
+    N, K = 1024, 1024
+    a = rnd(M, K, seed=41, dtype=BF)
+    w = rnd(N, K, seed=42, scale=0.05, dtype=BF)
+    ref = a.float() @ w.float().t()
+    B = w if layout == "nt" else w.t().contiguous()
+    lay, ldb = (ops.NT, K) if layout == "nt" else (ops.NN, N)
+    bias = rnd(N, seed=43)
+    lib = _lib.lib()
+    lib.swat_gemm_set_tile(90)
+    lib.swat_gemm_prof_begin(16)
+    try:
+        if epi == "bias_act_c2":
+            C = torch.empty(M, N, device=dev(), dtype=BF)
+            C2 = torch.empty(M, N, device=dev(), dtype=BF)
+            ops.gemm(lay, a, B, M, N, K, K, ldb, C, N, bias=bias, act="quick_gelu", C2=C2)
+            close(C.float(), (ref + bias).to(BF).float(), True, K)
+            close(C2.float(), (C.float() * torch.sigmoid(1.702 * C.float())), True, 8)
+            only = torch.empty(M, N, device=dev(), dtype=BF)
+            ops.gemm(lay, a, B, M, N, K, K, ldb, None, N, bias=bias, act="quick_gelu", C2=only)
+            assert torch.equal(only, C2)
+        elif epi == "residual_f32":
+            C = rnd(M, N, seed=44)
+            res = C.clone()
+            ops.gemm(lay, a, B, M, N, K, K, ldb, C, N, bias=bias, residual=C)
+            close(C, ref + bias + res, False, K)
+        elif epi == "actin":
+            f = rnd(M, N, seed=45, dtype=BF)
+            C = torch.empty(M, N, device=dev(), dtype=BF)
+            ops.gemm(lay, a, B, M, N, K, K, ldb, C, N, actin=f, ldact=N, act="quick_gelu")
+            x = f.float()
+            sg = torch.sigmoid(1.702 * x)
+            close(C.float(), ref * (sg * (1 + 1.702 * x * (1 - sg))), True, K)
+        else:
+            C = torch.full((M, N), float("nan"), device=dev())
+            ops.gemm(lay, a, B, M, N, K, K, ldb, C, N)
+            close(C, ref, False, K)
+            again = torch.full((M, N), float("nan"), device=dev())
+            ops.gemm(lay, a, B, M, N, K, K, ldb, again, N)
+            assert torch.equal(C, again)
+    finally:
+        lib.swat_gemm_set_tile(-1)
+        ms, cnt, fl = (ctypes.c_double * 12)(), (ctypes.c_int64 * 12)(), (ctypes.c_double * 12)()
+        lib.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
+    assert cnt[11] >= 1, "the product must have gone through the 256 x 128 loader / consumer kernel"
+
+
+def test_gemm_256x128_loader_consumer_tile_weight_gradient_many_rows():
+    """The same kernel on one deep weight gradient (ViT-L/14 c_fc at B = 32: 4 096 x 1 024 outputs, 8 256 padded rows): 128 tiles on
+    128 workgroups, 129 k-tiles each, with the bias gradient's column sums."""
+    from swat_amd import _lib
+    lib = _lib.lib()
+    R, Nout, Nin = 8256, 4096, 1024
+    dy, x = rnd(R, Nout, seed=61, dtype=BF), rnd(R, Nin, seed=62, dtype=BF)
+    dy[8224:].zero_(); x[8224:].zero_()
+    dw = torch.full((Nout, Nin), float("nan"), device=dev())
+    db = torch.full((Nout,), float("nan"), device=dev())
+    ws = torch.empty(lib.swat_colsum_bf16_workspace_bytes(Nout), dtype=torch.uint8, device=dev())
+    lib.swat_gemm_set_tile(90)
+    try:
+        _lib.check(lib.swat_linear_wgrad_bias(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), R, Nout, Nin, Nout, Nin, _lib.ptr(ws),
+                                              _lib.stream()), "swat_linear_wgrad_bias")
+    finally:
+        lib.swat_gemm_set_tile(-1)
+    close(dw, dy.float().t() @ x.float(), False, R)
+    ref = dy.float().sum(0)
+    assert (db - ref).abs().max().item() <= 1e-5 * math.sqrt(R) * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("M,N,K", [(32, 200, 512), (32, 768, 512), (64, 1000, 768), (5, 37, 64), (1, 1, 1024), (33, 129, 192)])

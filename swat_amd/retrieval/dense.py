@@ -115,37 +115,60 @@ EPS_MAX_D = 1024                    # largest d the bound above covers
 _cache = {}
 
 
+_shape_cache = {}
+
+
+def _shape_buffers(nq, d, k, dev):
+    """Everything of a call that depends only on (n_q, d, k, device): candidate lists, re-score index / value tensors, the staging
+    workspace (zeroed once: the scan's regroup pass leaves its counters zero), the packed-query buffer.  A NEW query tensor — the
+    case a retrieval job has — re-uses all of it: the cold call then launches the threshold sample product, two rank selections,
+    the query packing and one |q| reduction, and nothing else (round 3 rebuilt these 14 tensors per query tensor: ~0.05 ms of
+    allocator work and fill launches per cold call)."""
+    key = (nq, d, k, str(dev))
+    b = _shape_cache.get(key)
+    if b is None:
+        K2 = min(TOPK2_MAX, max(64, (max(2 * k, k + 256) + 63) // 64 * 64))
+        nbytes, wbytes = int(_lib.lib().swat_dense_packed_bytes(nq, d)), int(_lib.lib().swat_dense_workspace_bytes(nq))
+        packed = bool(nbytes and wbytes)  # d % 128 == 0, n_q <= 4096: the packed image the deep kernel reads linearly (csrc/retrieval_bf16.hip)
+        b = dict(K2=K2, packed=packed,
+                 qb=torch.empty(nbytes, dtype=torch.uint8, device=dev) if packed else None,
+                 ws=torch.zeros(wbytes, dtype=torch.uint8, device=dev) if packed else None,   # the slot counters start (and are left) zero
+                 row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
+                 idx2=torch.empty((nq, K2), dtype=torch.int64, device=dev), val2=torch.empty((nq, K2), dtype=torch.float32, device=dev),
+                 cnt2=torch.empty(nq, dtype=torch.int64, device=dev), keys2=torch.empty((nq, K2), dtype=torch.int64, device=dev),
+                 fails=torch.zeros(1, dtype=torch.int32, device=dev),   # zeroed by the select launch, added to by the last one
+                 keys=torch.empty((nq, CAP), dtype=torch.int64, device=dev), cnt=torch.zeros(nq, dtype=torch.int32, device=dev),
+                 n2=torch.zeros(1, dtype=torch.float32, device=dev), cnt_clean=True)
+        if len(_shape_cache) >= 4:
+            _shape_cache.clear()
+        _shape_cache[key] = b
+    return b
+
+
 def _prepared(db, queries, k, sample):
-    """Per (database, queries, k): pruning thresholds (from a row sample, exact scores), the packed bf16 queries, |q| max, the
-    static index tensors of the re-scoring step.  A hit needs the SAME tensor objects (weak references: a new tensor that
-    happens to reuse a freed tensor's address is a miss) at the same version, so in-place updates invalidate it too."""
+    """Per (database, queries, k): pruning thresholds (from a row sample), the packed bf16 queries, |q| max — on top of the
+    shape's buffers (_shape_buffers).  A hit needs the SAME tensor objects (weak references: a new tensor that happens to reuse a
+    freed tensor's address is a miss) at the same version, so in-place updates invalidate it too."""
     import weakref
     key = (db.shape, db._version, queries.shape, queries._version, k)
     hit = (_cache.get("key") == key and _cache["db_ref"]() is db and _cache["q_ref"]() is queries
            and _cache["ptrs"] == (db.data_ptr(), queries.data_ptr()))
     if not hit:
-        nq = queries.shape[0]
-        K2 = min(TOPK2_MAX, max(64, (max(2 * k, k + 256) + 63) // 64 * 64))
+        nq, d = queries.shape
+        b = _shape_buffers(nq, d, k, db.device)
+        K2 = b["K2"]
         thr = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)), approx=True)
-        dev = db.device
-        d = queries.shape[1]
-        nbytes, wbytes = int(_lib.lib().swat_dense_packed_bytes(nq, d)), int(_lib.lib().swat_dense_workspace_bytes(nq))
-        ws = None
-        if nbytes and wbytes:  # d % 128 == 0, n_q <= 4096: the packed image the deep kernel reads linearly (csrc/retrieval_bf16.hip)
-            qb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if b["packed"]:
+            qb = b["qb"]
             _lib.check(_lib.lib().swat_dense_pack_queries(_lib.ptr(queries), nq, d, _lib.ptr(qb), _lib.stream()), "swat_dense_pack_queries")
-            ws = torch.zeros(wbytes, dtype=torch.uint8, device=dev)   # the slot counters start (and are left) zero: swat_sim_candidates_shadow
         else:
             qb = queries.to(torch.bfloat16).contiguous()
+        clean = b["cnt_clean"]
         _cache.clear()
+        _cache.update(b)
         _cache.update(key=key, db_ref=weakref.ref(db), q_ref=weakref.ref(queries), ptrs=(db.data_ptr(), queries.data_ptr()),
-                      thr=thr, qb=qb, ws=ws, qn2=queries.norm(dim=1).max().reshape(1), K2=K2,   # max |q| stays on the device: no host sync
-                      row_seg=torch.arange(nq, device=dev, dtype=torch.int32).repeat_interleave(K2).contiguous(),
-                      idx2=torch.empty((nq, K2), dtype=torch.int64, device=dev), val2=torch.empty((nq, K2), dtype=torch.float32, device=dev),
-                      cnt2=torch.empty(nq, dtype=torch.int64, device=dev), keys2=torch.empty((nq, K2), dtype=torch.int64, device=dev),
-                      fails=torch.zeros(1, dtype=torch.int32, device=dev),   # zeroed by the select launch, added to by the last one
-                      keys=torch.empty((nq, CAP), dtype=torch.int64, device=dev), cnt=torch.zeros(nq, dtype=torch.int32, device=dev),
-                      n2=torch.zeros(1, dtype=torch.float32, device=dev))
+                      thr=thr, qb=qb, qn2=queries.norm(dim=1).max().reshape(1),   # max |q| stays on the device: no host sync
+                      cnt_clean=clean, shape=b)
     return _cache
 
 
@@ -179,6 +202,8 @@ def candidates(c, db, row_base=0, shadow=None, set_n2=True):
     L = _lib.lib()
     nq = c["cnt"].numel()
     c["cnt_clean"] = False   # the counters now hold this pass's counts (topk_dense's last launch clears them again)
+    if "shape" in c:
+        c["shape"]["cnt_clean"] = False
     if shadow is not None and c["ws"] is not None:
         _lib.check(L.swat_sim_candidates_shadow(_lib.ptr(c["qb"]), nq, _lib.ptr(shadow.rows), db.shape[0], db.shape[1], _lib.ptr(c["thr"]),
                                                 int(row_base), _lib.ptr(c["keys"]), CAP, _lib.ptr(c["cnt"]), _lib.ptr(c["ws"]),
@@ -224,6 +249,8 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
     if not c.get("cnt_clean", False):
         cnt.zero_()
     c["cnt_clean"] = False
+    if "shape" in c:
+        c["shape"]["cnt_clean"] = False
     if use_shadow:
         n2 = shadow.n2
     else:
@@ -247,6 +274,8 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
                                             _lib.ptr(cnt), CAP, K2, _lib.ptr(val2), _lib.ptr(thr), need, float(EPS_BF16), _lib.ptr(n2),
                                             _lib.ptr(c["qn2"]), _lib.ptr(c["fails"]), 1, _lib.stream()), "swat_candidates_topk_proof")
     c["cnt_clean"] = True   # (the launch above clears every cnt[q] once it has read it)
+    if "shape" in c:
+        c["shape"]["cnt_clean"] = True
     if c["fails"].item() != 0:  # the one host synchronisation of the call
         last_path = "exact-fallback"
         return topk_dense_exact(db, queries, k, row_base, sample)

@@ -583,6 +583,70 @@ def preprocess_secondary(dev, bsz=32, h=375, w=500, steps=50):
                          "achieved": round(nbytes / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / dt / 8e12, 4), "traffic": None}}
 
 
+def decode_secondary(dev, bsz=32, h=375, w=500, steps=20, with_cpu=True):
+    """§8(f).2, both halves: one batch of JPEG FILES (synthetic 500 x 375 photographs-like content, quality 90, 4:2:0 — what a scraped
+    LAION / few-shot image looks like) -> normalised fp32 batch: Huffman entropy decode on host threads, dequantise + inverse DCT +
+    chroma upsampling + colour conversion + crop / bicubic resize / flip / normalise on the GPU (swat_jpeg_decode_batch +
+    swat_preprocess_batch), against what the reference's loader workers do per image on one host core (Pillow decode + the host
+    transform).  Host-bound by construction (the entropy decode): reported with the thread count, no device roofline."""
+    import io
+    import numpy as np
+    from PIL import Image
+    from swat_amd import jpeg, transforms as T
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:h, 0:w]
+    files = []
+    for i in range(bsz):
+        a = np.stack([128 + 100 * np.sin(xx / (7.0 + i) + yy / 11.0), 128 + 90 * np.cos(xx / 5.0 - yy / (3.0 + i)), (xx * 3 + yy * 5 + 17 * i) % 256], -1)
+        a = np.clip(a + rng.normal(0, 10, a.shape), 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(a).save(b, "JPEG", quality=90, subsampling=2)
+        files.append(b.getvalue())
+    tf = T.DeviceBatchTransform(224, "train", dev)
+    torch.manual_seed(0)
+    geo = [tf.geometry(w, h) for _ in range(bsz)]
+    sizes = [(w, h)] * bsz
+    threads = min(16, os.cpu_count() or 1)
+    out = tf.from_jpeg(files, geometry=geo, sizes=sizes, threads=threads)
+    # the check: the same files through Pillow + the same device transform (itself pinned to Pillow, tests/test_gpu_preprocess.py)
+    same = bool(torch.equal(out, tf([Image.open(io.BytesIO(f)).convert("RGB") for f in files], geometry=geo)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tf.from_jpeg(files, geometry=geo, sizes=sizes, threads=threads)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        jpeg.decode_batch(files, dev, sizes=sizes, threads=threads)
+    torch.cuda.synchronize()
+    dt_dec = (time.perf_counter() - t0) / steps
+    rec = {"metric": "JPEG decode + image transform img/s (files -> normalised fp32 batch)", "value": round(bsz / dt, 1), "unit": "img/s",
+           "config": {"workload": f"{bsz} baseline JPEG files {w}x{h} (quality 90, 4:2:0, {sum(len(f) for f in files) // bsz} B each) -> [{bsz},3,224,224] fp32, "
+                                  "train transform", "host_threads": threads},
+           "ms_per_pass": round(dt * 1e3, 3), "dtype": "u8/int16/int32", "decode_only_img_per_s": round(bsz / dt_dec, 1),
+           "equals_pillow_decode": same}
+    if with_cpu:
+        host_tf = T.build_transform(224, "train")
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 3.0:
+            host_tf(Image.open(io.BytesIO(files[n % bsz])).convert("RGB"))
+            n += 1
+        t_one = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        m = 0
+        while time.perf_counter() - t0 < 2.0:
+            Image.open(io.BytesIO(files[m % bsz])).convert("RGB")
+            m += 1
+        t_dec = (time.perf_counter() - t0) / m
+        rec["cpu_baseline"] = {"value": round(1.0 / t_one, 1), "unit": "img/s", "cores": 1, "kind": "reference",
+                               "sample": f"{n} images: Pillow decode (libjpeg-turbo) + the host train transform on one core, the work of one of the "
+                                         "reference's loader workers (utils/dataloader.py:107-135 runs 8 of them)",
+                               "decode_only_img_per_s": round(1.0 / t_dec, 1)}
+    return rec
+
+
 def self_launch(n, argv):
     """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <argv>` as a child process (one rank
     per GPU, rendezvous on 127.0.0.1 at a free port), pass rank 0's single JSON line through and return the child's
@@ -710,6 +774,7 @@ def main():
         if world == 1:
             sec.append(retrieval_secondary(dev, d=768, with_cpu=False))  # ViT-L/14 embedding width
             sec.append(preprocess_secondary(dev))
+            sec.append(decode_secondary(dev, with_cpu=not args.no_cpu_baseline))
             sec += [finetune_secondary_subprocess(arch) for arch in ("ViT-B-16", "ViT-L-14")]
         if rank == 0:
             out["secondary"] = sec

@@ -346,6 +346,23 @@ int64_t swat_transformer_workspace_bytes(const int32_t* dims);
 int swat_transformer_forward(const int32_t* dims, const int64_t* offs, const float* params,
                              const void* shadow_bf16, float* x, void* workspace, swat_stream_t stream);
 
+/* §8(f).2, decode half (ref: `self.loader(path)` = PIL `Image.open(path).convert('RGB')` — utils/datasets/dataset_utils.py:130-180,
+ *     in 8 worker processes: utils/dataloader.py:107-135; retrieval/extract_mined_feature.py:103-117).  Baseline JPEG (SOF0, 8 bit,
+ *     1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals): Huffman entropy decode on host threads, dequantisation + libjpeg's
+ *     "islow" inverse DCT + fancy chroma upsampling + YCbCr -> RGB on the GPU, bytes identical to Pillow's, written in the layout
+ *     swat_preprocess_batch reads.
+ *     swat_jpeg_info           : width / height from the headers.  -> 0, 1 = not a file this path decodes (progressive, CMYK, other
+ *                                sampling, not a JPEG: the caller keeps such a file on Pillow), 2 = corrupt.
+ *     swat_jpeg_entropy_decode : the host half alone — quantised coefficient blocks, int16, natural order,
+ *                                [component][block row][block column][64], block grids padded to whole MCUs; dims (HOST int32[8]) = W, H,
+ *                                components, luma h, luma v, MCUs across, MCUs down, 0; coef_i16 may be null (dims only).
+ *     swat_jpeg_decode_batch   : files / nbytes / offsets / status are HOST arrays; pixels_u8 is DEVICE memory, image i (HWC RGB) at byte
+ *                                offsets[i]; status[i] = 0 decoded, 1 / 2 as above (nothing written).  threads <= 0: chosen by the library. */
+int swat_jpeg_info(const void* file, int64_t nbytes, int32_t* width, int32_t* height);
+int swat_jpeg_entropy_decode(const void* file, int64_t nbytes, int32_t* dims, void* coef_i16, int64_t coef_capacity);
+int swat_jpeg_decode_batch(const void* const* files, const int64_t* nbytes, int n, void* pixels_u8, const int64_t* offsets,
+                           int32_t* status, int threads, swat_stream_t stream);
+
 /* §8(f).2  Image side of the input pipeline (ref: utils/extras.py:66-85 `transform` = RandomResizedCrop(224, bicubic)
  *     + RandomHorizontalFlip + ToTensor + Normalize for training, Resize(224, bicubic) + CenterCrop + ToTensor +
  *     Normalize for validation; applied per sample at utils/datasets/dataset_utils.py:165-180).  Decoded RGB images go

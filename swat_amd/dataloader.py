@@ -10,7 +10,7 @@ import torch
 from torch.utils.data import DataLoader, Dataset
 
 from .features import extract_test_feats
-from .transforms import DecodeOnly, DeviceBatchTransform, build_transform
+from .transforms import DecodeOnly, DeviceBatchTransform, ReadOnly, build_transform
 
 
 def _pil_loader(path):
@@ -122,13 +122,24 @@ def _raw_collate(samples):
     return (imgs, geo), *default_collate([tuple(s[1:]) for s in samples])
 
 
+def _file_collate(samples):
+    """--gpu_decode: images stay a list of FILE byte arrays (+ geometry, + the (w, h, baseline) the worker read from the headers)"""
+    from torch.utils.data import default_collate
+    files = [s[0][0].numpy() for s in samples]
+    geo = [tuple(int(v) for v in s[0][1]) for s in samples]
+    sizes = [(int(s[0][2][0]), int(s[0][2][1])) if int(s[0][2][2]) else None for s in samples]
+    return (files, geo, sizes), *default_collate([tuple(s[1:]) for s in samples])
+
+
 class DeviceTransformLoader:
     """A DataLoader whose workers only decode (transform = DecodeOnly) and whose batches get crop / resize / flip /
     normalise on the GPU (`swat_preprocess_batch`) as they leave the iterator: yields the tuples the reference's loaders
     yield (utils/datasets/dataset_utils.py:165-180), with the image batch already on the device."""
 
-    def __init__(self, dataset, n_px, mode, device, **loader_kw):
-        self.loader = DataLoader(dataset, collate_fn=_raw_collate, **loader_kw)
+    def __init__(self, dataset, n_px, mode, device, decode=False, **loader_kw):
+        # decode: the workers hand over the image FILES (transform = ReadOnly) and the JPEG decode runs on host threads + the GPU too
+        self.decode = decode
+        self.loader = DataLoader(dataset, collate_fn=_file_collate if decode else _raw_collate, **loader_kw)
         self.dataset, self.batch_size = dataset, self.loader.batch_size
         self.tf = DeviceBatchTransform(n_px, mode, device)
 
@@ -136,6 +147,10 @@ class DeviceTransformLoader:
         return len(self.loader)
 
     def __iter__(self):
+        if self.decode:
+            for (files, geo, sizes), *rest in self.loader:
+                yield (self.tf.from_jpeg(files, geometry=geo, sizes=sizes), *rest)
+            return
         for (imgs, geo), *rest in self.loader:
             yield (self.tf(imgs, geometry=geo), *rest)
 
@@ -158,13 +173,17 @@ def get_dataloader(args, train_split, val_split, test_split, tokenized_text_prom
     if getattr(args, 'world', 1) > 1 and getattr(args, 'dp_weak', False):
         from .dp import RankStridedSampler
         train_kw = dict(sampler=RankStridedSampler(len(tr), args.rank, args.world))
-    if getattr(args, 'gpu_transform', False) and not getattr(args, 'synthetic', 0):
+    gpu_decode = getattr(args, 'gpu_decode', False)
+    if (getattr(args, 'gpu_transform', False) or gpu_decode) and not getattr(args, 'synthetic', 0):
         dev = getattr(args, 'device', 'cuda')
         for ds, mode in ((tr, 'train'), (va, 'val'), (te, 'val')):
-            ds.transform = DecodeOnly(224, mode)
-        train_loader = DeviceTransformLoader(tr, 224, 'train', dev, batch_size=args.bsz, drop_last=True, num_workers=args.num_workers, **train_kw)
-        val_loader = DeviceTransformLoader(va, 224, 'val', dev, batch_size=128, drop_last=False, shuffle=False, num_workers=args.num_workers)
-        test_loader = DeviceTransformLoader(te, 224, 'val', dev, batch_size=256, drop_last=False, shuffle=False, num_workers=args.num_workers)
+            if gpu_decode:   # workers read files; decode + transform on the GPU (same draws, same order: the geometry needs only (w, h))
+                ds.loader, ds.transform = ReadOnly.load, ReadOnly(224, mode)
+            else:
+                ds.transform = DecodeOnly(224, mode)
+        train_loader = DeviceTransformLoader(tr, 224, 'train', dev, decode=gpu_decode, batch_size=args.bsz, drop_last=True, num_workers=args.num_workers, **train_kw)
+        val_loader = DeviceTransformLoader(va, 224, 'val', dev, decode=gpu_decode, batch_size=128, drop_last=False, shuffle=False, num_workers=args.num_workers)
+        test_loader = DeviceTransformLoader(te, 224, 'val', dev, decode=gpu_decode, batch_size=256, drop_last=False, shuffle=False, num_workers=args.num_workers)
         return train_loader, val_loader, test_loader
     train_loader = DataLoader(tr, batch_size=args.bsz, pin_memory=True, drop_last=True, num_workers=args.num_workers, **train_kw)
     val_loader = DataLoader(va, batch_size=128, drop_last=False, pin_memory=True, shuffle=False, num_workers=args.num_workers)

@@ -72,6 +72,9 @@ def build_parser():
     p.add_argument('--num_workers', type=int, default=8)
     p.add_argument('--gpu_transform', action='store_true',
                    help='loader workers only decode; crop / bicubic resize / flip / normalise run on the GPU per batch (bit-exact)')
+    p.add_argument('--gpu_decode', action='store_true',
+                   help='implies --gpu_transform; loader workers only READ the image files: baseline JPEGs are entropy-decoded on host threads and '
+                        'dequantised / inverse-DCT-ed / upsampled / colour-converted on the GPU (bytes identical to Pillow), other files fall back to Pillow')
     p.add_argument('--start_validation', type=int, default=0)
     p.add_argument('--lr_classifier', type=float, default=1e-4)
     p.add_argument('--lr_backbone', type=float, default=1e-6)

@@ -91,6 +91,33 @@ class DecodeOnly:
         return torch.from_numpy(a), torch.tensor(sample_geometry(self.n_px, self.mode, a.shape[1], a.shape[0]), dtype=torch.int32)
 
 
+class ReadOnly:
+    """Worker-side half of GPU decode + transform (--gpu_decode): the worker only READS the file and draws this sample's geometry from
+    the image size in its headers; `DeviceBatchTransform.from_jpeg` decodes (host threads + GPU) and transforms the collated batch.
+    Used as the dataset's `loader` AND `transform`: loader(path) -> file bytes, transform(bytes) -> (uint8 [n] tensor, geometry, (w, h)).
+    A file the GPU path does not decode (progressive, CMYK, PNG ...) is sized through Pillow here and decoded by Pillow there."""
+
+    def __init__(self, n_px, mode='train'):
+        self.n_px, self.mode = n_px, mode
+
+    @staticmethod
+    def load(path):
+        with open(path, 'rb') as f:
+            return f.read()
+
+    def __call__(self, data):
+        from . import jpeg
+        wh = jpeg.info(data)
+        known = wh is not None
+        if not known:
+            import io
+            from PIL import Image
+            wh = Image.open(io.BytesIO(data)).size
+        geo = sample_geometry(self.n_px, self.mode, wh[0], wh[1])
+        return (torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()), torch.tensor(geo, dtype=torch.int32),
+                torch.tensor([wh[0], wh[1], int(known)], dtype=torch.int32))
+
+
 class DeviceBatchTransform:
     """The same two transforms for a whole batch of decoded images on the GPU (include/swat_hip.h
     `swat_preprocess_batch`): crop + antialiased bicubic resize + flip + ToTensor + Normalize in three launches, bit for
@@ -114,6 +141,46 @@ class DeviceBatchTransform:
     def geometry(self, w, h):
         """-> (x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip) for one image; draws from torch's CPU generator"""
         return sample_geometry(self.n_px, self.mode, w, h)
+
+    def from_jpeg(self, files, geometry=None, sizes=None, stream=None, threads=0):
+        """files: the image FILES (bytes / uint8 arrays).  Decode on host threads + GPU (swat_amd/jpeg.py: bytes identical to
+        Pillow's `convert('RGB')`), then the same three transform launches on the decoded bytes where they already are — the pixels
+        never visit the host.  geometry as for __call__ (drawn here, from (w, h), when not given)."""
+        from . import jpeg
+        dev = self.device
+        with torch.cuda.device(dev):
+            s = stream if stream is not None else torch.cuda.current_stream(dev)
+            pixels, offsets, shapes = jpeg.decode_batch(files, dev, sizes=sizes, threads=threads, stream=s, tail_bytes=8)
+            B, n = len(shapes), self.n_px
+            if B == 0:
+                return torch.empty(0, 3, n, n, device=dev)
+            desc = np.zeros((B, 12), np.int32)
+            row_start = np.zeros(B + 1, np.int64)
+            ks = 5
+            for b, (h, w) in enumerate(shapes):
+                g = geometry[b] if geometry is not None else self.geometry(w, h)
+                x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip = g
+                if not (0 <= x0 and 0 <= y0 and 0 < in_w and 0 < in_h and x0 + in_w <= w and y0 + in_h <= h
+                        and 0 <= off_x and 0 <= off_y and off_x + n <= out_w and off_y + n <= out_h):
+                    raise ValueError(f"image {b}: geometry {g} does not fit a {w} x {h} image / a {n}-pixel window")
+                desc[b] = (w, h, x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip, 0)
+                row_start[b + 1] = row_start[b] + in_h
+                ks = max(ks, _axis_ksize(in_w, out_w), _axis_ksize(in_h, out_h))
+            meta = torch.from_numpy(np.concatenate([offsets, row_start, desc.reshape(-1).view(np.int64)]))
+            lib, ptr = self._lib.lib(), self._lib.ptr
+            with torch.cuda.stream(s):
+                m = meta.to(dev)   # (small: 8 (2 B + 1) + 48 B bytes)
+                need = lib.swat_preprocess_workspace_bytes(B, n, ks, int(row_start[-1]))
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
+                out = torch.empty(B, 3, n, n, dtype=torch.float32, device=dev)
+                mp = m.data_ptr()
+                self._lib.check(lib.swat_preprocess_batch(ptr(pixels), mp, mp + 8 * (2 * B + 1), mp + 8 * B, ptr(self._lut), ptr(out), B, n,
+                                                          int(desc[:, 4].max()), int(desc[:, 5].max()), ks, ptr(self._ws),
+                                                          self._ws.numel(), s.cuda_stream), "swat_preprocess_batch")
+                pixels.record_stream(s)
+                m.record_stream(s)
+        return out
 
     def __call__(self, images, geometry=None, stream=None):
         """images: PIL images or uint8 [H, W, 3] arrays.  geometry: optional per-image tuples as `geometry()` returns."""

@@ -1,0 +1,101 @@
+"""GPU: baseline-JPEG decode (host Huffman + HIP dequantise / inverse DCT / upsample / colour: csrc/jpeg.hip) against Pillow — every
+byte — and through the loaders (--gpu_decode) against the reference-shaped loader whose workers run Pillow.
+ref: utils/datasets/dataset_utils.py:130-180, utils/dataloader.py:107-135."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from tests.test_oracle_jpeg import CASES, jpeg_bytes, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_decode_batch_equals_pillow_byte_for_byte():
+    from oracle import jpeg_oracle as jo
+    from swat_amd import jpeg
+    rng = np.random.default_rng(5)
+    files, want = [], []
+    for h, w, sub, q, rst in CASES + [(375, 500, 2, 90, 0), (500, 375, 1, 75, 5), (224, 224, 0, 100, 0), (257, 1000, 2, 60, 0)]:
+        files.append(jpeg_bytes(synth(rng, h, w), q, sub, rst))
+        want.append(np.asarray(Image.open(io.BytesIO(files[-1])).convert("RGB")))
+    files.append(jpeg_bytes(synth(rng, 40, 30)[..., 0], 80))                      # grayscale
+    want.append(np.asarray(Image.open(io.BytesIO(files[-1])).convert("RGB")))
+    b = io.BytesIO()
+    Image.fromarray(synth(rng, 33, 44)).save(b, "JPEG", progressive=True)         # not baseline: decoded by Pillow, same buffer
+    files.append(b.getvalue())
+    want.append(np.asarray(Image.open(io.BytesIO(files[-1])).convert("RGB")))
+    b = io.BytesIO()
+    Image.fromarray(synth(rng, 21, 19)).save(b, "PNG")                            # not a JPEG at all
+    files.append(b.getvalue())
+    want.append(np.asarray(Image.open(io.BytesIO(files[-1])).convert("RGB")))
+    assert np.array_equal(jo.decode(files[3]), want[3])                            # (the oracle is the checker, spot-checked here too)
+    for threads in (1, 4):
+        pixels, offsets, shapes = jpeg.decode_batch(files, "cuda:0", threads=threads)
+        host = pixels.cpu().numpy()
+        for i, w_ in enumerate(want):
+            h, w = shapes[i]
+            assert (h, w) == w_.shape[:2]
+            got = host[offsets[i]:offsets[i] + 3 * h * w].reshape(h, w, 3)
+            assert np.array_equal(got, w_), (i, threads, np.abs(got.astype(int) - w_.astype(int)).max())
+    one = jpeg.decode(files[10], "cuda:0")
+    assert np.array_equal(one.cpu().numpy(), want[10])
+
+
+def test_decode_feeds_the_device_transform_like_pillow_does():
+    """DeviceBatchTransform.from_jpeg (files -> decode on the GPU -> crop / bicubic resize / flip / normalise where the bytes already
+    are) gives the batch that decoding with Pillow and transforming with __call__ gives, bit for bit."""
+    from swat_amd import transforms as T
+    rng = np.random.default_rng(6)
+    files = [jpeg_bytes(synth(rng, int(rng.integers(100, 420)), int(rng.integers(100, 420))), int(rng.integers(50, 96)), int(rng.integers(0, 3)))
+             for _ in range(9)]
+    imgs = [Image.open(io.BytesIO(f)).convert("RGB") for f in files]
+    for mode in ("train", "val"):
+        tf = T.DeviceBatchTransform(224, mode, "cuda:0")
+        torch.manual_seed(8)
+        geo = [tf.geometry(*im.size) for im in imgs]
+        want = tf(imgs, geometry=geo)
+        got = tf.from_jpeg(files, geometry=geo)
+        assert torch.equal(got, want)
+        torch.manual_seed(8)
+        assert torch.equal(tf.from_jpeg(files), want)    # geometry drawn inside, from the header sizes: the same draws
+
+
+def test_loader_with_gpu_decode_matches_host_loader(tmp_path):
+    """real JPEG files (+ one PNG, one progressive JPEG), workers that only read them, decode + transform on the GPU: the batches of
+    the reference-shaped loader whose workers decode and transform with Pillow"""
+    from types import SimpleNamespace
+    from swat_amd import dataloader as dl, transforms as T
+    rng = np.random.default_rng(22)
+    os.makedirs(tmp_path / "img")
+    lines = []
+    for i in range(12):
+        h, w = int(rng.integers(120, 400)), int(rng.integers(120, 400))
+        name = f"img/{i}.jpg" if i != 7 else f"img/{i}.png"
+        if i == 7:
+            Image.fromarray(synth(rng, h, w)).save(tmp_path / name)
+        else:
+            Image.fromarray(synth(rng, h, w)).save(tmp_path / name, "JPEG", quality=int(rng.integers(60, 96)), subsampling=int(rng.integers(0, 3)),
+                                                   progressive=(i == 3))
+        lines.append(f"{name} {i % 3} {i % 2}\n")
+    (tmp_path / "split.txt").write_text("".join(lines))
+    split = [["split.txt"], [str(tmp_path)]]
+    args = SimpleNamespace(dataset_root=str(tmp_path), bsz=4, num_workers=0, device="cuda:0", gpu_transform=False, gpu_decode=False)
+    val_tf = T.build_transform(224, "val")
+    torch.manual_seed(3)
+    want = [list(l) for l in dl.get_dataloader(args, split, split, split, None, val_tf)]
+    args.gpu_decode = True
+    torch.manual_seed(3)
+    loaders = dl.get_dataloader(args, split, split, split, None, val_tf)
+    assert all(isinstance(l, dl.DeviceTransformLoader) and l.decode for l in loaders)
+    got = [list(l) for l in loaders]
+    for lw, lg in zip(want, got):
+        assert len(lw) == len(lg) > 0
+        for bw, bg in zip(lw, lg):
+            assert bg[0].is_cuda and torch.equal(bg[0].cpu(), bw[0])
+            assert all(torch.equal(a, b) for a, b in zip(bg[1:], bw[1:]))
+    args.num_workers = 2
+    assert all(torch.equal(a[0].cpu(), b[0]) for a, b in zip(dl.get_dataloader(args, split, split, split, None, val_tf)[1], want[1]))

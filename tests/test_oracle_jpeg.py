@@ -1,0 +1,72 @@
+"""CPU: the JPEG oracle (oracle/jpeg_oracle.py — libjpeg's baseline decode restated in numpy) against Pillow itself, and the host half
+of the product's decoder (swat_jpeg_info / swat_jpeg_entropy_decode: marker parse + Huffman entropy decode in C++, no GPU involved)
+against the oracle's coefficient blocks.  ref: `Image.open(path).convert('RGB')`, utils/datasets/dataset_utils.py:130-180."""
+import ctypes
+import io
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import jpeg_oracle as jo
+
+CASES = [(h, w, sub, q, rst) for (h, w) in ((16, 16), (37, 53), (75, 100), (9, 7), (1, 1), (33, 17)) for sub in (0, 1, 2)
+         for q, rst in ((30, 0), (85, 2), (95, 0))]
+
+
+def synth(rng, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.stack([128 + 100 * np.sin(xx / 7.0 + yy / 11.0), 128 + 90 * np.cos(xx / 5.0 - yy / 3.0), (xx * 3 + yy * 5) % 256], -1)
+    return np.clip(a + rng.normal(0, 12, a.shape), 0, 255).astype(np.uint8)
+
+
+def jpeg_bytes(a, q=85, sub=2, rst=0, **kw):
+    b = io.BytesIO()
+    if rst:
+        kw["restart_marker_blocks"] = rst
+    Image.fromarray(a).save(b, "JPEG", quality=q, subsampling=sub, **kw) if a.ndim == 3 else Image.fromarray(a).save(b, "JPEG", quality=q, **kw)
+    return b.getvalue()
+
+
+def test_oracle_decodes_what_pillow_decodes():
+    """4:4:4 / 4:2:2 / 4:2:0, odd sizes down to one pixel, three qualities, restart markers, grayscale: every byte equal."""
+    rng = np.random.default_rng(0)
+    for h, w, sub, q, rst in CASES:
+        data = jpeg_bytes(synth(rng, h, w), q, sub, rst)
+        want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        assert np.array_equal(jo.decode(data), want), (h, w, sub, q, rst)
+    data = jpeg_bytes(synth(rng, 40, 30)[..., 0], 80)
+    assert np.array_equal(jo.decode(data), np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
+    with pytest.raises(jo.Unsupported):
+        b = io.BytesIO()
+        Image.fromarray(synth(rng, 20, 20)).save(b, "JPEG", progressive=True)
+        jo.decode(b.getvalue())
+
+
+def test_host_entropy_decode_matches_the_oracle():
+    """swat_jpeg_entropy_decode (C++, host): quantised coefficient blocks [component][block row][block column][64] in natural order
+    equal the oracle's for every case; swat_jpeg_info reads the size; progressive / non-JPEG files are reported as 'not ours' (1)."""
+    from swat_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    for h, w, sub, q, rst in CASES + [(375, 500, 2, 90, 0)]:
+        data = jpeg_bytes(synth(rng, h, w), q, sub, rst)
+        buf = np.frombuffer(data, np.uint8)
+        W, H = ctypes.c_int32(), ctypes.c_int32()
+        assert L.swat_jpeg_info(buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.byref(W), ctypes.byref(H)) == 0
+        assert (W.value, H.value) == (w, h)
+        dims = (ctypes.c_int32 * 8)()
+        assert L.swat_jpeg_entropy_decode(buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.cast(dims, ctypes.c_void_p), None, 0) == 0
+        want = jo.coefficients(jo.parse(data))
+        flat = np.concatenate([x.reshape(-1) for x in want])
+        got = np.full(flat.size, 12345, np.int16)
+        assert L.swat_jpeg_entropy_decode(buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.cast(dims, ctypes.c_void_p),
+                                          got.ctypes.data_as(ctypes.c_void_p), got.size) == 0
+        assert list(dims)[:5] == [w, h, 3, (2 if sub else 1), (2 if sub == 2 else 1)]
+        assert np.array_equal(got, flat), (h, w, sub, q, rst)
+    b = io.BytesIO()
+    Image.fromarray(synth(rng, 20, 20)).save(b, "JPEG", progressive=True)
+    for blob in (b.getvalue(), b"not a jpeg at all", b"\xff\xd8\xff"):
+        a = np.frombuffer(blob, np.uint8)
+        W, H = ctypes.c_int32(), ctypes.c_int32()
+        assert L.swat_jpeg_info(a.ctypes.data_as(ctypes.c_void_p), a.size, ctypes.byref(W), ctypes.byref(H)) in (1, 2)

@@ -774,7 +774,7 @@ def main():
         if world == 1:
             sec.append(retrieval_secondary(dev, d=768, with_cpu=False))  # ViT-L/14 embedding width
             sec.append(preprocess_secondary(dev))
-            sec.append(decode_secondary(dev, with_cpu=not args.no_cpu_baseline))
+            sec.append(decode_secondary(dev, with_cpu=with_cpu))
             sec += [finetune_secondary_subprocess(arch) for arch in ("ViT-B-16", "ViT-L-14")]
         if rank == 0:
             out["secondary"] = sec

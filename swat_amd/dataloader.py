@@ -140,7 +140,7 @@ class DeviceTransformLoader:
         # decode: the workers hand over the image FILES (transform = ReadOnly) and the JPEG decode runs on host threads + the GPU too
         self.decode = decode
         self.loader = DataLoader(dataset, collate_fn=_file_collate if decode else _raw_collate, **loader_kw)
-        self.dataset, self.batch_size = dataset, self.loader.batch_size
+        self.dataset, self.batch_size, self.batch_sampler = dataset, self.loader.batch_size, self.loader.batch_sampler
         self.tf = DeviceBatchTransform(n_px, mode, device)
 
     def __len__(self):
@@ -169,10 +169,14 @@ def get_dataloader(args, train_split, val_split, test_split, tokenized_text_prom
         va = load_dataset(args.dataset_root, val_split, preprocess, tokenized_text_prompts)
         te = load_dataset(args.dataset_root, test_split, preprocess, tokenized_text_prompts)
     # data-parallel, --dp_weak: the shuffled epoch is dealt out by rank (swat_amd/dp.py); otherwise the reference's loader
-    train_kw = dict(shuffle=True)
+    train_kw = dict(shuffle=True, batch_size=args.bsz, drop_last=True)
     if getattr(args, 'world', 1) > 1 and getattr(args, 'dp_weak', False):
         from .dp import RankStridedSampler
-        train_kw = dict(sampler=RankStridedSampler(len(tr), args.rank, args.world))
+        train_kw = dict(sampler=RankStridedSampler(len(tr), args.rank, args.world), batch_size=args.bsz, drop_last=True)
+    elif getattr(args, 'world', 1) > 1 and not getattr(args, 'dp_full_load', False):
+        # global batch split over the ranks: each rank's loader yields its own rows (+ CutMix partners) only
+        from .dp import RankBatchSampler
+        train_kw = dict(batch_sampler=RankBatchSampler(len(tr), args.bsz, args.rank, args.world))
     gpu_decode = getattr(args, 'gpu_decode', False)
     if (getattr(args, 'gpu_transform', False) or gpu_decode) and not getattr(args, 'synthetic', 0):
         dev = getattr(args, 'device', 'cuda')
@@ -181,11 +185,11 @@ def get_dataloader(args, train_split, val_split, test_split, tokenized_text_prom
                 ds.loader, ds.transform = ReadOnly.load, ReadOnly(224, mode)
             else:
                 ds.transform = DecodeOnly(224, mode)
-        train_loader = DeviceTransformLoader(tr, 224, 'train', dev, decode=gpu_decode, batch_size=args.bsz, drop_last=True, num_workers=args.num_workers, **train_kw)
+        train_loader = DeviceTransformLoader(tr, 224, 'train', dev, decode=gpu_decode, num_workers=args.num_workers, **train_kw)
         val_loader = DeviceTransformLoader(va, 224, 'val', dev, decode=gpu_decode, batch_size=128, drop_last=False, shuffle=False, num_workers=args.num_workers)
         test_loader = DeviceTransformLoader(te, 224, 'val', dev, decode=gpu_decode, batch_size=256, drop_last=False, shuffle=False, num_workers=args.num_workers)
         return train_loader, val_loader, test_loader
-    train_loader = DataLoader(tr, batch_size=args.bsz, pin_memory=True, drop_last=True, num_workers=args.num_workers, **train_kw)
+    train_loader = DataLoader(tr, pin_memory=True, num_workers=args.num_workers, **train_kw)
     val_loader = DataLoader(va, batch_size=128, drop_last=False, pin_memory=True, shuffle=False, num_workers=args.num_workers)
     test_loader = DataLoader(te, batch_size=256, drop_last=False, pin_memory=True, shuffle=False, num_workers=args.num_workers)
     return train_loader, val_loader, test_loader

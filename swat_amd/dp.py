@@ -3,11 +3,13 @@
 
 The reference trains on one GPU (utils/training.py:1452-1489, loaders utils/dataloader.py:107-135).  Two ways to spread it:
 
-* global batch (default): the job's batch stays `--bsz`; every rank iterates the SAME loader (same seed, RNG states
-  re-synchronised from rank 0 at the start of every training loop) and takes rows [rank*b, (rank+1)*b) of each batch.
-  The CutMix scalars (r, lambda, box) and the permutation are the single-process draws; a row's CutMix partner is taken
-  from the rank's own copy of the whole batch.  Per-rank mean losses averaged over ranks = the whole-batch mean, so the
-  optimizer trajectory is the single-process one up to the summation order of the gradient reduction.
+* global batch (default): the job's batch stays `--bsz`; every rank draws the SAME shuffles and CutMix decisions (same seed, RNG
+  states re-synchronised from rank 0 at the start of every training loop) and works on rows [rank*b, (rank+1)*b) of each batch.
+  Its loader yields those rows and, in a CutMix iteration, the b partner rows they are pasted from — nothing else is read or
+  decoded (RankBatchSampler below; `--dp_full_load` restores the round-3 form in which every rank loaded the whole batch and
+  sliced it, shard_batch).  The CutMix scalars (r, lambda, box) and the permutation are the single-process draws.  Per-rank mean
+  losses averaged over ranks = the whole-batch mean, so the optimizer trajectory is the single-process one up to the summation
+  order of the gradient reduction.
 * `--dp_weak`: every rank loads its own `--bsz` rows per step (global batch = world x bsz): the sampler deals the
   shuffled index list out by rank (same permutation on every rank), CutMix permutes inside the rank's batch.
 
@@ -50,9 +52,9 @@ def init_from_env(args, split_batch=True):
     per = getattr(args, 'bsz', 0) // world
     if split_batch and not getattr(args, 'dp_weak', False) and 0 < per < 16 and rank == 0:
         import warnings
-        warnings.warn(f"--bsz {args.bsz} over {world} ranks leaves {per} images per GPU and step (every rank still loads and "
-                      f"decodes the whole batch to keep the single-process trajectory): this mode reproduces a 1-GPU run, it does "
-                      f"not speed it up.  Use --dp_weak (every rank loads its own --bsz images, global batch {world} x {args.bsz}) to scale.")
+        warnings.warn(f"--bsz {args.bsz} over {world} ranks leaves {per} images per GPU and step: this mode reproduces the 1-GPU "
+                      f"trajectory of the reference's batch size; a step that small is launch-bound on every rank.  Use --dp_weak "
+                      f"(every rank its own --bsz images, global batch {world} x {args.bsz}) to scale throughput.")
     return args
 
 
@@ -136,6 +138,59 @@ class RankStridedSampler(Sampler):
     def __iter__(self):
         order = torch.randperm(self.n).tolist() if self.shuffle else list(range(self.n))
         return iter(order[self.rank:self.n // self.nranks * self.nranks:self.nranks])
+
+
+class RankBatchSampler(Sampler):
+    """Global-batch mode without W-fold loading: rank r loads ONLY rows [r b, (r + 1) b) of every global batch, plus — in a CutMix
+    iteration — the b partner rows its own rows are pasted from.  (Round 3: every rank iterated the whole loader and decoded all
+    W b images of every batch to keep the single-process trajectory; at 8 ranks that is 8x the decode work for the same job.)
+
+    How the single-process trajectory survives.  The batch composition is the reference loader's: `RandomSampler`'s permutation
+    (drawn here exactly as torch draws it: a seed from the global generator, randperm on a private generator), cut into batches of
+    `bsz`, tail dropped.  The CutMix decisions of iteration i (np.random.rand, np.random.beta, torch.randperm(bsz), rand_bbox's two
+    np.random.randint: ref utils/training.py:1458-1472) are drawn HERE, when batch i's indices are handed to the DataLoader, in the
+    same per-stream order as the training loop draws them in a single process, and queued for the loop (`pop_draw`).  The draws thus
+    happen earlier in wall time, not in another order — the streams are the single-process streams as long as nothing else in the MAIN
+    process draws from torch's / numpy's global generators during an epoch: loader workers (the reference's default, 8) have their own
+    generators, `--synthetic` items are seeded per item.  With `--num_workers 0` on real files the dataset's crop / flip draws share
+    torch's global generator with randperm(bsz): the job is then still a correct run of the same recipe, but not stream-identical to a
+    1-process run.
+    Yields index lists of length b (no CutMix in this iteration) or 2 b (own rows, then partner rows)."""
+
+    def __init__(self, n, bsz, rank, nranks, img_hw=(224, 224)):
+        if bsz % nranks:
+            raise ValueError(f"--bsz {bsz} must be a multiple of the world size {nranks}")
+        self.n, self.bsz, self.rank, self.nranks, self.img_hw = n, bsz, rank, nranks, img_hw
+        self.b = bsz // nranks
+        self.draw_fn = None          # training.cutmix_draw bound to args (set by the loop: configure)
+        self.draws = []
+
+    def configure(self, draw_fn):
+        """draw_fn(size) -> (lam, rand_index | None, box | None): the loop's per-iteration CutMix draws (None: no CutMix at all)"""
+        self.draw_fn = draw_fn
+        self.draws = []
+
+    def pop_draw(self):
+        return self.draws.pop(0)
+
+    def __len__(self):
+        return self.n // self.bsz
+
+    def __iter__(self):
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())      # torch.utils.data.RandomSampler.__iter__, verbatim order
+        g = torch.Generator()
+        g.manual_seed(seed)
+        order = torch.randperm(self.n, generator=g).tolist()
+        lo, hi = self.rank * self.b, (self.rank + 1) * self.b
+        for i in range(self.n // self.bsz):
+            batch = order[i * self.bsz:(i + 1) * self.bsz]
+            lam, perm, box = self.draw_fn((self.bsz, 3) + tuple(self.img_hw)) if self.draw_fn is not None else (1.0, None, None)
+            self.draws.append((lam, perm, box))
+            own = batch[lo:hi]
+            if perm is None:
+                yield own
+            else:
+                yield own + [batch[j] for j in perm[lo:hi].tolist()]
 
 
 class _NullLog:

@@ -72,6 +72,9 @@ def build_parser():
     p.add_argument('--num_workers', type=int, default=8)
     p.add_argument('--gpu_transform', action='store_true',
                    help='loader workers only decode; crop / bicubic resize / flip / normalise run on the GPU per batch (bit-exact)')
+    p.add_argument('--dp_full_load', action='store_true',
+                   help='data-parallel global-batch mode: every rank loads the WHOLE --bsz batch and slices its rows (the round-3 behaviour); '
+                        'default: a rank-aware sampler loads only the rank\'s rows and their CutMix partners')
     p.add_argument('--gpu_decode', action='store_true',
                    help='implies --gpu_transform; loader workers only READ the image files: baseline JPEGs are entropy-decoded on host threads and '
                         'dequantised / inverse-DCT-ed / upsampled / colour-converted on the GPU (bytes identical to Pillow), other files fall back to Pillow')

@@ -83,6 +83,13 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
     split_batch = nranks > 1 and not getattr(args, 'dp_weak', False)  # every rank sees the whole --bsz batch, takes its rows
     dp.sync_rng(args)  # identical shuffles and CutMix draws on every rank from here on
     step = FusedTrainStep(model, classifier_head, logit_scale, optimizer, world_size=nranks)
+    # global-batch data parallelism with a rank-aware loader (swat_amd/dp.py RankBatchSampler): this rank's loader yields only its
+    # rows (+ its CutMix partners), the iteration's CutMix draws were made by the sampler and are popped here
+    rank_sampler = getattr(getattr(train_loader, 'loader', train_loader), 'batch_sampler', None)
+    if not isinstance(rank_sampler, dp.RankBatchSampler):
+        rank_sampler = None
+    if rank_sampler is not None:
+        rank_sampler.configure((lambda size: cutmix_draw(args, size)) if use_cutmix else None)
 
     val_loss = -1
     val_acc = -1
@@ -100,6 +107,15 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
             num_iter += 1
             images = inputs.to(args.device, non_blocking=True)
             labels = labels.to(args.device, non_blocking=True).long()
+            if rank_sampler is not None:
+                lam, rand_index, box = rank_sampler.pop_draw()
+                b = rank_sampler.b
+                if rand_index is not None:   # rows b .. 2b - 1 are the partners of rows 0 .. b - 1
+                    step(images, labels[:b], labels[b:2 * b], lam, perm=torch.arange(b, 2 * b, device=args.device), box=box, batch=b)
+                else:
+                    step(images, labels, labels, 1.0)
+                scheduler.step()
+                continue
             if use_cutmix:
                 lam, rand_index, box = cutmix_draw(args, images.size())
             else:

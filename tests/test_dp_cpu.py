@@ -142,3 +142,58 @@ def test_single_process_is_untouched():
     y = torch.arange(4)
     loc, ya, yb, pl, b = dp.shard_batch(x, y, None, 0, 1)
     assert b == 4 and torch.equal(loc, x) and pl is None
+
+
+def test_rank_batch_sampler_yields_the_single_process_batches_rank_by_rank():
+    """dp.RankBatchSampler (global-batch data parallelism without W-fold loading): with the ranks' RNG states equal, the rows each rank
+    loads are its slice of the batches a single process gets from DataLoader(shuffle=True, drop_last=True), its partner rows are the
+    single process's CutMix partners of those rows, and the queued (lambda, permutation, box) draws are the single process's draws —
+    over two epochs, CutMix on (mix_prob 0.5: iterations with and without a paste) and off."""
+    import types
+    import numpy as np
+    from torch.utils.data import DataLoader, Dataset
+    from swat_amd import dp, training
+
+    class Ids(Dataset):
+        def __len__(self):
+            return 53
+
+        def __getitem__(self, i):
+            return i
+
+    args = types.SimpleNamespace(cutmix_beta=1.0, mix_prob=0.5)
+    n, bsz, world = 53, 12, 3
+
+    def seed():
+        torch.manual_seed(11)
+        np.random.seed(11)
+
+    for use_cutmix in (True, False):
+        seed()
+        single = []          # (batch indices, lam, perm, box) per iteration of the 1-process loop
+        for epoch in range(2):
+            for batch in DataLoader(Ids(), batch_size=bsz, shuffle=True, drop_last=True):
+                lam, perm, box = training.cutmix_draw(args, (bsz, 3, 224, 224)) if use_cutmix else (1.0, None, None)
+                single.append((batch.tolist(), lam, perm, box))
+        assert len(single) == 2 * (n // bsz)
+        for rank in range(world):
+            seed()
+            sampler = dp.RankBatchSampler(n, bsz, rank, world)
+            sampler.configure((lambda size: training.cutmix_draw(args, size)) if use_cutmix else None)
+            loader = DataLoader(Ids(), batch_sampler=sampler)
+            assert len(loader) == n // bsz
+            it = 0
+            for epoch in range(2):
+                for rows in loader:
+                    lam, perm, box = sampler.pop_draw()
+                    b_idx, s_lam, s_perm, s_box = single[it]
+                    b = bsz // world
+                    assert lam == s_lam and box == s_box and (perm is None) == (s_perm is None)
+                    own = b_idx[rank * b:(rank + 1) * b]
+                    if perm is None:
+                        assert rows.tolist() == own
+                    else:
+                        assert torch.equal(perm, s_perm)
+                        assert rows.tolist() == own + [b_idx[j] for j in s_perm[rank * b:(rank + 1) * b].tolist()]
+                    it += 1
+            assert it == len(single) and sampler.draws == []

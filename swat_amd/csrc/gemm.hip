@@ -859,7 +859,10 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
         }
         tile = layout == L_TN ? 50 : (a.K % 64 == 0 ? 14 : 20);
     }
-    if (tile == 80 && (layout == L_TN || batch != 1 || a.inner != 1 || a.K % 64 != 0 || a.K < 128 || a.lda % 8 || a.ldb % 8)) tile = layout == L_TN ? 50 : 14;
+    // (the 256 x 256 kernel forms its per-thread operand offsets in 32 bits: the whole operands must stay below 4 GiB)
+    if (tile == 80 && (layout == L_TN || batch != 1 || a.inner != 1 || a.K % 64 != 0 || a.K < 128 || a.lda % 8 || a.ldb % 8 ||
+                       (int64_t)a.M * a.lda * 2 >= (1ll << 32) || (int64_t)(layout == L_NT ? a.N : a.K) * a.ldb * 2 >= (1ll << 32)))
+        tile = layout == L_TN ? 50 : 14;
     if (tile == 80) rc = launch_gemm_big(layout, a, s, ev0, ev1);  // 256 x 256, matrix-core bound (gemm_big.hip)
     else if (tile >= 70 && tile <= 72 && batch == 1 && a.inner == 1) rc = launch_gemm_pc_group(layout, &a, 1, s, ev0, ev1, tile);  // persistent tile loop
     else if (tile >= 70) { set_error("gemm: persistent configuration %d needs one unbatched product", tile); rc = -1; }

@@ -138,17 +138,25 @@ __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __re
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= B) return;
     const float* zr = z + (int64_t)row * C;
+    // torch.argmax's order: a NaN is greater than everything, ties (and several NaNs) go to the lower index — diverged logits must
+    // give the predictions and the confusion matrix the host path gave (round-3 advisor finding: the shuffle reduce dropped NaNs)
+    auto better = [](float v, int c, float b, int a) {
+        const bool vn = v != v, bn = b != b;
+        if (vn != bn) return vn;
+        if (vn) return c < a;
+        return v > b || (v == b && c < a);
+    };
     float best = -INFINITY;
     int arg = 0x7fffffff;
     for (int c = lane; c < C; c += 64) {
         const float v = zr[c];
-        if (v > best || (v == best && c < arg) || arg == 0x7fffffff) { best = v; arg = c; }  // NaN rows: first index, like a plain scan
+        if (arg == 0x7fffffff || better(v, c, best, arg)) { best = v; arg = c; }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oa = __shfl_xor(arg, o, 64);
-        if (ov > best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+        if (oa != 0x7fffffff && (arg == 0x7fffffff || better(ov, oa, best, arg))) { best = ov; arg = oa; }
     }
     if (lane == 0) {
         if (arg == 0x7fffffff) arg = 0;

@@ -24,11 +24,11 @@ def merge_topk(idx_list, val_list, k):
     """idx/val per shard: [n_seg, k] (global rows, -1 padded / -inf), shards in rank order -> the k best of every
     query by (value desc, global row asc) — the reference's stable sorted(reverse=True) order, since rows of a lower
     rank are lower global rows.  On the GPU: swat_merge_topk_lists (the library's own bitonic top-k over the packed
-    (value, ~row) keys).  CPU tensors (the gloo tests of the merge bookkeeping) use a stable descending sort — the same
-    order by construction; the data path never takes it (ShardedIndex / bench.py hold GPU tensors)."""
+    (value, ~row) keys) for up to 8 192 gathered entries per query.  CPU tensors (the gloo tests of the merge bookkeeping) and longer
+    rows (e.g. 8 ranks x k = 2 048) use a stable descending sort — the same order by construction."""
     idx = torch.cat(idx_list, dim=1).contiguous()
     val = torch.cat(val_list, dim=1).contiguous()
-    if idx.is_cuda:
+    if idx.is_cuda and idx.shape[1] <= 8192:   # (the library's merge sorts up to 8 192 keys per query; longer rows: the stable sort below)
         from .. import _lib
         L = _lib.lib()
         nq, m = idx.shape

@@ -405,6 +405,34 @@ def test_colsum_and_cast():
     assert torch.equal(ops.cast_bf16(Xf), Xf.to(BF))
 
 
+def test_argmax_confusion_follows_torch_argmax_on_ties_and_nans():
+    """swat_argmax_confusion (validate's device tail, ref testing.py:449-458): first index of the row maximum, NaN greater than
+    everything (several NaNs: the first), like torch.argmax — also on diverged logits."""
+    from swat_amd import _lib
+    L = _lib.lib()
+    B, C = 37, 203
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(B, C, generator=g)
+    z[1, 5] = z[1, 150] = z[1].max() + 1.0          # a tie across lanes: the lower index
+    z[2, 77] = float("nan")                          # one NaN
+    z[3, 190] = z[3, 66] = float("nan")              # two NaNs: the first
+    z[4, :] = float("nan")
+    z[5, 0] = float("inf"); z[5, 100] = float("nan")
+    y = torch.randint(0, C, (B,), generator=g)
+    zd, yd = z.to(dev()), y.to(dev())
+    pred = torch.empty(B, dtype=torch.int64, device=dev())
+    conf = torch.zeros(C, C, dtype=torch.int64, device=dev())
+    correct = torch.zeros(1, dtype=torch.int64, device=dev())
+    _lib.check(L.swat_argmax_confusion(_lib.ptr(zd), _lib.ptr(yd), B, C, _lib.ptr(pred), None, _lib.ptr(conf), _lib.ptr(correct), _lib.stream()),
+               "swat_argmax_confusion")
+    want = torch.argmax(z, dim=1)
+    assert torch.equal(pred.cpu(), want)
+    ref = torch.zeros(C, C, dtype=torch.int64)
+    for a, b in zip(y.tolist(), want.tolist()):
+        ref[a, b] += 1
+    assert torch.equal(conf.cpu(), ref) and correct.item() == int((want == y).sum())
+
+
 def test_tail_kernels():
     from swat_amd import ops
     B, E, C = 32, 512, 200

@@ -488,6 +488,29 @@ def test_saved_index_shards_merge_to_the_single_gpu_answer(tmp_path, world):
     assert torch.equal(m_val[valid], w_val[valid])
 
 
+def test_shard_merge_of_more_than_8192_gathered_entries_per_query():
+    """8 ranks x k = 2 048 gathered entries per query are beyond the library merge's 8 192 keys: merge_topk takes its stable
+    descending sort there — the same lists as the library merge gives on the first 8 192 and as a host stable sort gives on all."""
+    from swat_amd.retrieval import shard
+    dev = _dev()
+    rs = np.random.RandomState(9)
+    nq, world, k = 5, 8, 2048
+    idxs, vals = [], []
+    for r in range(world):
+        v = np.sort(rs.randint(0, 400, size=(nq, k)).astype(np.float32) / 400.0, axis=1)[:, ::-1].copy()   # many exact ties
+        i = np.sort(rs.choice(100000, size=(nq, k), replace=False), axis=1) + r * 100000
+        i[:, -17:] = -1
+        v[:, -17:] = -np.inf
+        idxs.append(torch.from_numpy(i).to(dev))
+        vals.append(torch.from_numpy(v).to(dev))
+    m_idx, m_val, m_cnt = shard.merge_topk(idxs, vals, k)
+    c_idx, c_val, c_cnt = shard.merge_topk([i.cpu() for i in idxs], [v.cpu() for v in vals], k)
+    assert torch.equal(m_idx.cpu(), c_idx) and torch.equal(m_val.cpu(), c_val) and torch.equal(m_cnt.cpu(), c_cnt)
+    l_idx, l_val, l_cnt = shard.merge_topk(idxs[:4], vals[:4], k)       # 8 192 entries: the library merge
+    h_idx, h_val, h_cnt = shard.merge_topk([i.cpu() for i in idxs[:4]], [v.cpu() for v in vals[:4]], k)
+    assert torch.equal(l_idx.cpu(), h_idx) and torch.equal(l_cnt.cpu(), h_cnt)
+
+
 def _write_mined(root, case):
     os.makedirs(f"{root}/synthetic", exist_ok=True)
     torch.save({"image_features": torch.from_numpy(case["img"]), "caption_features": torch.from_numpy(case["cap"]),

@@ -57,6 +57,15 @@ int swat_vit_mega_launches(void);
 int swat_vit_mega_inject_failure(int launches, int handoff);
 /* Per-workgroup phase stamps of the next persistent forwards (64 x uint64 per workgroup, 100 MHz ticks); null = off. */
 int swat_vit_mega_trace(void* device_buffer);
+/* The data-gradient chain of the blocks' backward (swat_vit_backward with stage_hi >= L, stage_lo <= 1) as one persistent launch:
+ * 0 = op by op, 1 = persistent when eligible (default; env SWAT_VIT_MEGA_BWD).  _inject_failure / _trace: as the forward's. */
+int swat_vit_set_mega_backward(int mode);
+int swat_vit_mega_backward_inject_failure(int launches, int handoff);
+int swat_vit_mega_backward_launches(void);
+/* 1 when swat_vit_backward(dims, .., stage_hi >= L, stage_lo <= 1) would run the blocks as the persistent launch (shape and modes;
+ * the caller then makes that ONE call for all blocks instead of one per stage). */
+int swat_vit_backward_blocks_fused(const int32_t* dims);
+int swat_vit_mega_backward_trace(void* device_buffer);
 
 /* swat_adamw's launch shape: 0 = wide (up to 4096 blocks, the fastest alone), n > 0 = n blocks of 256 threads handling four
  *     16-byte quads per array and trip (n = 256: one block per CU, 4 of its 32 wave slots) so that GEMM workgroups on another

@@ -23,47 +23,6 @@ namespace swat {
 
 void launch_attn_fwd_tiled2(const unsigned short* qkv, unsigned short* out, float* lse, int B, int T, int d, int H, int causal, hipStream_t s);  // attention_tiled2.hip
 
-// S = Q K^T for the wave's 16 query rows, then the row softmax; returns P (fp32, already rounded through bf16) in s[][]
-__device__ __forceinline__ void scores_softmax(const unsigned short* base, int64_t ld, int d, int T, int wave, int r16, int g,
-                                               float scale, af32x4_t (&s)[4]) {
-    const int q = wave * 16 + r16, qq = q < T ? q : T - 1;
-    abf16x8_t qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(base + (int64_t)qq * ld + 32 * ks + 8 * g);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int key = 16 * j + r16, kk = key < T ? key : T - 1;
-        s[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(base + d + (int64_t)kk * ld + 32 * ks + 8 * g), qf[ks], s[j], 0, 0, 0);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int key = 16 * j + 4 * g + e;
-            s[j][e] = key < T ? s[j][e] * scale : -INFINITY;
-            mx = fmaxf(mx, s[j][e]);
-        }
-    mx = xor_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int key = 16 * j + 4 * g + e;
-            s[j][e] = key < T ? __expf(s[j][e] - mx) : 0.f;
-            sum += s[j][e];
-        }
-    const float inv = 1.0f / xor_sum(sum);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[j][e] = bf2f(f2bf(s[j][e] * inv));
-}
-
 __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
                                                              int T, int d, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned short vt[64 * ATP];

@@ -65,4 +65,45 @@ __device__ __forceinline__ void store4(unsigned short* p, const af32x4_t& v) {
     *reinterpret_cast<au32x2_t*>(p) = o;
 }
 
+// S = Q K^T for the wave's 16 query rows, then the row softmax; returns P (fp32, already rounded through bf16) in s[][]
+__device__ __forceinline__ void scores_softmax(const unsigned short* base, int64_t ld, int d, int T, int wave, int r16, int g,
+                                               float scale, af32x4_t (&s)[4]) {
+    const int q = wave * 16 + r16, qq = q < T ? q : T - 1;
+    abf16x8_t qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(base + (int64_t)qq * ld + 32 * ks + 8 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int key = 16 * j + r16, kk = key < T ? key : T - 1;
+        s[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(base + d + (int64_t)kk * ld + 32 * ks + 8 * g), qf[ks], s[j], 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * j + 4 * g + e;
+            s[j][e] = key < T ? s[j][e] * scale : -INFINITY;
+            mx = fmaxf(mx, s[j][e]);
+        }
+    mx = xor_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * j + 4 * g + e;
+            s[j][e] = key < T ? __expf(s[j][e] - mx) : 0.f;
+            sum += s[j][e];
+        }
+    const float inv = 1.0f / xor_sum(sum);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[j][e] = bf2f(f2bf(s[j][e] * inv));
+}
+
 }  // namespace swat

@@ -584,6 +584,61 @@ SWAT_API int swat_layernorm_bwd_partial(const float* dy, int64_t dy_stride, int 
     return check_launch("swat_layernorm_bwd_partial");
 }
 
+namespace swat {
+// the same reduction for up to 64 independent sets of partial sums in one launch: grid (ceil(d / 32), 3, sets)
+struct LnRedSets {
+    const float* part[64];
+    float* out[64][3];
+};
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_sets_kernel(const LnRedSets a, int nblk, int d) {
+    __shared__ float sh[32][33];
+    const int q = blockIdx.y, z = blockIdx.z;
+    float* out = a.out[z][q];
+    if (!out) return;
+    const float* part = a.part[z];
+    const int t = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + t;
+    float acc = 0.f;
+    if (c < d) {
+        int i = j;
+        for (; i + 7 * 32 < nblk; i += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[((int64_t)(i + 32 * u) * 3 + q) * d + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; i < nblk; i += 32) acc += part[((int64_t)i * 3 + q) * d + c];
+    }
+    sh[j][t] = acc;
+    __syncthreads();
+    if (j == 0 && c < d) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) v += sh[g][t];
+        out[c] = v;
+    }
+}
+// sets[i] = {part, dgamma, dbeta, dcolsum (may be null)}
+int ln_bwd_finish_sets(const float* const* part, float* const* dgamma, float* const* dbeta, float* const* dcolsum, int nsets, int nblk, int d,
+                       hipStream_t s) {
+    for (int z0 = 0; z0 < nsets; z0 += 64) {
+        LnRedSets a{};
+        const int n = nsets - z0 < 64 ? nsets - z0 : 64;
+        for (int i = 0; i < n; ++i) {
+            a.part[i] = part[z0 + i];
+            a.out[i][0] = dgamma[z0 + i]; a.out[i][1] = dbeta[z0 + i]; a.out[i][2] = dcolsum[z0 + i];
+        }
+        hipLaunchKernelGGL(ln_bwd_reduce_sets_kernel, dim3((d + 31) / 32, 3, n), dim3(1024), 0, s, a, nblk, d);
+    }
+    return check_launch("ln_bwd_finish_sets");
+}
+int ln_bwd_finish_blocks(const float* part, int nblk, int d, float* dgamma, float* dbeta, float* dcolsum, hipStream_t s) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 31) / 32, 3), dim3(1024), 0, s, part, nblk, d, dgamma, dbeta, dcolsum);
+    return check_launch("ln_bwd_finish_blocks");
+}
+}  // namespace swat
+
 SWAT_API int swat_layernorm_bwd_finish(const void* workspace, int rows, int d, float* dgamma, float* dbeta, float* dcolsum,
                                        swat_stream_t s) {
     if (rows <= 0) return 0;

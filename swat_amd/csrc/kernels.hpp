@@ -66,6 +66,22 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
                      unsigned short* h2, unsigned short* a, unsigned short* qkv, unsigned short* f, unsigned short* gact, float* mean1,
                      float* rstd1, float* mean2, float* rstd2, hipStream_t s);
 
+// data gradients + LayerNorm / attention backward of all blocks as one persistent launch (vit_mega.hip); same return values
+bool vit_mega_backward_fits(int B, int T, int d, int H, int mlp);   // shape only: the workspace carve
+bool vit_mega_backward_shape(int B, int T, int d, int H, int mlp, int L);   // shape + modes: will it run
+int64_t vit_mega_backward_lnp_bytes(int B, int d);
+int vit_mega_backward(int B, int T, int d, int H, int mlp, int L, int act, int M, int Mp, const float* params, const unsigned short* shadow,
+                      const int64_t* layer_offs, const float* xs, const float* x1, const unsigned short* qkv, const unsigned short* f,
+                      const float* mean1, const float* rstd1, const float* mean2, const float* rstd2, float* dx, unsigned short* dxb,
+                      unsigned short* dfb, unsigned short* dxb2, unsigned short* dqkv, float* dh2, float* dh1, float* lnp1, float* lnp2,
+                      hipStream_t s);
+
+// fixed-order reduction of `nblk` blocks [3][d] of LayerNorm-backward partial sums (elementwise.hip)
+int ln_bwd_finish_blocks(const float* part, int nblk, int d, float* dgamma, float* dbeta, float* dcolsum, hipStream_t s);
+// ... of `nsets` independent sets (same nblk, d) in one launch per 64 sets
+int ln_bwd_finish_sets(const float* const* part, float* const* dgamma, float* const* dbeta, float* const* dcolsum, int nsets, int nblk, int d,
+                       hipStream_t s);
+
 // device word that is non-zero while a persistent forward's give-up has not been read by the host (vit_mega.hip); null when no
 // persistent forward has run on the current device.  AdamW and the running loss sum skip their writes while it is set.
 const unsigned* mega_guard_word();

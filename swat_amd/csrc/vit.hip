@@ -84,6 +84,10 @@ struct VitWs {
     // output gradient, written for block l - 1 while block l + 1's lane work may still read its own: slot (l - 1) % 3 of three)
     unsigned short *dxb_r[3], *dxb2_r[2], *dfb_r[2], *dqkv_r[2];
     void *lnws1_r[2], *lnws2_r[2];
+    // persistent backward (csrc/vit_mega.hip), small batches of the B/32 shape only: every buffer that crosses workgroups is per block
+    unsigned short *mb_dxb, *mb_dfb, *mb_dxb2, *mb_dqkv;   // [L + 1 | L | L | L][Mp, d | mlp | d | 3d]
+    float *mb_dh2, *mb_dh1;                                // [L][4][M, d]
+    float *mb_lnp1, *mb_lnp2;                              // [L][panels * 16][3][d]
     void* csws;               // column-sum partials
     int64_t total;
 };
@@ -143,6 +147,17 @@ static VitWs carve(const VitDims& D, void* base) {
         w.dqkv_r[1] = (unsigned short*)take(Mp * 3 * d * 2);
         w.lnws1_r[1] = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
         w.lnws2_r[1] = take(swat_layernorm_bwd_workspace_bytes((int)M, (int)d));
+        if (vit_mega_backward_fits(D.B, D.T, D.d, D.H, D.mlp)) {
+            const int64_t L = D.L, lnp = vit_mega_backward_lnp_bytes(D.B, D.d);
+            w.mb_dxb = (unsigned short*)take((L + 1) * Mp * d * 2);
+            w.mb_dfb = (unsigned short*)take(L * Mp * D.mlp * 2);
+            w.mb_dxb2 = (unsigned short*)take(L * Mp * d * 2);
+            w.mb_dqkv = (unsigned short*)take(L * Mp * 3 * d * 2);
+            w.mb_dh2 = (float*)take(L * 4 * M * d * 4);   // four reduction quarters each
+            w.mb_dh1 = (float*)take(L * 4 * M * d * 4);
+            w.mb_lnp1 = (float*)take(L * lnp);
+            w.mb_lnp2 = (float*)take(L * lnp);
+        }
     }
     w.total = off;
     return w;
@@ -504,6 +519,16 @@ SWAT_API int swat_vit_backward_join(swat_stream_t stream) {
 //   stage L+1 : proj + ln_post (needs dfeats);  stage l+1 : block l;  stage 0 : ln_pre + embeddings + conv1.
 // Call with stage_hi >= stage_lo; stages run from stage_hi down to stage_lo.  Gradients are WRITTEN (not
 // accumulated) into `grads` at the parameters' own offsets.
+SWAT_API int swat_vit_backward_blocks_fused(const int32_t* dims) {
+    VitDims D;
+    if (parse_dims(dims, D) != 0 || !D.save || g_group_wgrad) return 0;
+    if (!vit_mega_backward_fits(D.B, D.T, D.d, D.H, D.mlp) || !vit_mega_backward_shape(D.B, D.T, D.d, D.H, D.mlp, D.L)) return 0;
+    const int d = D.d, mlp = D.mlp;
+    GemmArgs q[4] = {G(nullptr, nullptr, nullptr, d, mlp, D.Mp, d, mlp, mlp, 1), G(nullptr, nullptr, nullptr, mlp, d, D.Mp, mlp, d, d, 1),
+                     G(nullptr, nullptr, nullptr, d, d, D.Mp, d, d, d, 1), G(nullptr, nullptr, nullptr, 3 * d, d, D.Mp, 3 * d, d, d, 1)};
+    return wgrad_big_try(q, 4, nullptr, true) == 0 ? 1 : 0;
+}
+
 SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const float* params, const void* shadow_bf16,
                                void* workspace, const float* dfeats, float* grads, int stage_hi, int stage_lo,
                                swat_stream_t stream) {
@@ -549,9 +574,16 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
         one = !g_group_wgrad && wgrad_big_try(q, 4, nullptr, true) == 0;
     }
     hipEvent_t* blk = g_side.blk;
-    unsigned short* dxb_head = one ? w.dxb_r[(D.L - 1) % 3] : w.dxb;
+    // Persistent backward (csrc/vit_mega.hip): the data-gradient chain of ALL blocks as one launch when the call covers them all
+    // (stage_hi >= L, stage_lo <= 1) at the small-batch B/32 shape; the blocks' weight gradients and LayerNorm reductions follow
+    // on the lane.  The bf16 copy of the top gradient goes where that launch reads it whenever it MAY run (the op-by-op path of
+    // block L-1 reads the same slot).
+    const bool mega_may = w.mb_dxb && one && vit_mega_backward_shape(D.B, T, d, D.H, mlp, D.L);
+    bool mega = mega_may && stage_hi >= D.L && stage_lo <= 1;
+    unsigned short* dxb_top = mega_may ? w.mb_dxb + (int64_t)(D.L - 1) * D.Mp * d : nullptr;
+    unsigned short* dxb_head = dxb_top ? dxb_top : (one ? w.dxb_r[(D.L - 1) % 3] : w.dxb);
 
-    int ln1_pending = -1;
+    int ln1_pending = -1, mega_rc = 0;
     void* ln1_ws = nullptr;
     for (int stage = stage_hi; stage >= stage_lo; --stage) {
         if (stage == D.L + 1) {
@@ -568,7 +600,41 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             TRY(swat_layernorm_bwd(w.du, d, xl, (int64_t)T * d, params + O.lnpost_w, w.mean_post, w.rstd_post, nullptr, 0, w.dx,
                                    (int64_t)T * d, dxb_head, (int64_t)T * d, grads + O.lnpost_w, grads + O.lnpost_b,
                                    grads + (O.layer + 12 * (D.L - 1))[PRB], w.lnws, D.B, d, s));
+        } else if (stage >= 1 && mega && stage < D.L) {
+            continue;   // ran inside the persistent launch of stage L
+        } else if (stage == D.L && mega && [&]() -> bool {
+                       const int rc = vit_mega_backward(D.B, T, d, D.H, mlp, D.L, D.act, M, D.Mp, params, sh, O.layer, w.xs, w.x1, w.qkv, w.f,
+                                                        w.mean1, w.rstd1, w.mean2, w.rstd2, w.dx, w.mb_dxb, w.mb_dfb, w.mb_dxb2, w.mb_dqkv,
+                                                        w.mb_dh2, w.mb_dh1, w.mb_lnp1, w.mb_lnp2, s);
+                       if (rc < 0) mega_rc = rc;
+                       if (rc != 0) mega = false;   // not eligible after all (no persistent forward ran): op by op from here
+                       return rc == 0;
+                   }()) {
+            // lane: per block the four weight gradients as one launch; the 2 L LayerNorm reductions as one launch behind them
+            to_lane();
+            const int nblk = ((D.B + 1) / 2) * 16;
+            const int64_t lnp = vit_mega_backward_lnp_bytes(D.B, d) / 4;
+            std::vector<const float*> parts;
+            std::vector<float*> dgs, dbs_, dcs;
+            for (int l = D.L - 1; l >= 0; --l) {
+                const int64_t* lo = O.layer + 12 * l;
+                const void* dys[4] = {w.mb_dxb + (int64_t)l * D.Mp * d, w.mb_dfb + (int64_t)l * D.Mp * mlp, w.mb_dxb2 + (int64_t)l * D.Mp * d,
+                                      w.mb_dqkv + (int64_t)l * D.Mp * 3 * d};
+                const void* xs4[4] = {w.gact + (int64_t)l * D.Mp * mlp, w.h2 + (int64_t)l * D.Mp * d, w.a + (int64_t)l * D.Mp * d,
+                                      w.h1 + (int64_t)l * D.Mp * d};
+                float* dws[4] = {grads + lo[PRW], grads + lo[FCW], grads + lo[OUTW], grads + lo[QKVW]};
+                float* dbs[4] = {nullptr, grads + lo[FCB], nullptr, grads + lo[QKVB]};
+                const int rws[4] = {D.Mp, D.Mp, D.Mp, D.Mp}, nout[4] = {d, mlp, d, 3 * d}, nin[4] = {mlp, d, d, d};
+                const int ldy[4] = {d, mlp, d, 3 * d}, ldx[4] = {mlp, d, d, d};
+                TRY(swat_linear_wgrad_bias_group(4, dys, xs4, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                parts.push_back(w.mb_lnp2 + l * lnp); dgs.push_back(grads + lo[LN2W]); dbs_.push_back(grads + lo[LN2B]); dcs.push_back(grads + lo[OUTB]);
+                parts.push_back(w.mb_lnp1 + l * lnp); dgs.push_back(grads + lo[LN1W]); dbs_.push_back(grads + lo[LN1B]);
+                dcs.push_back(l > 0 ? grads + (O.layer + 12 * (l - 1))[PRB] : nullptr);
+            }
+            TRY(ln_bwd_finish_sets(parts.data(), dgs.data(), dbs_.data(), dcs.data(), (int)parts.size(), nblk, d, ws));
+            continue;
         } else if (stage >= 1) {
+            SWAT_REQUIRE(mega_rc == 0, "swat_vit_backward: the persistent backward failed to launch");
             const int l = stage - 1;
             const int64_t* lo = O.layer + 12 * l;
             const float* xin = w.xs + (int64_t)l * M * d;
@@ -582,7 +648,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             const unsigned short* ga = w.gact + (int64_t)l * D.Mp * mlp;
             if (one) {
                 const int si = l & 1;
-                unsigned short* dxb_in = w.dxb_r[l % 3];
+                unsigned short* dxb_in = (dxb_top && l == D.L - 1) ? dxb_top : w.dxb_r[l % 3];
                 unsigned short* dxb_out = w.dxb_r[(l + 2) % 3];   // block l - 1's slot
                 unsigned short *dfb = w.dfb_r[si], *dxb2 = w.dxb2_r[si], *dqkv = w.dqkv_r[si];
                 // this block's slots were last read by the lane work of block l + 2 (same parity; dxb_out: (l + 2) % 3 too)

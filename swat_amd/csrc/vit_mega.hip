@@ -93,6 +93,8 @@ __device__ __forceinline__ void mg_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ unsigned long long mg_clock() { return wall_clock64(); }  // 100 MHz
 
 // ---- the weight slice of a GEMM phase: tile row n of the phase -> row of W ([N][K] row-major, K contiguous) -------------------
+// (backward, data gradients dX = dY W: the reduction runs down the ROWS of W — W points at the member's first column, ldw is
+// still the row stride, and the slice [64 k][BN] of a stage is laid out in LDS as gemm_device.hpp's stp_off image)
 struct MegaW {
     const unsigned short* W;   // null: this member has no product in the phase
     int ldw, nk;               // row stride (elements), 64-deep k-steps
@@ -110,8 +112,8 @@ __device__ __forceinline__ void mg_barrier() {
 // `early(lw)` runs on the four loader waves between the two workgroup barriers — while lane 0 waits for the team they already
 // stream the first stages of the NEXT phase's weight slice into the LDS ring (weights depend on no hand-off).  The second
 // barrier is a raw s_barrier: __syncthreads() would drain those LDS-DMAs (vmcnt(0)).
-template <class Early>
-__device__ __forceinline__ void team_sync(const MegaFwd& p, int team, int member, unsigned target, Early&& early, unsigned long long* tr = nullptr) {
+template <class Params, class Early>
+__device__ __forceinline__ void team_sync(const Params& p, int team, int member, unsigned target, Early&& early, unsigned long long* tr = nullptr) {
     if (tr && threadIdx.x == 0) tr[0] = mg_clock();   // stores issued
     mg_drain();          // every storing wave
     __syncthreads();
@@ -164,6 +166,13 @@ __device__ __forceinline__ bf16x8_t mg_lds_b128(unsigned addr) {
 template <int N_>
 __device__ __forceinline__ void mg_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_ > 15 ? 15 : N_) : "memory"); }
 __device__ __forceinline__ void mg_pin(bf16x8_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ bf16x8_t mg_lds_tr(unsigned lo_addr, unsigned hi_addr) {
+    s16x4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(lo_addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(hi_addr));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
 template <int N_, typename F, int... Is>
 __device__ __forceinline__ void mg_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N_, typename F>
@@ -204,24 +213,34 @@ __device__ __forceinline__ void mg_issue_w(unsigned char* smem, int buf, const c
                                              (__attribute__((address_space(3))) void*)(smem + buf * PC::STAGE + PC::A_BYTES + (lw + MG_NL * i) * 1024),
                                              16, 0, 0);
 }
-template <int BN>
+template <int BN, bool WKC = true>
 __device__ __forceinline__ void mg_w_offsets(const MegaW& w, int lw, int lane, unsigned (&voff)[MgPieces<BN>::MAXW]) {
 #pragma unroll
     for (int i = 0; i < MgPieces<BN>::MAXW; ++i) {
         const int byte = (lw + MG_NL * i) * 1024 + lane * 16;
-        const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
-        voff[i] = (unsigned)(w.row(row < BN ? row : BN - 1) * w.ldw + 8 * t) * 2u;
+        if constexpr (WKC) {
+            const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
+            voff[i] = (unsigned)(w.row(row < BN ? row : BN - 1) * w.ldw + 8 * t) * 2u;
+        } else {
+            int k = 0, col = 0;
+            if (byte < BN * 128) stp_inv<BN>(byte, k, col);
+            voff[i] = (unsigned)(k * w.ldw + col) * 2u;
+        }
     }
 }
+// bytes from one 64-deep k-step of the weight slice to the next
+template <bool WKC>
+__device__ __forceinline__ int64_t mg_w_step(const MegaW& w) { return WKC ? (int64_t)128 : (int64_t)128 * w.ldw; }
 // the part of a GEMM phase that needs no hand-off: W of stages 0 .. NS-2 (run by the loader waves inside team_sync)
-template <int BN, int NS>
+template <int BN, int NS, bool WKC = true>
 __device__ __forceinline__ void mg_w_prologue(unsigned char* smem, const MegaW& w, int lw) {
     if (!w.W) return;
     unsigned voff[MgPieces<BN>::MAXW];
-    mg_w_offsets<BN>(w, lw, threadIdx.x & 63, voff);
+    mg_w_offsets<BN, WKC>(w, lw, threadIdx.x & 63, voff);
     const char* cur = reinterpret_cast<const char*>(w.W);
+    const int64_t step = mg_w_step<WKC>(w);
 #pragma unroll
-    for (int st = 0; st < NS - 1; ++st) mg_issue_w<BN>(smem, st, cur + 128 * st, voff, lw);
+    for (int st = 0; st < NS - 1; ++st) mg_issue_w<BN>(smem, st, cur + step * st, voff, lw);
 }
 
 // ---- one GEMM phase: C[112, BN] = A[rows, K] (row-major, lda) x W^T, W rows given by w.row(n), both operands
@@ -229,7 +248,7 @@ __device__ __forceinline__ void mg_w_prologue(unsigned char* smem, const MegaW& 
 // wave, CN consumer waves side by side in n); the W pieces of the first NS-1 stages were issued by mg_w_prologue before the
 // hand-off completed.  On return the fp32 tile sits in LDS at smem as [112][BN + 4] and the workgroup has passed a barrier
 // behind it.
-template <int BN, int CN, int NS>
+template <int BN, int CN, int NS, bool WKC = true>
 __device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned short* A, int lda, int rows, const MegaW& w) {
     constexpr int NL = MG_NL, NC = MG_NC;
     constexpr int FM = MG_FM, WN = BN / CN, FN = WN / 16;
@@ -253,9 +272,10 @@ __device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned s
             const int gr = row < rows ? row : rows - 1;
             voffA[i] = (unsigned)(gr * lda + 8 * t) * 2u;
         }
-        mg_w_offsets<BN>(w, lw, lane, voffW);
+        mg_w_offsets<BN, WKC>(w, lw, lane, voffW);
         const char* curA = reinterpret_cast<const char*>(A);
         const char* curW = reinterpret_cast<const char*>(w.W);
+        const int64_t stepW = mg_w_step<WKC>(w);
         auto issue_a = [&](int buf, int st) {
 #pragma unroll
             for (int i = 0; i < PC::MAXA; ++i)
@@ -274,7 +294,7 @@ __device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned s
             mg_wait_vmcnt_n(pro > 0 ? pro * nA + t * per : (NS - 3) * per);
             mg_barrier();
             issue_a(buf, t + NS - 1);
-            mg_issue_w<BN>(smem, buf, curW + 128 * (t + NS - 1), voffW, lw);
+            mg_issue_w<BN>(smem, buf, curW + stepW * (t + NS - 1), voffW, lw);
             buf = buf + 1 == NS ? 0 : buf + 1;
         }
         for (; t < nk; ++t) {   // tail: everything is issued; stages t + 2 .. nk - 1 may still fly
@@ -288,11 +308,20 @@ __device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned s
         const int wn0 = (active ? wave : 0) * WN;
         const int r16 = lane & 15, g = lane >> 4;
         const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
-        unsigned ra[2], rb[2];
+        constexpr int NB = WKC ? 1 : 2;   // LDS read instructions per B fragment (k-strided: two transposed 8-B reads)
+        unsigned ra[2], rb[2][WKC ? 1 : FN][NB];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             ra[ks] = lds0 + kc_off(r16, 4 * ks + g);
-            rb[ks] = lds0 + A_BYTES + kc_off(wn0 + r16, 4 * ks + g);
+            if constexpr (WKC) rb[ks][0][0] = lds0 + A_BYTES + kc_off(wn0 + r16, 4 * ks + g);
+            else {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int k = 32 * ks + 8 * g + (r16 >> 2);
+                    rb[ks][j][0] = lds0 + A_BYTES + stp_off<BN>(k, wn0 + 16 * j) + 8 * (r16 & 3);
+                    rb[ks][j][NB - 1] = lds0 + A_BYTES + stp_off<BN>(k + 4, wn0 + 16 * j) + 8 * (r16 & 3);
+                }
+            }
         }
         f32x4_t acc[FM][FN];
 #pragma unroll
@@ -308,9 +337,10 @@ __device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned s
             };
             auto read_b = [&](auto J, unsigned so, int ks, bf16x8_t (&bfr)[FN]) {
                 constexpr int j = decltype(J)::value;
-                bfr[j] = mg_lds_b128<2048 * j>(rb[ks] + so);
+                if constexpr (WKC) bfr[j] = mg_lds_b128<2048 * j>(rb[ks][0][0] + so);
+                else bfr[j] = mg_lds_tr(rb[ks][j][0] + so, rb[ks][j][NB - 1] + so);
             };
-            constexpr int NRI = FM + FN;
+            constexpr int NRI = FM + FN * NB;
             auto half = [&](auto WITH_READS, bf16x8_t (&bcur)[FN], bf16x8_t (&bnext)[FN], unsigned sn, int nks) {
                 mg_static_for<FM>([&](auto I) {
                     constexpr int i = decltype(I)::value;
@@ -323,7 +353,7 @@ __device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned s
                         mg_wait_lgkm<NRI - 1>();
                     } else {
                         constexpr int later_b = i + 1 < RB ? FN - (i + 1) * FN / RB : 0;
-                        mg_wait_lgkm<(FM - 1 - i) + later_b>();
+                        mg_wait_lgkm<(FM - 1 - i) + later_b * NB>();
                     }
                     mg_pin(fa[i]);
 #pragma unroll
@@ -664,6 +694,409 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
     MG_STAMP(stamp++);
 }
 
+// =====================================================================================================================
+// The persistent BACKWARD of the blocks: data gradients, LayerNorm backward and attention backward of all L blocks in one launch
+// (the weight gradients reduce over every row of the batch — a chip-wide dependency per block — and stay separate launches
+// behind it, csrc/gemm_xl.hip).
+//
+// ref: loss.backward() through the 12 ResidualAttentionBlocks (utils/training.py:1486-1488); op-by-op form: swat_vit_backward
+// (csrc/vit.hip), seven launches per block on the main chain, 6-7 us of fixed cost each on M = 1 600 rows.
+//
+// Same teams, panels and hand-off protocol as the forward above; per block (walked L-1 .. 0) a team alternates
+//     PRJ' : member i: dF[:, 192i ..] = (dx W_proj[:, 192i ..]) * act'(F)                                  -> dfb   (bf16)
+//     FC'  : member i: dh2[:, 48i ..] = dF W_fc[:, 48i ..]                                                -> dh2   (fp32)
+//     LN2' : member i, rows 7i ..: dx += LN'(dh2; x1), bf16 copy, partial sums of d gamma / d beta / colsum -> dx, dxb2, lnp2
+//     OUT' : member h < H: da[:, 64h ..] = dx W_out[:, 64h ..] kept in LDS, then the attention backward of head h
+//            for the panel's images (S and P recomputed from the saved q, k as in attn_bwd_small_kernel)  -> dqkv  (bf16)
+//     IN'  : member i: dh1[:, 48i ..] = dqkv W_in[:, 48i ..]                                              -> dh1   (fp32)
+//     LN1' : as LN2' with the block's input                                                               -> dx, dxb of block l-1, lnp1
+// The weights are read as stored ([out][in]: the reduction runs down their rows): stages [64 k][BN] in the stp_off image of
+// gemm_device.hpp, fragments through ds_read_b64_tr_b16 (csrc/gemm_pc.hip's L_NN form).  Every buffer that crosses workgroups
+// is per block (written once per launch: no acquire at the hand-offs, as in the forward with save = 1); the fp32 residual
+// gradient dx is updated in place by the member that owns the row — only that workgroup ever touches it.
+struct MegaBwd {
+    int B, T, d, H, mlp, L, act, save, M, Mp;
+    int P, npanels, nteams;
+    const float* params;
+    const unsigned short* shadow;
+    int64_t lo[12];
+    int64_t layer_stride;
+    // saved by the forward
+    const float *xs, *x1;
+    const unsigned short *qkv, *f;
+    const float *mean1, *rstd1, *mean2, *rstd2;
+    // gradients
+    float* dx;                 // [M, d] residual-stream gradient, in place (in: d(block L-1 output); out: d(block 0 input))
+    unsigned short* dxb;       // [L][Mp, d]: slot l = bf16 copy of d(block l output); slot L-1 comes from the ln_post backward
+    unsigned short *dfb, *dxb2, *dqkv;   // [L][Mp, mlp | d | 3d]: what the weight gradients reduce over
+    float *dh2, *dh1;          // [L][4][M, d]: the four reduction quarters of FC' / IN', summed by the LayerNorm backward
+    float *lnp1, *lnp2;        // [L][npanels * 16][3][d] partial sums of the LayerNorm backward (d gamma, d beta, colsum of bf16(dx))
+    // hand-off state: as MegaFwd
+    unsigned* ctr;
+    unsigned* status;
+    unsigned* host_flag;
+    unsigned launch_no;
+    unsigned long long spin_ticks;
+    int fail_sync;
+    unsigned long long* trace;
+};
+
+// fp32 tile cl[112][BN + 4] (BN = 48) -> out rows, write-through
+__device__ __forceinline__ void mg_epi_f32(const float* cl, float* out, int64_t ld, int rows, int tid) {
+    const int cc = tid % 12, r0 = tid / 12;
+    if (r0 >= 42) return;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int row = r0 + 42 * it;
+        if (row >= rows) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(cl + row * 52 + 4 * cc);
+        u32x4_t v;
+        v[0] = __float_as_uint(c0.x); v[1] = __float_as_uint(c0.y); v[2] = __float_as_uint(c0.z); v[3] = __float_as_uint(c0.w);
+        st_sc1_16(out + (int64_t)row * ld + 4 * cc, v);
+    }
+}
+
+// fp32 tile cl[112][196] (BN = 192) -> out rows, write-through: 48 chunks of 4 columns x 10 rows per pass (480 threads), 12 passes
+__device__ __forceinline__ void mg_epi_f32_wide(const float* cl, float* out, int64_t ld, int rows, int tid) {
+    const int cc = tid % 48, r0 = tid / 48;
+    if (r0 >= 10) return;
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int row = r0 + 10 * it;
+        if (row >= rows) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(cl + row * 196 + 4 * cc);
+        u32x4_t v;
+        v[0] = __float_as_uint(c0.x); v[1] = __float_as_uint(c0.y); v[2] = __float_as_uint(c0.z); v[3] = __float_as_uint(c0.w);
+        st_sc1_16(out + (int64_t)row * ld + 4 * cc, v);
+    }
+}
+
+// cl[112][196] * act'(F) -> dF (bf16, write-through); a thread keeps one 8-column chunk and walks 6 rows, the F loads first
+template <int ACT>
+__device__ __forceinline__ void mg_epi_actgrad(const float* cl, const unsigned short* f, unsigned short* out, int64_t ld, int rows, int tid) {
+    const int cc = tid % 24, r0 = tid / 24;
+    if (r0 >= 21) return;
+    u32x4_t fv[6];
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int row = r0 + 21 * it;
+        if (row < rows) fv[it] = *reinterpret_cast<const u32x4_t*>(f + (int64_t)row * ld + 8 * cc);
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int row = r0 + 21 * it;
+        if (row >= rows) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(cl + row * 196 + 8 * cc);
+        const float4 c1 = *reinterpret_cast<const float4*>(cl + row * 196 + 8 * cc + 4);
+        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            v[2 * h] *= act_bwd(bf2f((unsigned short)(fv[it][h] & 0xffffu)), ACT);
+            v[2 * h + 1] *= act_bwd(bf2f((unsigned short)(fv[it][h] >> 16)), ACT);
+        }
+        u32x4_t pk;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) pk[h] = pack_bf16x2(v[2 * h], v[2 * h + 1]);
+        st_sc1_16(out + (int64_t)row * ld + 8 * cc, pk);
+    }
+}
+
+// LayerNorm backward of the member's rows (one wave per row; arithmetic of ln_bwd_kernel, csrc/elementwise.hip):
+//   dx[row] += rstd * (dy g - mean(dy g) - xhat mean(dy g xhat));  dxb = bf16(dx) (write-through);
+//   part[0 | 1 | 2][d] = this member's sums over its rows of dy xhat | dy | bf16(dx)   (waves added in wave order)
+__device__ __forceinline__ void mg_ln_bwd(unsigned char* smem, int d, const float* dy, int64_t plane, const float* x, const float* gamma, const float* mean,
+                                          const float* rstd, float* dx, unsigned short* dxb, float* part, int row0, int rows_valid,
+                                          int member) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = 7 * member + wave;
+    float4 dg[3], db[3], dcs[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[i] = dg[i];
+        dcs[i] = dg[i];
+    }
+    if (wave < 7 && r < rows_valid) {
+        const int64_t row = row0 + r;
+        const float4* dyr = reinterpret_cast<const float4*>(dy + row * d);
+        const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+        float4* dxr = reinterpret_cast<float4*>(dx + row * d);
+        float4 dyv[3], xh[3], add[3], gm[3], pl[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {   // d = 768: 3 float4 per lane; every load of the row in flight before the first use
+            const int c = lane + 64 * i;
+            dyv[i] = dyr[c];
+#pragma unroll
+            for (int sp = 1; sp < 4; ++sp) pl[sp - 1][i] = reinterpret_cast<const float4*>(dy + sp * plane + row * d)[c];
+            xh[i] = xr[c];
+            add[i] = dxr[c];
+            gm[i] = reinterpret_cast<const float4*>(gamma)[c];
+        }
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int sp = 1; sp < 4; ++sp) {   // the four reduction quarters of the producing product, fixed order
+                const float4 t = pl[sp - 1][i];
+                dyv[i].x += t.x; dyv[i].y += t.y; dyv[i].z += t.z; dyv[i].w += t.w;
+            }
+            const float4 xv = xh[i];
+            xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            const float a0 = dyv[i].x * gm[i].x, a1 = dyv[i].y * gm[i].y, a2 = dyv[i].z * gm[i].z, a3 = dyv[i].w * gm[i].w;
+            s1 += a0 + a1 + a2 + a3;
+            s2 += a0 * xh[i].x + a1 * xh[i].y + a2 * xh[i].z + a3 * xh[i].w;
+            dg[i].x += dyv[i].x * xh[i].x; dg[i].y += dyv[i].y * xh[i].y;
+            dg[i].z += dyv[i].z * xh[i].z; dg[i].w += dyv[i].w * xh[i].w;
+            db[i].x += dyv[i].x; db[i].y += dyv[i].y; db[i].z += dyv[i].z; db[i].w += dyv[i].w;
+            dyv[i] = make_float4(a0, a1, a2, a3);
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = lane + 64 * i;
+            float4 o;
+            o.x = rs * (dyv[i].x - m1 - xh[i].x * m2);
+            o.y = rs * (dyv[i].y - m1 - xh[i].y * m2);
+            o.z = rs * (dyv[i].z - m1 - xh[i].z * m2);
+            o.w = rs * (dyv[i].w - m1 - xh[i].w * m2);
+            o.x += add[i].x; o.y += add[i].y; o.z += add[i].z; o.w += add[i].w;
+            dxr[c] = o;
+            const unsigned p0 = pack_bf16x2(o.x, o.y), p1 = pack_bf16x2(o.z, o.w);
+            st_sc1_8(dxb + row * d + 4 * c, p0, p1);
+            dcs[i].x += __uint_as_float(p0 << 16); dcs[i].y += __uint_as_float(p0 & 0xffff0000u);
+            dcs[i].z += __uint_as_float(p1 << 16); dcs[i].w += __uint_as_float(p1 & 0xffff0000u);
+        }
+    }
+    float* sh = reinterpret_cast<float*>(smem);   // [7][d]
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (wave < 7) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                reinterpret_cast<float4*>(sh + wave * d)[lane + 64 * i] = q == 0 ? dg[i] : (q == 1 ? db[i] : dcs[i]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < d; c += MG_THREADS) {
+            float v = sh[c];
+#pragma unroll
+            for (int w = 1; w < 7; ++w) v += sh[w * d + c];
+            part[q * d + c] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// attention backward of one (image, head): 4 waves (w = query / key rows 16w ..), tiles [64][ATP] of this image group in LDS:
+// qt, kt (staged from the saved qkv), dot_ (the head's columns of da, bf16), dst / pt (written here).  Arithmetic and rounding
+// points of attn_bwd_small_kernel (csrc/attention.hip); `live` = false: a group without an image in this pass (it keeps the
+// workgroup barriers, stores nothing).
+__device__ __forceinline__ void mg_attn_bwd(const unsigned short* base /* q of the image's row 0, this head */, int64_t ld, int d, int T,
+                                            const unsigned short* qt, const unsigned short* kt, const unsigned short* dot_, unsigned short* dst,
+                                            unsigned short* pt, unsigned short* dbase, int w, int lane, float scale, bool live) {
+    const int r16 = lane & 15, g = lane >> 4;
+    af32x4_t p[4];
+    scores_softmax(base, ld, d, T, w, r16, g, scale, p);
+    const int q = w * 16 + r16, qq = q < T ? q : T - 1;
+    abf16x8_t dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) dof[ks] = ld_frag(dot_ + qq * ATP + 32 * ks + 8 * g);
+    af32x4_t ds[4];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int key = 16 * j + r16, kk = key < T ? key : T - 1;
+        ds[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            ds[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(base + 2 * d + (int64_t)kk * ld + 32 * ks + 8 * g), dof[ks], ds[j], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dot += p[j][e] * ds[j][e];
+    }
+    dot = xor_sum(dot);
+    const bool qv = q < T;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * j + 4 * g + e;
+            ds[j][e] = (qv && key < T) ? scale * p[j][e] * (ds[j][e] - dot) : 0.f;
+            if (!qv) p[j][e] = 0.f;
+        }
+        store4(dst + q * ATP + 16 * j + 4 * g, ds[j]);
+        store4(pt + q * ATP + 16 * j + 4 * g, p[j]);
+    }
+    __syncthreads();   // dst / pt complete (both image groups pass here together)
+    const abf16x8_t dsf[2] = {acc_frag(ds, 0), acc_frag(ds, 1)};
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc) {
+        af32x4_t o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(kt, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * jc, r16), dsf[ks], o, 0, 0, 0);
+        if (qv && live) st_sc1_8(dbase + (int64_t)q * ld + 16 * jc + 4 * g, pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+    }
+    const int key = w * 16 + r16;
+    abf16x8_t dst_f[2], pt_f[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        dst_f[ks] = tr_frag(dst, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * w, r16);
+        pt_f[ks] = tr_frag(pt, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * w, r16);
+    }
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc) {
+        af32x4_t dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(qt, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * jc, r16), dst_f[ks], dk, 0, 0, 0);
+            dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dot_, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * jc, r16), pt_f[ks], dv, 0, 0, 0);
+        }
+        if (key < T && live) {
+            st_sc1_8(dbase + d + (int64_t)key * ld + 16 * jc + 4 * g, pack_bf16x2(dk[0], dk[1]), pack_bf16x2(dk[2], dk[3]));
+            st_sc1_8(dbase + 2 * d + (int64_t)key * ld + 16 * jc + 4 * g, pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(MG_THREADS) void vit_bwd_mega_kernel(const MegaBwd p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[MG_LDS];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    int team, member;
+    if (p.nteams % 8 == 0) {
+        const int q = p.nteams / 8, s = b >> 3;
+        team = (b & 7) * q + s / MG_TEAM;
+        member = s % MG_TEAM;
+    } else {
+        team = b / MG_TEAM;
+        member = b % MG_TEAM;
+    }
+    const int d = p.d, T = p.T, mlp = p.mlp;
+    const int64_t M = p.M, Mp = p.Mp;
+    const float scale = 1.0f / sqrtf(64.0f);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    unsigned seq = 0;
+    int stamp = 0;
+    const int trl = p.L > 2 ? p.L / 2 : p.L - 1;   // the block whose phases the trace stamps
+    MG_STAMP(stamp++);
+    auto w_prj = [&](int l) {   // dF columns 192 member ..: W_proj [d][mlp], reduction over its d rows
+        return MegaW{p.shadow + (int64_t)l * p.layer_stride + p.lo[PRW] + 192 * member, mlp, d >> 6, 0, -1, d};
+    };
+#define MB_TR(k_) ((p.trace && l == trl && panel == team) ? p.trace + (size_t)blockIdx.x * 64 + 8 + 4 * (k_) : nullptr)
+#define MB_SYNC(next_, BN_, NS_, k_)                                                                                                  \
+    team_sync(p, team, member, ++seq * MG_TEAM, [&](int lw) { mg_w_prologue<BN_, NS_, false>(smem, next_, lw); }, MB_TR(k_));         \
+    if (l == trl) MG_STAMP(stamp++)
+#define MB_SYNC0(k_)                                                              \
+    team_sync(p, team, member, ++seq * MG_TEAM, [&](int) {}, MB_TR(k_));          \
+    if (l == trl) MG_STAMP(stamp++)
+#define MB_GEMM_DONE(k_)                                                                                             \
+    if (p.trace && l == trl && panel == team && tid == 0) p.trace[(size_t)blockIdx.x * 64 + 32 + (k_)] = mg_clock()
+    // the first product's weight stages: no hand-off in front of it
+    if (team < p.npanels && wave >= MG_NC) mg_w_prologue<192, 4, false>(smem, w_prj(p.L - 1), wave - MG_NC);
+    for (int panel = team; panel < p.npanels; panel += p.nteams) {
+        const int img0 = panel * p.P;
+        const int nimg = (p.B - img0) < p.P ? (p.B - img0) : p.P;
+        const int row0 = img0 * T, rows = nimg * T;
+        const int64_t pblk = (int64_t)panel * MG_TEAM + member;   // this member's block of LayerNorm partial sums
+        const int64_t npart = (int64_t)p.npanels * MG_TEAM;
+        for (int l = p.L - 1; l >= 0; --l) {
+            const int64_t po = (int64_t)l * p.layer_stride;
+            if (l == trl) MG_STAMP(stamp++);
+            const float* xin = p.xs + (int64_t)l * M * d;
+            const float* x1 = p.x1 + (int64_t)l * M * d;
+            const unsigned short* qkv = p.qkv + (int64_t)l * M * 3 * d;
+            const unsigned short* f = p.f + (int64_t)l * M * mlp;
+            const unsigned short* dxb_in = p.dxb + (int64_t)l * Mp * d;
+            unsigned short* dxb_out = p.dxb + (int64_t)(l > 0 ? l - 1 : p.L) * Mp * d;   // (slot L: a scratch slot nobody reads)
+            unsigned short* dfb = p.dfb + (int64_t)l * Mp * mlp;
+            unsigned short* dxb2 = p.dxb2 + (int64_t)l * Mp * d;
+            unsigned short* dqkv = p.dqkv + (int64_t)l * Mp * 3 * d;
+            float* dh2 = p.dh2 + (int64_t)l * 4 * M * d;   // four planes: the reduction quarters of FC' / IN'
+            float* dh1 = p.dh1 + (int64_t)l * 4 * M * d;
+            const int ng = member & 3, kg = member >> 2;   // FC' / IN': 192 columns x a quarter of the reduction per member
+            const MegaW wP = w_prj(l);
+            const MegaW wF{p.shadow + po + p.lo[FCW] + (int64_t)kg * (mlp >> 2) * d + 192 * ng, d, mlp >> 8, 0, -1, d};
+            const MegaW wO{member < p.H ? p.shadow + po + p.lo[OUTW] + 64 * member : nullptr, d, d >> 6, 0, -1, d};
+            const MegaW wI{p.shadow + po + p.lo[QKVW] + (int64_t)kg * ((3 * d) >> 2) * d + 192 * ng, d, (3 * d) >> 8, 0, -1, d};
+            // ---------------- PRJ': dF = (dx W_proj) * act'(F) ----------------
+            {
+                const int n0 = 192 * member;
+                mg_gemm_nt<192, 4, 4, false>(smem, dxb_in + (int64_t)row0 * d, d, rows, wP);
+                MB_GEMM_DONE(0);
+                const float* cl = reinterpret_cast<const float*>(smem);
+                const unsigned short* fi = f + (int64_t)row0 * mlp + n0;
+                unsigned short* fo = dfb + (int64_t)row0 * mlp + n0;
+                if (p.act == 1) mg_epi_actgrad<1>(cl, fi, fo, mlp, rows, tid);
+                else if (p.act == 2) mg_epi_actgrad<2>(cl, fi, fo, mlp, rows, tid);
+                else mg_epi_actgrad<0>(cl, fi, fo, mlp, rows, tid);
+            }
+            MB_SYNC(wF, 192, 4, 0);
+            // ---------------- FC': dh2[kg] = dF[:, quarter kg] W_fc[quarter kg, 192 ng ..] ----------------
+            mg_gemm_nt<192, 4, 4, false>(smem, dfb + (int64_t)row0 * mlp + kg * (mlp >> 2), mlp, rows, wF);
+            MB_GEMM_DONE(1);
+            mg_epi_f32_wide(reinterpret_cast<const float*>(smem), dh2 + (int64_t)kg * M * d + (int64_t)row0 * d + 192 * ng, d, rows, tid);
+            MB_SYNC0(1);
+            // ---------------- LN2' ----------------
+            mg_ln_bwd(smem, d, dh2, M * d, x1, p.params + po + p.lo[LN2W], p.mean2 + (int64_t)l * M, p.rstd2 + (int64_t)l * M, p.dx, dxb2,
+                      p.lnp2 + ((int64_t)l * npart + pblk) * 3 * d, row0, rows, member);
+            MB_SYNC(wO, 64, 6, 2);
+            // ---------------- OUT' + attention backward (member = head) ----------------
+            if (member < p.H) {
+                const int h = member;
+                mg_gemm_nt<64, 4, 6, false>(smem, dxb2 + (int64_t)row0 * d, d, rows, wO);
+                MB_GEMM_DONE(3);
+                const float* cl = reinterpret_cast<const float*>(smem);          // [112][68] fp32: da of this head
+                unsigned short* tiles = reinterpret_cast<unsigned short*>(smem + MG_ROWS * 68 * 4);   // 2 groups x {qt, kt, dot_, dst, pt}
+                const int grp = tid >> 8, gt = tid & 255;
+                unsigned short* qt = tiles + grp * 5 * 64 * ATP;
+                unsigned short *kt = qt + 64 * ATP, *dot_ = kt + 64 * ATP, *dst = dot_ + 64 * ATP, *pt = dst + 64 * ATP;
+                for (int im0 = 0; im0 < nimg; im0 += 2) {
+                    const bool live = im0 + grp < nimg;
+                    const int im = live ? im0 + grp : nimg - 1;
+                    const unsigned short* base = qkv + (int64_t)(row0 + im * T) * 3 * d + 64 * h;
+                    if (im0 > 0) __syncthreads();   // the tiles of the previous pass have been read
+                    for (int i = gt; i < 64 * 8; i += 256) {
+                        const int row = i >> 3, ch = i & 7;
+                        const int rr = row < T ? row : T - 1;
+                        *reinterpret_cast<au32x4_t*>(qt + row * ATP + ch * 8) = *reinterpret_cast<const au32x4_t*>(base + (int64_t)rr * 3 * d + ch * 8);
+                        *reinterpret_cast<au32x4_t*>(kt + row * ATP + ch * 8) = *reinterpret_cast<const au32x4_t*>(base + d + (int64_t)rr * 3 * d + ch * 8);
+                        const float* c = cl + (im * T + rr) * 68 + ch * 8;
+                        const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
+                        au32x4_t pk;
+                        pk[0] = pack_bf16x2(c0.x, c0.y); pk[1] = pack_bf16x2(c0.z, c0.w);
+                        pk[2] = pack_bf16x2(c1.x, c1.y); pk[3] = pack_bf16x2(c1.z, c1.w);
+                        *reinterpret_cast<au32x4_t*>(dot_ + row * ATP + ch * 8) = pk;
+                    }
+                    __syncthreads();
+                    mg_attn_bwd(base, 3 * (int64_t)d, d, T, qt, kt, dot_, dst, pt, dqkv + (int64_t)(row0 + im * T) * 3 * d + 64 * h, wave & 3, lane,
+                                scale, live);
+                }
+            }
+            MB_SYNC(wI, 192, 4, 3);
+            // ---------------- IN': dh1[kg] = dqkv[:, quarter kg] W_in[quarter kg, 192 ng ..] ----------------
+            mg_gemm_nt<192, 4, 4, false>(smem, dqkv + (int64_t)row0 * 3 * d + kg * ((3 * d) >> 2), 3 * d, rows, wI);
+            MB_GEMM_DONE(4);
+            mg_epi_f32_wide(reinterpret_cast<const float*>(smem), dh1 + (int64_t)kg * M * d + (int64_t)row0 * d + 192 * ng, d, rows, tid);
+            MB_SYNC0(4);
+            // ---------------- LN1' ----------------
+            mg_ln_bwd(smem, d, dh1, M * d, xin, p.params + po + p.lo[LN1W], p.mean1 + (int64_t)l * M, p.rstd1 + (int64_t)l * M, p.dx, dxb_out,
+                      p.lnp1 + ((int64_t)l * npart + pblk) * 3 * d, row0, rows, member);
+            {
+                // the next product of this workgroup: block l - 1's PRJ', or the next panel's first one
+                const bool more = l > 0 || panel + p.nteams < p.npanels;
+                MegaW wN = w_prj(l > 0 ? l - 1 : p.L - 1);
+                if (!more) wN.W = nullptr;
+                MB_SYNC(wN, 192, 4, 5);
+            }
+        }
+    }
+#undef MB_SYNC
+#undef MB_SYNC0
+#undef MB_GEMM_DONE
+#undef MB_TR
+    MG_STAMP(stamp++);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------
 // Per-device state of the persistent forward.  The arrival counters are one block per device: persistent launches of a device
 // are SERIALISED (a launch on another stream first waits for the previous launch's completion event) — two of them in flight at
@@ -677,12 +1110,16 @@ struct MegaDev {
     hipStream_t last = nullptr;
     bool any = false;
     int cus = 0, resident = -1;     // CUs of the device; workgroups of the kernel that fit one CU (occupancy query)
-    unsigned launches = 0;
+    int resident_bwd = -1;          // the same for the persistent backward
+    unsigned launches = 0, launches_bwd = 0;
 };
 static MegaDev g_mega_dev[16];
 static int g_mega_mode = -1;               // swat_vit_set_mega / SWAT_VIT_MEGA: 0 = op-by-op forward, 1 = persistent forward when eligible
 static unsigned long long* g_mega_trace = nullptr;
 static int g_fail_launches = 0, g_fail_sync = 0;   // swat_vit_mega_inject_failure
+static int g_mega_bwd = -1;                // swat_vit_set_mega_backward / SWAT_VIT_MEGA_BWD
+static unsigned long long* g_mega_trace_bwd = nullptr;
+static int g_fail_bwd_launches = 0, g_fail_bwd_sync = 0;
 
 static MegaDev* mega_dev() {
     int dev = 0;
@@ -785,8 +1222,117 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
     return rc;
 }
 
+// shapes the persistent backward can serve, whatever the modes say (csrc/vit.hip carves its per-block gradient buffers by this)
+bool vit_mega_backward_fits(int B, int T, int d, int H, int mlp) {
+    return d == 768 && mlp == 3072 && H == 12 && T >= 38 && T <= 56 && B >= 1 && (B + 1) / 2 <= 32;
+}
+// ... and does serve now: the forward's rule (whole rounds of 16 panels, at most two)
+bool vit_mega_backward_shape(int B, int T, int d, int H, int mlp, int L) {
+    if (g_mega_mode < 0) {
+        const char* e = getenv("SWAT_VIT_MEGA");
+        g_mega_mode = e ? (atoi(e) == 0 ? 0 : atoi(e) == 2 ? 2 : 1) : 1;
+    }
+    if (g_mega_bwd < 0) {
+        const char* e = getenv("SWAT_VIT_MEGA_BWD");
+        g_mega_bwd = e ? (atoi(e) != 0) : 1;
+    }
+    if (g_mega_mode == 0 || !g_mega_bwd || L < 1 || !vit_mega_backward_fits(B, T, d, H, mlp)) return false;
+    const int np = (B + 1) / 2, rounds = (np + 15) / 16;
+    if (g_mega_mode != 2 && np < rounds * 16 - 3) return false;
+    return true;
+}
+
+// bytes per block of the LayerNorm partial sums of the persistent backward: [panels * 16][3][d] floats
+int64_t vit_mega_backward_lnp_bytes(int B, int d) { return (int64_t)((B + 1) / 2) * MG_TEAM * 3 * d * 4; }
+
+// -> 0: launched; 1: not eligible (the caller runs the blocks op by op); < 0: error
+int vit_mega_backward(int B, int T, int d, int H, int mlp, int L, int act, int M, int Mp, const float* params, const unsigned short* shadow,
+                      const int64_t* layer_offs, const float* xs, const float* x1, const unsigned short* qkv, const unsigned short* f,
+                      const float* mean1, const float* rstd1, const float* mean2, const float* rstd2, float* dx, unsigned short* dxb,
+                      unsigned short* dfb, unsigned short* dxb2, unsigned short* dqkv, float* dh2, float* dh1, float* lnp1, float* lnp2,
+                      hipStream_t s) {
+    if (!vit_mega_backward_shape(B, T, d, H, mlp, L)) return 1;
+    const int64_t stride = L > 1 ? layer_offs[12] - layer_offs[0] : 0;
+    for (int l = 1; l < L; ++l)
+        for (int k = 0; k < 12; ++k)
+            if (layer_offs[12 * l + k] - layer_offs[k] != (int64_t)l * stride) return 1;
+    for (int k = 0; k < 12; ++k)
+        if (layer_offs[k] % 8) return 1;
+    if (stride % 8) return 1;
+    MegaDev* md = mega_dev();
+    if (!md || !md->state) return 1;   // (the state is created by the first persistent forward: a backward follows one)
+    const int npanels = (B + 1) / 2, nteams = npanels < 16 ? npanels : 16;
+    if (md->resident_bwd < 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vit_bwd_mega_kernel, MG_THREADS, 0) != hipSuccess) occ = 0;
+        (void)hipGetLastError();
+        md->resident_bwd = occ;
+    }
+    if (md->resident_bwd < 1 || md->cus < 1 || nteams * MG_TEAM > md->cus) return 1;
+    MegaBwd m{};
+    m.B = B; m.T = T; m.d = d; m.H = H; m.mlp = mlp; m.L = L; m.act = act; m.save = 1; m.M = M; m.Mp = Mp;
+    m.P = 2; m.npanels = npanels; m.nteams = nteams;
+    m.params = params; m.shadow = shadow;
+    for (int k = 0; k < 12; ++k) m.lo[k] = layer_offs[k];
+    m.layer_stride = stride;
+    m.xs = xs; m.x1 = x1; m.qkv = qkv; m.f = f; m.mean1 = mean1; m.rstd1 = rstd1; m.mean2 = mean2; m.rstd2 = rstd2;
+    m.dx = dx; m.dxb = dxb; m.dfb = dfb; m.dxb2 = dxb2; m.dqkv = dqkv; m.dh2 = dh2; m.dh1 = dh1; m.lnp1 = lnp1; m.lnp2 = lnp2;
+    m.ctr = md->state;
+    m.status = md->state + 16 * 32;
+    m.host_flag = md->host_flag;
+    m.launch_no = md->launches;    // the forward it follows: a give-up voids that step (the host replays from there)
+    ++md->launches_bwd;
+    m.spin_ticks = 50000000ull;
+    m.fail_sync = 0;
+    if (g_fail_bwd_launches > 0) {
+        --g_fail_bwd_launches;
+        m.fail_sync = g_fail_bwd_sync;
+        m.spin_ticks = 200000ull;
+    }
+    m.trace = g_mega_trace_bwd;
+    if (md->any && md->last != s) SWAT_HIP(hipStreamWaitEvent(s, md->done, 0));
+    SWAT_HIP(hipMemsetAsync(md->state, 0, 16 * 128, s));
+    // data-gradient products + attention backward inside the launch
+    const double flops = (double)L * B * T * (2.0 * d * 3 * d + 2.0 * d * d + 4.0 * d * mlp + 10.0 * T * d);
+    hipEvent_t e0, e1;
+    if (gemm_prof_take(12, flops, e0, e1)) hipExtLaunchKernelGGL(vit_bwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, e0, e1, 0, m);
+    else hipLaunchKernelGGL(vit_bwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, m);
+    const int rc = check_launch("vit_bwd_mega_kernel");
+    if (rc == 0) {
+        SWAT_HIP(hipEventRecord(md->done, s));
+        md->last = s;
+        md->any = true;
+    }
+    return rc;
+}
+
 }  // namespace swat
 using namespace swat;
+
+// 0 = data gradients of the blocks op by op, 1 = as one persistent launch when eligible (default; SWAT_VIT_MEGA_BWD)
+SWAT_API int swat_vit_set_mega_backward(int mode) {
+    SWAT_REQUIRE(mode == 0 || mode == 1, "swat_vit_set_mega_backward: mode must be 0 or 1");
+    g_mega_bwd = mode;
+    return 0;
+}
+
+// tuning / tests: as swat_vit_mega_inject_failure, for the next persistent BACKWARD launches (6 hand-offs per block, top block first)
+SWAT_API int swat_vit_mega_backward_inject_failure(int launches, int handoff) {
+    SWAT_REQUIRE(launches >= 0 && handoff >= 0, "swat_vit_mega_backward_inject_failure: negative argument");
+    g_fail_bwd_launches = launches;
+    g_fail_bwd_sync = handoff;
+    return 0;
+}
+
+SWAT_API int swat_vit_mega_backward_launches(void) {
+    MegaDev* md = mega_dev();
+    return md ? (int)md->launches_bwd : 0;
+}
+
+SWAT_API int swat_vit_mega_backward_trace(void* device_buffer) {
+    g_mega_trace_bwd = (unsigned long long*)device_buffer;
+    return 0;
+}
 
 SWAT_API int swat_vit_set_mega(int mode) {
     SWAT_REQUIRE(mode >= 0 && mode <= 2, "swat_vit_set_mega: mode must be 0, 1 or 2");

@@ -257,10 +257,23 @@ class FusedTrainStep:
                 finish(sl["head"], self.off_head, self.C * self.E)
                 if self.off_ls is not None:
                     finish(sl["ls"], self.off_ls, 1)
-                for s in range(self.visual.layers + 1, -1, -1):
-                    self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
-                    lo, hi = self._stage_slices[s]
-                    finish(sl["stages"][s], lo, hi - lo)
+                L = self.visual.layers
+                if lib.swat_vit_backward_blocks_fused(self.visual._last_ws[1]):
+                    # the blocks' data gradients run as ONE persistent launch (csrc/vit_mega.hip): one call for all of them, their
+                    # weight gradients follow on the lane and one AdamW launch over the blocks' joint arena range behind those
+                    for hi_s, lo_s in ((L + 1, L + 1), (L, 1), (0, 0)):
+                        self.visual.backward_raw(dfeats, stage_hi=hi_s, stage_lo=lo_s)
+                        if hi_s == lo_s:
+                            lo, hi = self._stage_slices[hi_s]
+                            finish(sl["stages"][hi_s], lo, hi - lo)
+                        else:
+                            lo, hi = self._stage_slices[lo_s][0], self._stage_slices[hi_s][1]
+                            finish(self._adamw_args(lo, hi), lo, hi - lo)
+                else:
+                    for s in range(L + 1, -1, -1):
+                        self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
+                        lo, hi = self._stage_slices[s]
+                        finish(sl["stages"][s], lo, hi - lo)
         finally:
             lib.swat_vit_backward_join(main.cuda_stream)
             lib.swat_vit_set_overlap(1)

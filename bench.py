@@ -91,27 +91,31 @@ def gemm_roofline(args, step, sched, images, labels, n_steps, bsz, overlap=1):
     torch.cuda.synchronize()
     lib.swat_vit_set_overlap(min(overlap, 1))
     step.trail = trail
-    ms = (ctypes.c_double * 12)()
-    cnt = (ctypes.c_int64 * 12)()
-    fl = (ctypes.c_double * 12)()
+    ms = (ctypes.c_double * 16)()
+    cnt = (ctypes.c_int64 * 16)()
+    fl = (ctypes.c_double * 16)()
     n = lib.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
-    names = ["NT_64", "NT_128", "NT_pc", "NN_64", "NN_128", "NN_pc", "TN_64", "TN_128", "TN_pc", "fwd_persistent", "TN_block_256x128", "xl_256x128"]
+    names = ["NT_64", "NT_128", "NT_pc", "NN_64", "NN_128", "NN_pc", "TN_64", "TN_128", "TN_pc", "fwd_persistent", "TN_block_256x128", "xl_256x128",
+             "bwd_persistent", "-", "-", "-"]
     total_ms = sum(ms) / n_steps
     # What is inside the timed kernels: every product of the step.  The persistent forward (csrc/vit_mega.hip, kind 9) holds all
     # twelve blocks' products AND their attention, LayerNorms and hand-offs — its whole duration is charged to the roofline.
     # Outside remain only the T = 50 attention products of the BACKWARD (attn_bwd_small_kernel: 2/3 of 8.8 GFLOP).
-    mega = cnt[9] > 0
+    # The persistent backward (kind 12) likewise holds the blocks' data-gradient products, attention backward and LayerNorm backward.
+    mega, mega_b = cnt[9] > 0, cnt[12] > 0
     attn_flops = 3 * 2 * (2.0 * 50 * 50 * 64) * bsz * 12 * 12
-    algo_flops = GFLOP_PER_IMG_STEP * 1e9 * bsz - (attn_flops * 2 / 3 if mega else attn_flops)
+    algo_flops = GFLOP_PER_IMG_STEP * 1e9 * bsz - attn_flops * ((0 if mega else 1) + (0 if mega_b else 2)) / 3
     achieved = algo_flops / (total_ms * 1e-3) / 1e12
     per_kind = {names[i]: {"launches_per_step": cnt[i] / n_steps, "avg_us": (1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0,
-                           "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0} for i in range(12) if cnt[i]}
+                           "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0} for i in range(16) if cnt[i]}
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r03_gemm_pmc.json")
+    tpath = os.path.join(ROOT, "profiles", "r04_gemm_pmc.json")
     if os.path.exists(tpath):  # PMC passes cannot run inside this process: the committed rocprofv3 --pmc result of this command
         traffic = round(json.load(open(tpath))["hbm_bytes_per_gemm_launch"])
-        traffic_src = "profiles/r03_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes, mean bytes per timed launch)"
-    return {"bound": "mfma", "kernel": "vit_fwd_mega_kernel (all forward blocks, one launch) + gemm_pc_kernel / gemm_dma_kernel / gemm_ring2_kernel / "
+        traffic_src = "profiles/r04_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes, mean bytes per timed launch)"
+    return {"bound": "mfma", "kernel": "vit_fwd_mega_kernel + vit_bwd_mega_kernel (all blocks' forward / data-gradient chain, one launch each) + gemm_xl_kernel "
+                                       "(weight gradients) + gemm_pc_kernel / gemm_ring_kernel (stem, head)" if mega and mega_b else
+                                       "vit_fwd_mega_kernel (all forward blocks, one launch) + gemm_pc_kernel / gemm_dma_kernel / gemm_ring2_kernel / "
                                        "gemm_ring_kernel (backward and stem products)" if mega else
                                        "gemm_pc_kernel / gemm_dma_kernel / gemm_ring2_kernel / gemm_ring_kernel (all GEMM instantiations)",
             "achieved": round(achieved, 2),
@@ -119,7 +123,9 @@ def gemm_roofline(args, step, sched, images, labels, n_steps, bsz, overlap=1):
             "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(algo_flops / (n / n_steps)),
             "gemm_ms_per_step": round(total_ms, 4), "gemm_launches_per_step": n / n_steps,
             "algorithmic_gflop_per_step": round(algo_flops / 1e9, 1),
-            "note": ("846.5 GFLOP per step minus 5.9 GFLOP of backward attention products that run outside the timed kernels; the persistent "
+            "note": ("all 846.5 GFLOP of the step; the persistent forward's and backward's durations include their LayerNorms, attention and "
+                     "team hand-offs" if mega and mega_b else
+                     "846.5 GFLOP per step minus 5.9 GFLOP of backward attention products that run outside the timed kernels; the persistent "
                      "forward's duration includes its LayerNorms, attention and team hand-offs" if mega else
                      "846.5 GFLOP per step minus 8.8 GFLOP of attention products that run outside gemm_*"),
             "per_instantiation": per_kind}
@@ -311,7 +317,7 @@ def retrieval_secondary(dev, rank=0, world=1, d=512, steps=5, with_cpu=True):
 def _pmc_traffic(kernel, d=512, contains=None):
     """HBM bytes per launch of a retrieval kernel from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh;
     counters cannot be collected inside this process).  None when the profile is absent or was taken at another d."""
-    p = os.path.join(ROOT, "profiles", "r03_retrieval_pmc.json")
+    p = os.path.join(ROOT, "profiles", "r04_retrieval_pmc.json")
     if not os.path.exists(p):
         p = os.path.join(ROOT, "profiles", "r02_retrieval_pmc.json")
     if not os.path.exists(p) or d != 512:

@@ -12,10 +12,11 @@ extern "C" {
 #endif
 
 /* Time every GEMM launch with start / stop hipEvents attached to the kernel's own dispatch packet (kernel execution
- *     time, as rocprofv3 reports it).  end() synchronises and fills 12 slots — layout * 3 + {0: 64-row tile,
+ *     time, as rocprofv3 reports it).  end() synchronises and fills 16 slots — layout * 3 + {0: 64-row tile,
  *     1: 128- / 256-row tile, 2: producer / consumer kernel} for NT / NN / TN, 9: the persistent forward (csrc/vit_mega.hip:
- *     all blocks in one launch), 10-11: unused — with total milliseconds, launch counts and flops; returns the launches
- *     seen.  The three arrays hold 12 entries. */
+ *     all blocks in one launch), 10: a block's weight gradients as one launch of 256 x 128 tiles, 11: the 256 x 128 loader /
+ *     consumer kernel on NT / NN products, 12: the persistent backward, 13-15: unused — with total milliseconds, launch counts
+ *     and flops; returns the launches seen.  The three arrays hold 16 entries. */
 int swat_gemm_prof_begin(int max_launches);
 int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind);
 /* Pin one tile configuration (-1 = automatic) — tests and tuning.  14-19, 25-28, 43: LDS-DMA ring (64x64 / 128x128 /

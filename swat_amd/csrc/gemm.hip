@@ -994,13 +994,15 @@ SWAT_API int swat_gemm_prof_begin(int max_launches) {
     return 0;
 }
 
-// Stop, synchronise the events and report per kind — 12 entries: layout * 3 + {64-row tile, 128-row / 256-row tile, producer /
+// Stop, synchronise the events and report per kind — 16 entries: layout * 3 + {64-row tile, 128-row / 256-row tile, producer /
 // consumer} for NT / NN / TN, then 9 = the persistent forward (csrc/vit_mega.hip: all blocks' products, LayerNorms and
-// attention in one launch), 10-11 unused: total ms, launches, flops.
+// attention in one launch), 10 = a block's weight gradients as one launch of 256 x 128 tiles, 11 = the 256 x 128 loader /
+// consumer kernel on NT / NN products, 12 = the persistent backward (data gradients of all blocks), 13-15 unused: total ms,
+// launches, flops.
 SWAT_API int swat_gemm_prof_end(double* ms_by_kind, int64_t* count_by_kind, double* flops_by_kind) {
     using swat::g_prof;
     g_prof.on = false;
-    for (int k = 0; k < 12; ++k) { ms_by_kind[k] = 0; count_by_kind[k] = 0; flops_by_kind[k] = 0; }
+    for (int k = 0; k < 16; ++k) { ms_by_kind[k] = 0; count_by_kind[k] = 0; flops_by_kind[k] = 0; }
     for (int i = 0; i < g_prof.n; ++i) {
         SWAT_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
         float ms = 0.f;

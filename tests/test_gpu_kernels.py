@@ -200,7 +200,7 @@ def test_block_weight_gradients_as_one_launch_of_256x128_tiles(shapes):
         run()
     finally:
         lib.swat_gemm_set_wgrad_big(1)
-        ms, cnt, fl = (ctypes.c_double * 12)(), (ctypes.c_int64 * 12)(), (ctypes.c_double * 12)()
+        ms, cnt, fl = (ctypes.c_double * 16)(), (ctypes.c_int64 * 16)(), (ctypes.c_double * 16)()
         lib.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
     assert cnt[10] == 2 and sum(cnt) == 2, "both calls must have been the grouped 256 x 128 launch"
     for (M, N, K, bias), dy, x, dw, db, f in zip(shapes, dys, xs, dws, dbs, first):
@@ -633,7 +633,7 @@ def test_gemm_256x128_loader_consumer_tile_epilogues(layout, epi, M):
             assert torch.equal(C, again)
     finally:
         lib.swat_gemm_set_tile(-1)
-        ms, cnt, fl = (ctypes.c_double * 12)(), (ctypes.c_int64 * 12)(), (ctypes.c_double * 12)()
+        ms, cnt, fl = (ctypes.c_double * 16)(), (ctypes.c_int64 * 16)(), (ctypes.c_double * 16)()
         lib.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
     assert cnt[11] >= 1, "the product must have gone through the 256 x 128 loader / consumer kernel"
 

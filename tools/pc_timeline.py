@@ -22,7 +22,7 @@ def run(name, cfg, exp, odt=torch.bfloat16):
     L.swat_gemm_prof_begin(4)
     ops.gemm(layout, A, B, m, n, k, lda, ldb, C, n)
     torch.cuda.synchronize()
-    ms = (ctypes.c_double * 12)(); cnt = (ctypes.c_int64 * 12)(); fl = (ctypes.c_double * 12)()
+    ms = (ctypes.c_double * 16)(); cnt = (ctypes.c_int64 * 16)(); fl = (ctypes.c_double * 16)()
     L.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
     L.swat_gemm_set_tile(-1); L.swat_gemm_set_exp(0); L.swat_gemm_set_trace(None)
     t = buf.cpu().numpy().reshape(-1, 8); t = t[t[:, 0] != 0]

@@ -20,7 +20,7 @@ def timeit(layout, A, B, m, n, k, lda, ldb, C):
     for _ in range(20):
         ops.gemm(layout, A, B, m, n, k, lda, ldb, C, n)
     torch.cuda.synchronize()
-    ms = (ctypes.c_double * 12)(); cnt = (ctypes.c_int64 * 12)(); fl = (ctypes.c_double * 12)()
+    ms = (ctypes.c_double * 16)(); cnt = (ctypes.c_int64 * 16)(); fl = (ctypes.c_double * 16)()
     L.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
     return sum(ms) / 20 * 1e3
 print("exp bits: 1 = no loads after the prologue, 2 = no LDS reads / MFMA, 4 = no epilogue, 8 = no k-skew; times in us")

@@ -37,7 +37,7 @@ def run(layout, m, n, k, epi, cfg):
     for _ in range(10):
         ops.gemm(layout, A, B, m, n, k, lda, ldb, C, n, **kw)
     torch.cuda.synchronize()
-    ms = (ctypes.c_double * 12)(); cnt = (ctypes.c_int64 * 12)(); fl = (ctypes.c_double * 12)()
+    ms = (ctypes.c_double * 16)(); cnt = (ctypes.c_int64 * 16)(); fl = (ctypes.c_double * 16)()
     L.swat_gemm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p))
     L.swat_gemm_set_tile(-1)
     return sum(ms) / 10 * 1e3

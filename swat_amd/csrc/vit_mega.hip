@@ -741,6 +741,22 @@ struct MegaBwd {
     unsigned long long* trace;
 };
 
+// Warm the L2 with lines a LATER part of the phase will load (saved activations of the forward: in HBM by now): the four consumer
+// waves, which otherwise only wait for the first stages, pull one dword of every 128-B line through the LDS-DMA path into a
+// 256-B scratch slot above the operand ring — no registers, nothing waits for it (the next compiler-placed vmcnt(0) of these
+// waves is behind the product).  nrows rows of `lines` 128-B lines each.
+__device__ __forceinline__ void mg_prefetch(unsigned char* smem, const void* base, int64_t row_stride_bytes, int nrows, int lines) {
+    const int tid = threadIdx.x;
+    if (tid >= 64 * MG_NC) return;
+    unsigned char* slot = smem + MG_LDS - 1024 + (tid >> 6) * 256;
+    const int total = nrows * lines;
+    for (int i = tid; i < total; i += 64 * MG_NC) {
+        const int r = i / lines, c = i - r * lines;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + r * row_stride_bytes + c * 128),
+                                         (__attribute__((address_space(3))) void*)slot, 4, 0, 0);
+    }
+}
+
 // fp32 tile cl[112][BN + 4] (BN = 48) -> out rows, write-through
 __device__ __forceinline__ void mg_epi_f32(const float* cl, float* out, int64_t ld, int rows, int tid) {
     const int cc = tid % 12, r0 = tid / 12;
@@ -868,36 +884,74 @@ __device__ __forceinline__ void mg_ln_bwd(unsigned char* smem, int d, const floa
             dcs[i].z += __uint_as_float(p1 << 16); dcs[i].w += __uint_as_float(p1 & 0xffff0000u);
         }
     }
-    float* sh = reinterpret_cast<float*>(smem);   // [7][d]
+    float* sh = reinterpret_cast<float*>(smem);   // [3][7][d]: all three quantities in one pass (64.5 KB)
+    if (wave < 7) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        if (wave < 7) {
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                reinterpret_cast<float4*>(sh + wave * d)[lane + 64 * i] = q == 0 ? dg[i] : (q == 1 ? db[i] : dcs[i]);
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < d; c += MG_THREADS) {
-            float v = sh[c];
-#pragma unroll
-            for (int w = 1; w < 7; ++w) v += sh[w * d + c];
-            part[q * d + c] = v;
-        }
-        __syncthreads();
+                reinterpret_cast<float4*>(sh + (q * 7 + wave) * d)[lane + 64 * i] = q == 0 ? dg[i] : (q == 1 ? db[i] : dcs[i]);
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 3 * d; c += MG_THREADS) {
+        const int q = c / d, cc = c - q * d;
+        float v = sh[q * 7 * d + cc];
+#pragma unroll
+        for (int w = 1; w < 7; ++w) v += sh[(q * 7 + w) * d + cc];
+        part[c] = v;
+    }
+    __syncthreads();
 }
 
 // attention backward of one (image, head): 4 waves (w = query / key rows 16w ..), tiles [64][ATP] of this image group in LDS:
-// qt, kt (staged from the saved qkv), dot_ (the head's columns of da, bf16), dst / pt (written here).  Arithmetic and rounding
+// qt, kt, vt (staged from the saved qkv), dot_ (the head's columns of da, bf16), dst / pt (written here).  Arithmetic and rounding
 // points of attn_bwd_small_kernel (csrc/attention.hip); `live` = false: a group without an image in this pass (it keeps the
 // workgroup barriers, stores nothing).
-__device__ __forceinline__ void mg_attn_bwd(const unsigned short* base /* q of the image's row 0, this head */, int64_t ld, int d, int T,
-                                            const unsigned short* qt, const unsigned short* kt, const unsigned short* dot_, unsigned short* dst,
-                                            unsigned short* pt, unsigned short* dbase, int w, int lane, float scale, bool live) {
+__device__ __forceinline__ void mg_attn_bwd(int64_t ld, int d, int T, const unsigned short* qt, const unsigned short* kt, const unsigned short* vt,
+                                            const unsigned short* dot_, unsigned short* dst, unsigned short* pt, unsigned short* dbase, int w,
+                                            int lane, float scale, bool live) {
     const int r16 = lane & 15, g = lane >> 4;
-    af32x4_t p[4];
-    scores_softmax(base, ld, d, T, w, r16, g, scale, p);
     const int q = w * 16 + r16, qq = q < T ? q : T - 1;
+    // S = Q K^T and the row softmax: scores_softmax (csrc/attention.hpp) with the q / k fragments from the tiles (rows >= T hold
+    // row T-1: the same clamping)
+    af32x4_t p[4];
+    {
+        abf16x8_t qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(qt + qq * ATP + 32 * ks + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = 16 * j + r16;
+            p[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                p[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(kt + key * ATP + 32 * ks + 8 * g), qf[ks], p[j], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = 16 * j + 4 * g + e;
+                p[j][e] = key < T ? p[j][e] * scale : -INFINITY;
+                mx = fmaxf(mx, p[j][e]);
+            }
+        mx = xor_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = 16 * j + 4 * g + e;
+                p[j][e] = key < T ? __expf(p[j][e] - mx) : 0.f;
+                sum += p[j][e];
+            }
+        const float inv = 1.0f / xor_sum(sum);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[j][e] = bf2f(f2bf(p[j][e] * inv));
+    }
     abf16x8_t dof[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) dof[ks] = ld_frag(dot_ + qq * ATP + 32 * ks + 8 * g);
@@ -905,11 +959,11 @@ __device__ __forceinline__ void mg_attn_bwd(const unsigned short* base /* q of t
     float dot = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int key = 16 * j + r16, kk = key < T ? key : T - 1;
+        const int key = 16 * j + r16;
         ds[j] = (af32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            ds[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(base + 2 * d + (int64_t)kk * ld + 32 * ks + 8 * g), dof[ks], ds[j], 0, 0, 0);
+            ds[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(vt + key * ATP + 32 * ks + 8 * g), dof[ks], ds[j], 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) dot += p[j][e] * ds[j][e];
     }
@@ -1021,6 +1075,7 @@ __global__ __launch_bounds__(MG_THREADS) void vit_bwd_mega_kernel(const MegaBwd 
             // ---------------- PRJ': dF = (dx W_proj) * act'(F) ----------------
             {
                 const int n0 = 192 * member;
+                mg_prefetch(smem, f + (int64_t)row0 * mlp + n0, (int64_t)mlp * 2, rows, 3);   // the epilogue's F tile
                 mg_gemm_nt<192, 4, 4, false>(smem, dxb_in + (int64_t)row0 * d, d, rows, wP);
                 MB_GEMM_DONE(0);
                 const float* cl = reinterpret_cast<const float*>(smem);
@@ -1032,6 +1087,10 @@ __global__ __launch_bounds__(MG_THREADS) void vit_bwd_mega_kernel(const MegaBwd 
             }
             MB_SYNC(wF, 192, 4, 0);
             // ---------------- FC': dh2[kg] = dF[:, quarter kg] W_fc[quarter kg, 192 ng ..] ----------------
+            {
+                const int r7 = 7 * member, n7 = rows - r7 < 7 ? rows - r7 : 7;
+                if (n7 > 0) mg_prefetch(smem, x1 + (int64_t)(row0 + r7) * d, (int64_t)d * 4, n7, d / 32);   // LN2' reads them next
+            }
             mg_gemm_nt<192, 4, 4, false>(smem, dfb + (int64_t)row0 * mlp + kg * (mlp >> 2), mlp, rows, wF);
             MB_GEMM_DONE(1);
             mg_epi_f32_wide(reinterpret_cast<const float*>(smem), dh2 + (int64_t)kg * M * d + (int64_t)row0 * d + 192 * ng, d, rows, tid);
@@ -1043,13 +1102,14 @@ __global__ __launch_bounds__(MG_THREADS) void vit_bwd_mega_kernel(const MegaBwd 
             // ---------------- OUT' + attention backward (member = head) ----------------
             if (member < p.H) {
                 const int h = member;
+                mg_prefetch(smem, qkv + (int64_t)row0 * 3 * d + 64 * h, (int64_t)d * 2, 3 * rows, 1);   // q | k | v head slices: rows of 128 B at stride d
                 mg_gemm_nt<64, 4, 6, false>(smem, dxb2 + (int64_t)row0 * d, d, rows, wO);
                 MB_GEMM_DONE(3);
                 const float* cl = reinterpret_cast<const float*>(smem);          // [112][68] fp32: da of this head
-                unsigned short* tiles = reinterpret_cast<unsigned short*>(smem + MG_ROWS * 68 * 4);   // 2 groups x {qt, kt, dot_, dst, pt}
+                unsigned short* tiles = reinterpret_cast<unsigned short*>(smem + MG_ROWS * 68 * 4);   // 2 groups x {qt, kt, vt, dot_, dst, pt}
                 const int grp = tid >> 8, gt = tid & 255;
-                unsigned short* qt = tiles + grp * 5 * 64 * ATP;
-                unsigned short *kt = qt + 64 * ATP, *dot_ = kt + 64 * ATP, *dst = dot_ + 64 * ATP, *pt = dst + 64 * ATP;
+                unsigned short* qt = tiles + grp * 6 * 64 * ATP;
+                unsigned short *kt = qt + 64 * ATP, *vt = kt + 64 * ATP, *dot_ = vt + 64 * ATP, *dst = dot_ + 64 * ATP, *pt = dst + 64 * ATP;
                 for (int im0 = 0; im0 < nimg; im0 += 2) {
                     const bool live = im0 + grp < nimg;
                     const int im = live ? im0 + grp : nimg - 1;
@@ -1060,6 +1120,7 @@ __global__ __launch_bounds__(MG_THREADS) void vit_bwd_mega_kernel(const MegaBwd 
                         const int rr = row < T ? row : T - 1;
                         *reinterpret_cast<au32x4_t*>(qt + row * ATP + ch * 8) = *reinterpret_cast<const au32x4_t*>(base + (int64_t)rr * 3 * d + ch * 8);
                         *reinterpret_cast<au32x4_t*>(kt + row * ATP + ch * 8) = *reinterpret_cast<const au32x4_t*>(base + d + (int64_t)rr * 3 * d + ch * 8);
+                        *reinterpret_cast<au32x4_t*>(vt + row * ATP + ch * 8) = *reinterpret_cast<const au32x4_t*>(base + 2 * d + (int64_t)rr * 3 * d + ch * 8);
                         const float* c = cl + (im * T + rr) * 68 + ch * 8;
                         const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
                         au32x4_t pk;
@@ -1068,12 +1129,16 @@ __global__ __launch_bounds__(MG_THREADS) void vit_bwd_mega_kernel(const MegaBwd 
                         *reinterpret_cast<au32x4_t*>(dot_ + row * ATP + ch * 8) = pk;
                     }
                     __syncthreads();
-                    mg_attn_bwd(base, 3 * (int64_t)d, d, T, qt, kt, dot_, dst, pt, dqkv + (int64_t)(row0 + im * T) * 3 * d + 64 * h, wave & 3, lane,
+                    mg_attn_bwd(3 * (int64_t)d, d, T, qt, kt, vt, dot_, dst, pt, dqkv + (int64_t)(row0 + im * T) * 3 * d + 64 * h, wave & 3, lane,
                                 scale, live);
                 }
             }
             MB_SYNC(wI, 192, 4, 3);
             // ---------------- IN': dh1[kg] = dqkv[:, quarter kg] W_in[quarter kg, 192 ng ..] ----------------
+            {
+                const int r7 = 7 * member, n7 = rows - r7 < 7 ? rows - r7 : 7;
+                if (n7 > 0) mg_prefetch(smem, xin + (int64_t)(row0 + r7) * d, (int64_t)d * 4, n7, d / 32);   // LN1' reads them next
+            }
             mg_gemm_nt<192, 4, 4, false>(smem, dqkv + (int64_t)row0 * 3 * d + kg * ((3 * d) >> 2), 3 * d, rows, wI);
             MB_GEMM_DONE(4);
             mg_epi_f32_wide(reinterpret_cast<const float*>(smem), dh1 + (int64_t)kg * M * d + (int64_t)row0 * d + 192 * ng, d, rows, tid);

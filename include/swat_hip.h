@@ -327,6 +327,22 @@ swat_stream_t swat_vit_aux_stream(int i); /* i = 0, 1: two more process-wide str
 int swat_vit_lane_order(swat_stream_t stream); /* `stream` waits for what the lane holds now; the lane is not joined */
 int swat_vit_lane_follow(swat_stream_t stream); /* the lane waits for what `stream` holds now (then work may be queued on swat_vit_lane_stream()) */
 int swat_vit_backward_join(swat_stream_t stream);
+/* AdamW (ref utils/optimizers.py:131-146, torch.optim.AdamW) of the blocks' parameters INSIDE the next swat_vit_backward call that
+ *     covers all blocks (stage_hi >= L, stage_lo <= 1) and runs them as the persistent backward: block by block beside the next
+ *     block's weight-gradient launch, or in the epilogue of the weight-gradient launch (swat_vit_set_block_adamw) — same
+ *     arithmetic as swat_adamw, one learning-rate group.
+ *     Pointers are the arena bases (params / grads / shadow must be the ones the backward call is given; lr_dev, bias_corr_dev:
+ *     DEVICE scalars as for swat_adamw).  The arming is used or dropped by that one call; swat_vit_fused_adamw_consumed() then says
+ *     (and clears) whether the blocks' range has been stepped — if not (shape not served, data-parallel run), the caller launches
+ *     swat_adamw for it as usual.  Single-process training only: a data-parallel step reduces the gradients first. */
+int swat_vit_arm_fused_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                             const float* lr_dev, const float* bias_corr_dev, float beta1, float beta2, float eps,
+                             float weight_decay, float grad_scale);
+int swat_vit_fused_adamw_consumed(void);
+/* How an armed AdamW runs: 1 (default; env SWAT_BLOCK_ADAMW) piped — per block on a second internal stream beside the next
+ *     block's weight-gradient launch; 2 inside the epilogue of ONE weight-gradient launch over all blocks (the gradient tile never
+ *     goes to memory); 0 not at all (the arming is dropped, the caller's own launch follows).  Results are bit-identical. */
+int swat_vit_set_block_adamw(int mode);
 /* A3+A4+A6 fused with their backward (ref utils/training.py:1475-1481): loss, d/dfeats, d/dW_head,
  *     d/dlogit_scale.  want_grad = 0: forward only (validate, testing.py:430-447); z_out / feat_norm_out
  *     optionally receive the un-scaled head output and the normalised features.  normalize = 0: feats are

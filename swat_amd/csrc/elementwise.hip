@@ -474,6 +474,54 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// the same update for up to 128 short ranges of the arena (one workgroup per range: biases and LayerNorm weights between the
+// matrices whose AdamW runs in the weight-gradient epilogue, csrc/gemm_xl.hip); one learning-rate group
+struct AdamRanges {
+    int64_t begin[128];
+    int len[128];
+};
+__global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, unsigned short* __restrict__ shadow, const AdamRanges r,
+                                                           const float* __restrict__ lrs, float beta1, float beta2, float eps, float wd,
+                                                           const float* __restrict__ bc, float grad_scale, const unsigned* __restrict__ guard) {
+    if (guard && __builtin_nontemporal_load(guard) != 0u) return;
+    const float bc1 = bc[0], sbc2 = sqrtf(bc[1]), lr = lrs[0];
+    const int64_t b = r.begin[blockIdx.x];
+    const int n4 = r.len[blockIdx.x] >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const int64_t e = b + 4 * (int64_t)i;
+        const float4 pn = *reinterpret_cast<const float4*>(p + e), gn = *reinterpret_cast<const float4*>(g + e);
+        const float4 mn = *reinterpret_cast<const float4*>(m + e), vn = *reinterpret_cast<const float4*>(v + e);
+        float pa[4] = {pn.x, pn.y, pn.z, pn.w}, ga[4] = {gn.x, gn.y, gn.z, gn.w}, ma[4] = {mn.x, mn.y, mn.z, mn.w}, va[4] = {vn.x, vn.y, vn.z, vn.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = ga[k] * grad_scale;
+            pa[k] *= 1.0f - lr * wd;
+            ma[k] = beta1 * ma[k] + (1.0f - beta1) * gg;
+            va[k] = beta2 * va[k] + (1.0f - beta2) * gg * gg;
+            const float denom = sqrtf(va[k]) / sbc2 + eps;
+            pa[k] -= (lr / bc1) * (ma[k] / denom);
+        }
+        *reinterpret_cast<float4*>(p + e) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+        *reinterpret_cast<float4*>(m + e) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+        *reinterpret_cast<float4*>(v + e) = make_float4(va[0], va[1], va[2], va[3]);
+        if (shadow) *reinterpret_cast<ushort4*>(shadow + e) = make_ushort4(f2bf(pa[0]), f2bf(pa[1]), f2bf(pa[2]), f2bf(pa[3]));
+    }
+}
+
+int launch_adamw_ranges(const int64_t* begin, const int* len, int n, const XlAdam& ad, hipStream_t s) {
+    if (n < 1 || n > 128) return 1;
+    AdamRanges r{};
+    for (int i = 0; i < n; ++i) {
+        if (begin[i] % 4 || len[i] % 4) return 1;
+        r.begin[i] = begin[i];
+        r.len[i] = len[i];
+    }
+    hipLaunchKernelGGL(adamw_ranges_kernel, dim3(n), dim3(256), 0, s, ad.p, ad.gbase, ad.m, ad.v, ad.shadow, r, ad.lr, ad.b1, ad.b2, ad.eps, ad.wd, ad.bc,
+                       ad.gscale, ad.guard);
+    return check_launch("adamw_ranges_kernel");
+}
+
 __global__ void cast_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int64_t n) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {

@@ -880,11 +880,28 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
 
 // n products of one layout (the weight gradients of a transformer block): ONE persistent launch over the joint tile list
 // when every product qualifies for the producer / consumer kernel's grouped form, else one launch each.
+static int g_wgrad_all = getenv("SWAT_WGRAD_ALL") ? atoi(getenv("SWAT_WGRAD_ALL")) : 1;   // all blocks' weight gradients behind the persistent backward: 1 = one launch, 0 = one per block
 static int g_wgrad_big = getenv("SWAT_WGRAD_BIG") ? atoi(getenv("SWAT_WGRAD_BIG")) : 1;   // swat_gemm_set_wgrad_big: 0 = never, 1 = when the joint list is one round of 256 x 128 tiles, 2 = always
 
 // the weight gradients of a block as ONE round of 256 x 128 tiles (gemm_wgrad.hip): taken when the joint tile list fills most of
 // the chip once — more tiles than CUs would run a second, mostly empty round at a whole tile's latency each.
 // -> 0 launched, 1 not taken (the caller goes on with its own route), < 0 error
+// all weight gradients of a tower's blocks (up to 64 products) as one persistent launch over the joint list of 256 x 128 tiles
+int wgrad_all_try(const GemmArgs* probs, int n, hipStream_t s, const XlAdam* adam) {
+    if (!g_wgrad_big || g_wgrad_all == 0 || n < 1 || n > 64 || g_force_cfg >= 0 || (g_exp & 4096)) return 1;
+    const bool prof = g_prof.on && g_prof.n < g_prof.cap;
+    hipEvent_t ev0 = prof ? g_prof.ev[2 * g_prof.n] : nullptr, ev1 = prof ? g_prof.ev[2 * g_prof.n + 1] : nullptr;
+    const int rc = launch_gemm_xl_table(probs, n, s, ev0, ev1, adam);
+    if (prof && rc == 0) {
+        g_prof.kind[g_prof.n] = 10;
+        double fl = 0;
+        for (int i = 0; i < n; ++i) fl += 2.0 * probs[i].M * probs[i].N * probs[i].K;
+        g_prof.flops[g_prof.n] = fl;
+        ++g_prof.n;
+    }
+    return rc;
+}
+
 int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s, bool dry_run) {
     if (!g_wgrad_big || n < 1 || n > 8 || g_force_cfg >= 0) return 1;
     int tiles = 0;

@@ -30,6 +30,7 @@
 //     or 4 (k-strided) address registers per operand and everything else is an immediate.
 // Shapes: M % 256 == 0, N % 128 == 0, K % 64 == 0 (the dispatcher cuts other shapes into a served part and a remainder).
 #include <hip/hip_ext.h>
+#include <string.h>
 #include <type_traits>
 #include <utility>
 #include "gemm_device.hpp"
@@ -51,6 +52,15 @@ struct XlArgs {
     int n, total;
     unsigned long long* trace;   // ablation build, exp bit 16
     int exp;                     // ablation build (swat_gemm_set_exp): 1 no DMA after the first ring fill, 2 no MFMA, 4 no epilogue, 256 no fragment reads
+};
+// the same with the product list in device memory: up to XL_MAXT products (all weight gradients of a tower in one launch)
+constexpr int XL_MAXT = 64;
+struct XlArgsTable {
+    const XlProb* p;
+    int n, total;
+    unsigned long long* trace;
+    int exp;
+    XlAdam adam;   // on != 0: the tiles are consumed by AdamW in the epilogue instead of being stored as gradients
 };
 
 template <int IMM>
@@ -90,11 +100,17 @@ __device__ __forceinline__ void xl_static_for(F&& f) { xl_static_for_impl<N_>(f,
 struct XlTile {
     int pi, m0, n0, tn;
 };
-__device__ __forceinline__ XlTile xl_decode(const XlArgs& a, int id) {
+template <class Args>
+__device__ __forceinline__ XlTile xl_decode(const Args& a, int id) {
     int pi = 0;
+    if constexpr (std::is_same<Args, XlArgs>::value) {
 #pragma unroll
-    for (int i = 1; i < XL_MAXP; ++i)
-        if (i < a.n && id >= a.p[i].tile0) pi = i;
+        for (int i = 1; i < XL_MAXP; ++i)
+            if (i < a.n && id >= a.p[i].tile0) pi = i;
+    } else {
+        for (int i = 1; i < a.n; ++i)
+            if (id >= a.p[i].tile0) pi = i;
+    }
     const int t = id - a.p[pi].tile0, tmn = a.p[pi].tiles_m, tnn = a.p[pi].tiles_n;
     int tm, tn;
     if ((tmn & 7) == 0 && (tnn & 3) == 0) {
@@ -219,8 +235,8 @@ __device__ __forceinline__ void xl_epilogue(const GemmArgs& p, f32x4_t (&acc)[4]
     else xl_epi_bf16<false, false>(p, acc, mbase, nbase, lane);
 }
 
-template <int LAYOUT, bool ABL>
-__global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const XlArgs a) {
+template <int LAYOUT, bool ABL, class Args = XlArgs>
+__global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const Args a) {
     constexpr bool A_KC = (LAYOUT != L_TN);
     constexpr bool B_KC = (LAYOUT == L_NT);
     __shared__ __attribute__((aligned(1024))) unsigned char smem[XL_NS * XL_STAGE];
@@ -449,6 +465,23 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const XlArgs a) {
     };
 
     if (t_first >= t_end) return;
+    // AdamW scalars of the fused epilogue (table form): this step's learning rate and bias corrections, the give-up guard
+    float ad_lr = 0.f, ad_bc1 = 1.f, ad_sbc2 = 1.f;
+    bool adam_live = false;
+    if constexpr (std::is_same<Args, XlArgsTable>::value) {
+        if (a.adam.on) {
+            ad_lr = a.adam.lr[0];
+            ad_bc1 = a.adam.bc[0];
+            ad_sbc2 = sqrtf(a.adam.bc[1]);
+            adam_live = !(a.adam.guard && __builtin_nontemporal_load(a.adam.guard) != 0u);
+            // Stagger.  Every workgroup alternates a main loop (matrix cores, ~34 us) and an AdamW epilogue (852 KB of HBM traffic);
+            // launched together they stay in lock-step — all epilogues at once, HBM-bound, then all main loops with the HBM idle.
+            // Four phase groups start a quarter of a cycle apart, so that at any time about a quarter of the chip streams
+            // parameters while the rest multiplies.
+            const unsigned long long t0 = wall_clock64(), dl = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned)a.adam.stagger;
+            while (wall_clock64() - t0 < dl) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     stamp(1);
     xl_bar();   // opening barrier: k-tile 0 of the first tile has landed
     stamp(2);
@@ -487,11 +520,50 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const XlArgs a) {
             if constexpr (LAYOUT == L_TN) {
                 // weight gradient: plain fp32 tile (gemm_xl_serves admits no fused epilogue here) — 16-byte stores, no operand loads
                 float* C = reinterpret_cast<float*>(G.C) + (int64_t)(T.m0 + 64 * wr + (lane_e & 15)) * G.ldc + T.n0 + 64 * wc + 4 * (lane_e >> 4);
+                bool adam = false;
+                if constexpr (std::is_same<Args, XlArgsTable>::value) adam = a.adam.on != 0;
+                if (adam) {
+                    if constexpr (std::is_same<Args, XlArgsTable>::value) {
+                        if (adam_live) {
+                            const int64_t off = C - a.adam.gbase;
+                            typedef float nt4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                            for (int i = 0; i < 4; ++i) {
+                                const int64_t ro = off + (int64_t)16 * i * G.ldc;
+                                nt4 pn[4], mn[4], vn[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        *reinterpret_cast<f32x4_t*>(C + (int64_t)16 * i * G.ldc + 16 * j) = acc[i][j];
+                                for (int j = 0; j < 4; ++j) {   // a row of fragments: 12 loads in flight
+                                    pn[j] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(a.adam.p + ro + 16 * j));
+                                    mn[j] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(a.adam.m + ro + 16 * j));
+                                    vn[j] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(a.adam.v + ro + 16 * j));
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    float pa[4], ma[4], va[4];
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        const float gg = acc[i][j][k] * a.adam.gscale;
+                                        pa[k] = pn[j][k] * (1.0f - ad_lr * a.adam.wd);
+                                        ma[k] = a.adam.b1 * mn[j][k] + (1.0f - a.adam.b1) * gg;
+                                        va[k] = a.adam.b2 * vn[j][k] + (1.0f - a.adam.b2) * gg * gg;
+                                        const float denom = sqrtf(va[k]) / ad_sbc2 + a.adam.eps;
+                                        pa[k] -= (ad_lr / ad_bc1) * (ma[k] / denom);
+                                    }
+                                    __builtin_nontemporal_store((nt4){pa[0], pa[1], pa[2], pa[3]}, reinterpret_cast<nt4*>(a.adam.p + ro + 16 * j));
+                                    __builtin_nontemporal_store((nt4){ma[0], ma[1], ma[2], ma[3]}, reinterpret_cast<nt4*>(a.adam.m + ro + 16 * j));
+                                    __builtin_nontemporal_store((nt4){va[0], va[1], va[2], va[3]}, reinterpret_cast<nt4*>(a.adam.v + ro + 16 * j));
+                                    *reinterpret_cast<ushort4*>(a.adam.shadow + ro + 16 * j) = make_ushort4(f2bf(pa[0]), f2bf(pa[1]), f2bf(pa[2]), f2bf(pa[3]));
+                                }
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            *reinterpret_cast<f32x4_t*>(C + (int64_t)16 * i * G.ldc + 16 * j) = acc[i][j];
+                }
             } else {
                 xl_epilogue(G, acc, T.m0 + 64 * wr, T.n0 + 64 * wc, lane_e);
             }
@@ -557,6 +629,59 @@ int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipE
     else XL_LAUNCH(L_TN);
 #undef XL_LAUNCH
     return check_launch("gemm_xl_kernel");
+}
+
+// up to 64 weight gradients (TN) over one joint tile list, the product list in device memory.  The table lives in a per-device
+// buffer and is re-sent only when it changes (a training step asks for the same pointers every time).  -> 0 / 1 not served / < 0
+int launch_gemm_xl_table(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const XlAdam* adam) {
+    if (n < 1 || n > XL_MAXT) return 1;
+    struct Cache {
+        XlProb* dev = nullptr;
+        XlProb* pinned[4] = {nullptr, nullptr, nullptr, nullptr};
+        XlProb last[XL_MAXT];
+        int n = 0, slot = 0;
+        hipStream_t last_stream = nullptr;
+    };
+    static Cache cache[16];
+    int devi = 0;
+    if (hipGetDevice(&devi) != hipSuccess || devi < 0 || devi >= 16) return 1;
+    Cache& c = cache[devi];
+    XlProb t[XL_MAXT];
+    memset(t, 0, sizeof(t));
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!gemm_xl_serves(L_TN, probs[i])) return 1;
+        t[i].g = probs[i];
+        t[i].tiles_m = probs[i].M / XL_BM;
+        t[i].tiles_n = probs[i].N / XL_BN;
+        t[i].tile0 = total;
+        total += t[i].tiles_m * t[i].tiles_n;
+    }
+    if (total == 0) return 1;
+    if (!c.dev) {
+        if (hipMalloc((void**)&c.dev, sizeof(XlProb) * XL_MAXT) != hipSuccess) return -1;
+        for (int k = 0; k < 4; ++k)
+            if (hipHostMalloc((void**)&c.pinned[k], sizeof(XlProb) * XL_MAXT, hipHostMallocDefault) != hipSuccess) return -1;
+    }
+    if (c.n != n || memcmp(c.last, t, sizeof(XlProb) * n) != 0) {
+        // stream-ordered behind the launches that read the old table; the staging slot is not rewritten before three more changes
+        XlProb* stage = c.pinned[c.slot];
+        c.slot = (c.slot + 1) & 3;
+        memcpy(stage, t, sizeof(XlProb) * n);
+        SWAT_HIP(hipMemcpyAsync(c.dev, stage, sizeof(XlProb) * n, hipMemcpyHostToDevice, s));
+        memcpy(c.last, t, sizeof(XlProb) * n);
+        c.n = n;
+        c.last_stream = s;
+    } else if (c.last_stream != s) {
+        return 1;   // the table was sent on another stream: not ordered with this launch — the caller takes the per-block launches
+    }
+    XlArgsTable a{};
+    a.p = c.dev; a.n = n; a.total = total; a.trace = nullptr; a.exp = 0;
+    if (adam) a.adam = *adam;
+    const dim3 grid(total < 256 ? total : 256), block(XL_THREADS);
+    if (ev0) hipExtLaunchKernelGGL((gemm_xl_kernel<L_TN, false, XlArgsTable>), grid, block, 0, s, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((gemm_xl_kernel<L_TN, false, XlArgsTable>), grid, block, 0, s, a);
+    return check_launch("gemm_xl_kernel (table)");
 }
 
 }  // namespace swat

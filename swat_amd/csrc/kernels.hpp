@@ -53,6 +53,25 @@ int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t e
 // 256 x 128 tiles, loader / consumer waves, persistent over the joint tile list of n <= 8 products of one layout (gemm_xl.hip)
 bool gemm_xl_serves(int layout, const GemmArgs& g);
 int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp = 0, unsigned long long* trace = nullptr);
+// AdamW applied to a weight-gradient tile while it is still in the accumulators (torch.optim.AdamW semantics and the arithmetic of
+// adamw_kernel, csrc/elementwise.hip — ref utils/optimizers.py:131-146): the gradient is never written; parameter, moments and the
+// bf16 shadow are read / written at the arena offset of the product's output (C - gbase).  One learning-rate group.
+struct XlAdam {
+    int on;
+    const float* gbase;           // arena.grad
+    float *p, *m, *v;             // arena.flat, exp_avg, exp_avg_sq
+    unsigned short* shadow;
+    const float *lr, *bc;         // device scalars: lr of the group; {1 - b1^t, 1 - b2^t}
+    float b1, b2, eps, wd, gscale;
+    const unsigned* guard;        // non-zero: a persistent launch of the step gave up — leave everything as it is
+    int stagger;                  // start offset between the four phase groups of workgroups, 100 MHz ticks (gemm_xl.hip)
+};
+// up to 64 weight gradients (TN) as ONE launch, the product list in device memory (gemm_xl.hip); adam != null: consumed by AdamW in
+// the epilogue.  wgrad_all_try: policy + timing slot
+int launch_gemm_xl_table(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const XlAdam* adam = nullptr);
+int wgrad_all_try(const GemmArgs* probs, int n, hipStream_t s, const XlAdam* adam = nullptr);
+// AdamW of up to 128 short arena ranges (biases, LayerNorm weights between the matrices) in one launch (elementwise.hip)
+int launch_adamw_ranges(const int64_t* begin, const int* len, int n, const XlAdam& ad, hipStream_t s);
 // M <= 64 rows (the remainder of a many-row product): one wave per 16 output columns (gemm_skinny.hip); -> 0 / 1 not served / < 0
 int launch_gemm_skinny(int layout, const GemmArgs& a, hipStream_t s);
 int wgrad_big_try(const GemmArgs* probs, int n, hipStream_t s, bool dry_run = false);   // policy + launch_wgrad_group (gemm.hip); same

@@ -8,6 +8,7 @@
 //
 // Numerics: fp32 master weights + bf16 shadow weights; GEMMs read bf16 operands and accumulate in fp32; the
 // residual stream, LayerNorm statistics, softmax, proj and everything after it are fp32.
+#include <stdlib.h>
 #include <vector>
 #include "kernels.hpp"
 #include "../../include/swat_hip.h"
@@ -519,6 +520,40 @@ SWAT_API int swat_vit_backward_join(swat_stream_t stream) {
 //   stage L+1 : proj + ln_post (needs dfeats);  stage l+1 : block l;  stage 0 : ln_pre + embeddings + conv1.
 // Call with stage_hi >= stage_lo; stages run from stage_hi down to stage_lo.  Gradients are WRITTEN (not
 // accumulated) into `grads` at the parameters' own offsets.
+// AdamW inside the weight-gradient launch of the persistent backward (csrc/gemm_xl.hip): armed by the optimizer's owner for the NEXT
+// swat_vit_backward call that covers all blocks; that call clears it whether it used it or not
+struct FusedAdamState {
+    bool armed = false, consumed = false;
+    XlAdam ad{};
+};
+static FusedAdamState g_fused_adam;
+static int g_block_adamw = -1;   // swat_vit_set_block_adamw / SWAT_BLOCK_ADAMW: what an armed AdamW becomes (0 ignored, 1 piped, 2 epilogue)
+
+SWAT_API int swat_vit_arm_fused_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                                      const float* lr_dev, const float* bias_corr_dev, float beta1, float beta2, float eps,
+                                      float weight_decay, float grad_scale) {
+    SWAT_REQUIRE(params && grads && exp_avg && exp_avg_sq && shadow_bf16 && lr_dev && bias_corr_dev, "swat_vit_arm_fused_adamw: null pointer");
+    XlAdam& a = g_fused_adam.ad;
+    a.on = 1; a.gbase = grads; a.p = params; a.m = exp_avg; a.v = exp_avg_sq; a.shadow = (unsigned short*)shadow_bf16;
+    a.lr = lr_dev; a.bc = bias_corr_dev; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.gscale = grad_scale;
+    a.guard = nullptr;
+    g_fused_adam.armed = true;
+    g_fused_adam.consumed = false;
+    return 0;
+}
+SWAT_API int swat_vit_set_block_adamw(int mode) {
+    SWAT_REQUIRE(mode >= 0 && mode <= 2, "swat_vit_set_block_adamw: mode must be 0, 1 or 2");
+    g_block_adamw = mode;
+    return 0;
+}
+// 1: the last swat_vit_backward over all blocks applied AdamW to every parameter of the blocks itself (the caller skips its own
+// launch for that arena range); reading clears it
+SWAT_API int swat_vit_fused_adamw_consumed(void) {
+    const bool c = g_fused_adam.consumed;
+    g_fused_adam.consumed = false;
+    return c ? 1 : 0;
+}
+
 SWAT_API int swat_vit_backward_blocks_fused(const int32_t* dims) {
     VitDims D;
     if (parse_dims(dims, D) != 0 || !D.save || g_group_wgrad) return 0;
@@ -616,6 +651,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             const int64_t lnp = vit_mega_backward_lnp_bytes(D.B, d) / 4;
             std::vector<const float*> parts;
             std::vector<float*> dgs, dbs_, dcs;
+            std::vector<GemmArgs> wg;
             for (int l = D.L - 1; l >= 0; --l) {
                 const int64_t* lo = O.layer + 12 * l;
                 const void* dys[4] = {w.mb_dxb + (int64_t)l * D.Mp * d, w.mb_dfb + (int64_t)l * D.Mp * mlp, w.mb_dxb2 + (int64_t)l * D.Mp * d,
@@ -624,14 +660,98 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                                       w.h1 + (int64_t)l * D.Mp * d};
                 float* dws[4] = {grads + lo[PRW], grads + lo[FCW], grads + lo[OUTW], grads + lo[QKVW]};
                 float* dbs[4] = {nullptr, grads + lo[FCB], nullptr, grads + lo[QKVB]};
-                const int rws[4] = {D.Mp, D.Mp, D.Mp, D.Mp}, nout[4] = {d, mlp, d, 3 * d}, nin[4] = {mlp, d, d, d};
-                const int ldy[4] = {d, mlp, d, 3 * d}, ldx[4] = {mlp, d, d, d};
-                TRY(swat_linear_wgrad_bias_group(4, dys, xs4, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                const int nout[4] = {d, mlp, d, 3 * d}, nin[4] = {mlp, d, d, d};
+                for (int i = 0; i < 4; ++i) {
+                    GemmArgs a = G(dys[i], xs4[i], dws[i], nout[i], nin[i], D.Mp, nout[i], nin[i], nin[i], 1);
+                    a.colsum = dbs[i];
+                    wg.push_back(a);
+                }
                 parts.push_back(w.mb_lnp2 + l * lnp); dgs.push_back(grads + lo[LN2W]); dbs_.push_back(grads + lo[LN2B]); dcs.push_back(grads + lo[OUTB]);
                 parts.push_back(w.mb_lnp1 + l * lnp); dgs.push_back(grads + lo[LN1W]); dbs_.push_back(grads + lo[LN1B]);
                 dcs.push_back(l > 0 ? grads + (O.layer + 12 * (l - 1))[PRB] : nullptr);
             }
+            // all 4 L weight gradients as one launch over the joint tile list (csrc/gemm_xl.hip); else one launch per block
+            const XlAdam* adam = nullptr;
+            if (g_fused_adam.armed && g_fused_adam.ad.p == params && g_fused_adam.ad.gbase == grads && g_fused_adam.ad.shadow == sh) {
+                g_fused_adam.ad.guard = mega_guard_word();
+                static const int stagger_us = getenv("SWAT_XL_STAGGER") ? atoi(getenv("SWAT_XL_STAGGER")) : 12;
+                g_fused_adam.ad.stagger = 100 * stagger_us;
+                adam = &g_fused_adam.ad;
+            }
+            g_fused_adam.armed = false;
+            if (g_block_adamw < 0) g_block_adamw = getenv("SWAT_BLOCK_ADAMW") ? atoi(getenv("SWAT_BLOCK_ADAMW")) : 1;
+            if (g_block_adamw == 0) adam = nullptr;
+            const int adam_pipe = g_block_adamw == 1 ? 1 : 0;
+            if (adam && adam_pipe && fork) {
+                // Piped form (the default): per block, the weight-gradient launch on the lane and the block's AdamW on a second stream —
+                // beside the NEXT block's weight gradients.  The 256 x 128 kernel is bound by the matrix cores and holds 3 x 152 of a
+                // SIMD's 512 registers: one 52-register wave of the HBM-bound AdamW fits beside its three (measured: 12 x (33 + 36) us
+                // one after the other -> 12 x ~51 us; the epilogue form below — AdamW on the accumulators — spares the gradient's
+                // round trip through memory but leaves its IEEE divisions and square roots to 8 waves per CU: no faster than apart)
+                TRY(ln_bwd_finish_sets(parts.data(), dgs.data(), dbs_.data(), dcs.data(), (int)parts.size(), nblk, d, ws));
+                hipStream_t os = g_side.aux[0];
+                const int64_t stride = D.L > 1 ? O.layer[12] - O.layer[0] : 0;
+                const int64_t zero = 0;
+                const int grp = adam_pipe >= 2 ? 2 : 1;   // blocks per weight-gradient launch (<= 8 products)
+                for (size_t l4 = 0; l4 < wg.size(); l4 += 4 * grp) {
+                    const int l_hi = D.L - 1 - (int)(l4 / 4);
+                    const int nl = l_hi + 1 < grp ? l_hi + 1 : grp, l_lo = l_hi - nl + 1;
+                    const void* dys[8]; const void* xs4[8]; float* dws[8]; float* dbs[8];
+                    int rws[8], nout[8], nin[8], ldy[8], ldx[8];
+                    for (int i = 0; i < 4 * nl; ++i) {
+                        const GemmArgs& a = wg[l4 + i];
+                        dys[i] = a.A; xs4[i] = a.B; dws[i] = (float*)a.C; dbs[i] = a.colsum;
+                        rws[i] = a.K; nout[i] = a.M; nin[i] = a.N; ldy[i] = a.lda; ldx[i] = a.ldb;
+                    }
+                    TRY(swat_linear_wgrad_bias_group(4 * nl, dys, xs4, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                    hipEvent_t e = g_side.next();
+                    if (!e || hipEventRecord(e, ws) != hipSuccess || hipStreamWaitEvent(os, e, 0) != hipSuccess) lane_ok = false;
+                    const int64_t b = O.layer[12 * l_lo + LN1W];
+                    const int64_t n = l_hi + 1 < D.L ? stride * nl : stride * (nl - 1) + O.layer[12 * l_hi + PRB] + d - O.layer[12 * l_hi + LN1W];
+                    TRY(swat_adamw(adam->p + b, adam->gbase + b, adam->m + b, adam->v + b, adam->shadow + b, n, &zero, 1, adam->lr, adam->b1, adam->b2,
+                                   adam->eps, adam->wd, adam->bc, adam->gscale, os));
+                }
+                hipEvent_t e2 = g_side.next();
+                if (!e2 || hipEventRecord(e2, os) != hipSuccess || hipStreamWaitEvent(ws, e2, 0) != hipSuccess) lane_ok = false;
+                g_fused_adam.consumed = true;
+                continue;
+            }
+            int wrc = (int)wg.size() <= 64 ? wgrad_all_try(wg.data(), (int)wg.size(), ws, adam_pipe ? nullptr : adam) : 1;
+            if (wrc < 0) return wrc;
+            const bool fused_adam = wrc == 0 && adam && !adam_pipe;
+            if (wrc == 1) {
+                for (size_t l4 = 0; l4 < wg.size(); l4 += 4) {
+                    const void* dys[4]; const void* xs4[4]; float* dws[4]; float* dbs[4];
+                    int rws[4], nout[4], nin[4], ldy[4], ldx[4];
+                    for (int i = 0; i < 4; ++i) {
+                        const GemmArgs& a = wg[l4 + i];
+                        dys[i] = a.A; xs4[i] = a.B; dws[i] = (float*)a.C; dbs[i] = a.colsum;
+                        rws[i] = a.K; nout[i] = a.M; nin[i] = a.N; ldy[i] = a.lda; ldx[i] = a.ldb;
+                    }
+                    TRY(swat_linear_wgrad_bias_group(4, dys, xs4, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                }
+            }
             TRY(ln_bwd_finish_sets(parts.data(), dgs.data(), dbs_.data(), dcs.data(), (int)parts.size(), nblk, d, ws));
+            if (fused_adam) {
+                // the matrices are done; biases and LayerNorm weights of the blocks (their gradients are complete now): one launch
+                std::vector<int64_t> rb;
+                std::vector<int> rl;
+                for (int l = 0; l < D.L; ++l) {
+                    const int64_t* lo = O.layer + 12 * l;
+                    const int which[8] = {LN1W, LN1B, QKVB, OUTB, LN2W, LN2B, FCB, PRB};
+                    const int len[8] = {d, d, 3 * d, d, d, d, mlp, d};
+                    for (int k = 0; k < 8; ++k) {
+                        rb.push_back(lo[which[k]]);
+                        rl.push_back(len[k]);
+                    }
+                }
+                for (size_t r0 = 0; r0 < rb.size(); r0 += 128) {
+                    const int n = (int)(rb.size() - r0 < 128 ? rb.size() - r0 : 128);
+                    const int rc = launch_adamw_ranges(rb.data() + r0, rl.data() + r0, n, *adam, ws);
+                    SWAT_REQUIRE(rc == 0, "swat_vit_backward: AdamW of the blocks' vector parameters failed to launch");
+                }
+                g_fused_adam.consumed = true;
+            }
             continue;
         } else if (stage >= 1) {
             SWAT_REQUIRE(mega_rc == 0, "swat_vit_backward: the persistent backward failed to launch");

@@ -39,6 +39,10 @@ class FusedTrainStep:
         # staged backward (one call per stage + a slice all-reduce after each) is the N > 1 path; `staged=True` forces it
         # at world 1 so single-GPU tests exercise exactly the code the 8-GPU job runs
         self.staged = (self.world > 1) if staged is None else bool(staged)
+        # one GPU: AdamW of the blocks' matrices inside their weight-gradient launch (csrc/gemm_xl.hip) when the blocks' backward runs
+        # as the persistent launch; SWAT_FUSE_ADAMW=0 keeps the separate optimizer launch
+        import os
+        self.fuse_adamw = os.environ.get("SWAT_FUSE_ADAMW", "1") != "0"
         self.reduce = self.staged and dist.is_initialized()
         # contiguous gradient slices per backward stage (the tower is laid out stage by stage in the arena)
         self._stage_slices = []
@@ -262,13 +266,23 @@ class FusedTrainStep:
                     # the blocks' data gradients run as ONE persistent launch (csrc/vit_mega.hip): one call for all of them, their
                     # weight gradients follow on the lane and one AdamW launch over the blocks' joint arena range behind those
                     for hi_s, lo_s in ((L + 1, L + 1), (L, 1), (0, 0)):
-                        self.visual.backward_raw(dfeats, stage_hi=hi_s, stage_lo=lo_s)
                         if hi_s == lo_s:
+                            self.visual.backward_raw(dfeats, stage_hi=hi_s, stage_lo=lo_s)
                             lo, hi = self._stage_slices[hi_s]
                             finish(sl["stages"][hi_s], lo, hi - lo)
                         else:
                             lo, hi = self._stage_slices[lo_s][0], self._stage_slices[hi_s][1]
-                            finish(self._adamw_args(lo, hi), lo, hi - lo)
+                            args = self._adamw_args(lo, hi)
+                            if self.fuse_adamw:
+                                # AdamW of the blocks inside their weight-gradient launch (include/swat_hip.h: swat_vit_arm_fused_adamw)
+                                a = self.arena
+                                _lib.check(lib.swat_vit_arm_fused_adamw(a.flat.data_ptr(), a.grad.data_ptr(), a.exp_avg.data_ptr(),
+                                                                        a.exp_avg_sq.data_ptr(), a.shadow.data_ptr(), args[8], args[13],
+                                                                        args[9], args[10], args[11], args[12], args[14]),
+                                           "swat_vit_arm_fused_adamw")
+                            self.visual.backward_raw(dfeats, stage_hi=hi_s, stage_lo=lo_s)
+                            if not (self.fuse_adamw and lib.swat_vit_fused_adamw_consumed()):
+                                finish(args, lo, hi - lo)
                 else:
                     for s in range(L + 1, -1, -1):
                         self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)

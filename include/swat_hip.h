@@ -335,6 +335,10 @@ int swat_vit_backward_join(swat_stream_t stream);
  *     DEVICE scalars as for swat_adamw).  The arming is used or dropped by that one call; swat_vit_fused_adamw_consumed() then says
  *     (and clears) whether the blocks' range has been stepped — if not (shape not served, data-parallel run), the caller launches
  *     swat_adamw for it as usual.  Single-process training only: a data-parallel step reduces the gradients first. */
+/* loss_accum (float64, device) += loss (device scalar), stream-ordered; skipped while the device guard of a persistent launch that
+ *     gave up stands.  For a step whose backward runs as the persistent launch the running loss sum is fed here, behind that
+ *     backward, instead of by swat_head_loss (pass it loss_accum = null): a give-up then voids the step as a whole. */
+int swat_loss_accumulate(const float* loss, double* loss_accum, swat_stream_t stream);
 int swat_vit_arm_fused_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                              const float* lr_dev, const float* bias_corr_dev, float beta1, float beta2, float eps,
                              float weight_decay, float grad_scale);

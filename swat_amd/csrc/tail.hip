@@ -114,6 +114,12 @@ __global__ __launch_bounds__(256) void ce_mixed_kernel(const float* __restrict__
     }
 }
 
+// loss_accum += loss, unless a persistent launch of the step gave up (the host re-runs the step): for steps whose BACKWARD may
+// void them — the addition is queued behind that backward instead of being made by ce_finish_kernel
+__global__ void loss_accumulate_kernel(const float* __restrict__ loss, double* __restrict__ loss_accum, const unsigned* __restrict__ guard) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !(guard && guard[0] != 0u)) loss_accum[0] += (double)loss[0];
+}
+
 __global__ void ce_finish_kernel(const float* __restrict__ per_loss, const float* __restrict__ per_dls, int B,
                                  float* __restrict__ loss, float* __restrict__ dls, double* __restrict__ loss_accum,
                                  const unsigned* __restrict__ guard) {
@@ -345,4 +351,10 @@ SWAT_API int swat_argmax_confusion(const float* z, const int64_t* labels, int B,
     hipLaunchKernelGGL(argmax_confusion_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, z, labels, B, C, pred_out, max_out,
                        (unsigned long long*)confusion, (unsigned long long*)correct);
     return check_launch("swat_argmax_confusion");
+}
+
+SWAT_API int swat_loss_accumulate(const float* loss, double* loss_accum, swat_stream_t s) {
+    SWAT_REQUIRE(loss && loss_accum, "swat_loss_accumulate: null pointer");
+    hipLaunchKernelGGL(swat::loss_accumulate_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, loss, loss_accum, swat::mega_guard_word());
+    return swat::check_launch("swat_loss_accumulate");
 }

@@ -434,6 +434,7 @@ struct SideLane {
     hipEvent_t doneA = nullptr, doneB = nullptr;  // last lane read of {dxb, dfb} / {dxb2, dqkv}
     hipEvent_t blk[2] = {nullptr, nullptr};       // one-launch form: end of the lane work of the last block with this parity
     bool open = false;           // lane work issued and not joined yet
+    hipEvent_t aux_done = nullptr;  // end of what the backward queued on aux[0] (the piped AdamW of the blocks): joined with the lane
     hipEvent_t next() {
         if (ev.size() < 1024) {
             hipEvent_t e;
@@ -491,6 +492,7 @@ SWAT_API int swat_vit_lane_order(swat_stream_t stream) {
     SWAT_REQUIRE(e, "cannot create an event");
     SWAT_HIP(hipEventRecord(e, g_side.st));
     SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+    if (g_side.aux_done) SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, g_side.aux_done, 0));
     return 0;
 }
 
@@ -510,6 +512,10 @@ SWAT_API int swat_vit_backward_join(swat_stream_t stream) {
     SWAT_REQUIRE(e, "cannot create an event");
     SWAT_HIP(hipEventRecord(e, g_side.st));
     SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+    if (g_side.aux_done) {
+        SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, g_side.aux_done, 0));
+        g_side.aux_done = nullptr;
+    }
     g_side.open = false;
     g_side.doneA = g_side.doneB = nullptr;
     g_side.blk[0] = g_side.blk[1] = nullptr;
@@ -711,8 +717,11 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                     TRY(swat_adamw(adam->p + b, adam->gbase + b, adam->m + b, adam->v + b, adam->shadow + b, n, &zero, 1, adam->lr, adam->b1, adam->b2,
                                    adam->eps, adam->wd, adam->bc, adam->gscale, os));
                 }
+                // the second stream's tail is joined with the lane's (swat_vit_backward_join / swat_vit_lane_order), not in front of what
+                // the caller queues on the lane next: the small optimizer launches of the head run beside the last block's AdamW
                 hipEvent_t e2 = g_side.next();
-                if (!e2 || hipEventRecord(e2, os) != hipSuccess || hipStreamWaitEvent(ws, e2, 0) != hipSuccess) lane_ok = false;
+                if (!e2 || hipEventRecord(e2, os) != hipSuccess) lane_ok = false;
+                g_side.aux_done = e2;
                 g_fused_adam.consumed = true;
                 continue;
             }

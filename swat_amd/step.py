@@ -126,12 +126,17 @@ class FusedTrainStep:
         else:
             feats = images.float().contiguous()  # pre-extracted, already normalised features (train_probing)
         g = a.grad
+        # a step whose blocks run backward as ONE persistent launch (one GPU, trailing mode) can still be voided by that launch: its
+        # loss joins the running sum behind it (on the lane, _trailing_backward), not in the loss kernel
+        self._late_loss = bool(self.train_visual and self.trail and not self.reduce and
+                               _lib.lib().swat_vit_backward_blocks_fused(self.visual._last_ws[1]))
         ls_ptr = a.flat.data_ptr() + 4 * self.off_ls if self.off_ls is not None else _lib.ptr(self._ls_fixed)
         dls_ptr = g.data_ptr() + 4 * self.off_ls if self.off_ls is not None else _lib.ptr(self._dls_scratch)
         rc = _lib.lib().swat_head_loss(_lib.ptr(feats), a.flat.data_ptr() + 4 * self.off_head, ls_ptr,
                                        _lib.ptr(target_a), _lib.ptr(target_b), float(lam), _lib.ptr(ws), _lib.ptr(self.loss),
                                        _lib.ptr(dfeats), g.data_ptr() + 4 * self.off_head, dls_ptr, None,
-                                       None, _lib.ptr(self.loss_accum), B, self.E, self.C, 1, int(self.train_visual), _lib.stream())
+                                       None, None if self._late_loss else _lib.ptr(self.loss_accum), B, self.E, self.C, 1, int(self.train_visual),
+                                       _lib.stream())
         _lib.check(rc, "swat_head_loss")
         if self.trail:
             return self._trailing_backward(g, dfeats)
@@ -258,18 +263,27 @@ class FusedTrainStep:
                         blocks, bucket = 0, bucket + 1
             else:
                 _lib.check(lib.swat_vit_lane_follow(main.cuda_stream), "swat_vit_lane_follow")
-                finish(sl["head"], self.off_head, self.C * self.E)
-                if self.off_ls is not None:
-                    finish(sl["ls"], self.off_ls, 1)
                 L = self.visual.layers
-                if lib.swat_vit_backward_blocks_fused(self.visual._last_ws[1]):
+                fused_blocks = self._late_loss
+
+                def finish_head():
+                    finish(sl["head"], self.off_head, self.C * self.E)
+                    if self.off_ls is not None:
+                        finish(sl["ls"], self.off_ls, 1)
+                if not fused_blocks:
+                    finish_head()
+                if fused_blocks:
                     # the blocks' data gradients run as ONE persistent launch (csrc/vit_mega.hip): one call for all of them, their
                     # weight gradients follow on the lane and one AdamW launch over the blocks' joint arena range behind those
+                    # (the optimizer launches of the head, the logit scale and stage L+1 wait until the persistent backward is behind
+                    # them on the lane: a hand-off it gives up on voids the step, and the device guard must be up before ANY update
+                    # of the step — the host then re-runs the whole step, swat_amd/step.py:_recover)
                     for hi_s, lo_s in ((L + 1, L + 1), (L, 1), (0, 0)):
                         if hi_s == lo_s:
                             self.visual.backward_raw(dfeats, stage_hi=hi_s, stage_lo=lo_s)
-                            lo, hi = self._stage_slices[hi_s]
-                            finish(sl["stages"][hi_s], lo, hi - lo)
+                            if hi_s == 0:
+                                lo, hi = self._stage_slices[0]
+                                finish(sl["stages"][0], lo, hi - lo)
                         else:
                             lo, hi = self._stage_slices[lo_s][0], self._stage_slices[hi_s][1]
                             args = self._adamw_args(lo, hi)
@@ -283,6 +297,10 @@ class FusedTrainStep:
                             self.visual.backward_raw(dfeats, stage_hi=hi_s, stage_lo=lo_s)
                             if not (self.fuse_adamw and lib.swat_vit_fused_adamw_consumed()):
                                 finish(args, lo, hi - lo)
+                            finish_head()
+                            lo, hi = self._stage_slices[L + 1]
+                            finish(sl["stages"][L + 1], lo, hi - lo)
+                            _lib.check(lib.swat_loss_accumulate(_lib.ptr(self.loss), _lib.ptr(self.loss_accum), lane_h), "swat_loss_accumulate")
                 else:
                     for s in range(L + 1, -1, -1):
                         self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)

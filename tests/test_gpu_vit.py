@@ -519,12 +519,15 @@ def test_adamw_inside_the_weight_gradient_launch_equals_the_separate_optimizer_l
     assert not torch.equal(sep[1], _b32_step(seed=3)[2].arena.flat)   # (the weights did move)
 
 
-def test_persistent_forward_give_up_is_detected_and_the_step_is_re_run_op_by_op():
+@pytest.mark.parametrize("which", ["forward", "backward"])
+def test_persistent_forward_give_up_is_detected_and_the_step_is_re_run_op_by_op(which):
     """Hardening of csrc/vit_mega.hip (round-3 advisor finding): a team member that never arrives (here injected: it skips one
     arrival, spin bound 2 ms) must not cost the job its weights.  The launch flags the give-up on the device and in a pinned host
     word; every AdamW launch and the running loss sum skip their writes while the flag stands; the next call of the step notices
     (no synchronisation needed), switches the process to the op-by-op forward and runs the voided steps again.  The trajectory
-    must equal a run that never used the persistent forward."""
+    must equal a run that never used the persistent forward.  "backward": the same for the persistent BACKWARD (vit_bwd_mega_kernel) —
+    by then the step's loss is computed, but no optimizer launch of the step may have run yet (the head's, too, are queued behind
+    the persistent backward): the give-up voids the step as a whole."""
     from swat_amd import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(5)
@@ -534,8 +537,8 @@ def test_persistent_forward_give_up_is_detected_and_the_step_is_re_run_op_by_op(
         model, head, opt, sched, step = _b32_step()
         losses = []
         for it, (x, y) in enumerate(data):
-            if inject and it == 1:
-                L.swat_vit_mega_inject_failure(1, 9)   # the 2nd step's forward: member 1 of team 0 misses hand-off 9 (block 2)
+            if inject and it == 1:   # the 2nd step: member 1 of team 0 misses hand-off 9 (forward: block 2; backward: block 10)
+                (L.swat_vit_mega_inject_failure if which == "forward" else L.swat_vit_mega_backward_inject_failure)(1, 9)
             step(x, y, y.flip(0), 0.7, perm=torch.arange(31, -1, -1, device=dev()), box=(10, 20, 120, 200))
             sched.step()
             losses.append(step.loss.clone())
@@ -553,6 +556,7 @@ def test_persistent_forward_give_up_is_detected_and_the_step_is_re_run_op_by_op(
         assert L.swat_vit_mega_poll() == 0 and L.swat_vit_mega_status() == 0
     finally:
         L.swat_vit_mega_inject_failure(0, 0)
+        L.swat_vit_mega_backward_inject_failure(0, 0)
         L.swat_vit_set_mega(1)
     assert got[4] == want[4] == 4
     assert abs(got[1] - want[1]) < 1e-2 * abs(want[1])          # the loss sum holds each step once (no void step in it)

@@ -71,6 +71,8 @@ struct MegaFwd {
     unsigned* host_flag;    // pinned host word: launch number of the first launch that gave up (the host polls it without a sync)
     unsigned launch_no;     // 1-based number of this launch on its device
     unsigned long long spin_ticks;  // bound of a hand-off wait (100 MHz ticks)
+    unsigned ctr_base;      // the team counters' value when this launch starts: they only grow (no memset in front of a launch);
+                            // hand-off number q of the launch completes at ctr_base + 16 q
     int fail_sync;          // tuning (swat_vit_mega_inject_failure): member 1 of team 0 skips its arrival at hand-off number
                             // fail_sync of the launch (1-based); 0 in production
     unsigned long long* trace;  // tuning: per workgroup phase stamps (null in production)
@@ -122,16 +124,17 @@ __device__ __forceinline__ void team_sync(const Params& p, int team, int member,
         if (tr) tr[1] = mg_clock();                   // stores drained, workgroup together
         unsigned* c = p.ctr + team * 32;
         const bool skip = p.fail_sync && target == (unsigned)p.fail_sync * MG_TEAM && team == 0 && member == 1;
+        target += p.ctr_base;
         if (!skip) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = mg_clock();
         unsigned spins = 0;
-        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             __builtin_amdgcn_s_sleep(1);
             // a hand-off that has already been given up on anywhere (this launch or an earlier one the host has not seen yet):
             // the launch's values are void, do not wait 0.5 s at each of its 72 hand-offs
             if ((++spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             if (mg_clock() - t0 > p.spin_ticks) {  // a member never arrived (not resident / faulted): give up, flag it
-                __hip_atomic_store(p.status, 0x80000000u | target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.status, 0x80000000u | (target - p.ctr_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned expect = 0;
                 __hip_atomic_compare_exchange_strong(p.host_flag, &expect, p.launch_no, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_SYSTEM);
@@ -737,6 +740,7 @@ struct MegaBwd {
     unsigned* host_flag;
     unsigned launch_no;
     unsigned long long spin_ticks;
+    unsigned ctr_base;
     int fail_sync;
     unsigned long long* trace;
 };
@@ -1177,6 +1181,9 @@ struct MegaDev {
     int cus = 0, resident = -1;     // CUs of the device; workgroups of the kernel that fit one CU (occupancy query)
     int resident_bwd = -1;          // the same for the persistent backward
     unsigned launches = 0, launches_bwd = 0;
+    unsigned ctr = 0;               // value of the team counters after the launches queued so far
+    bool ctr_dirty = false;         // the counters will not be uniform after the launches queued so far (injected failure, ragged rounds)
+    int ctr_teams = 0;              // teams of the last launch
 };
 static MegaDev g_mega_dev[16];
 static int g_mega_mode = -1;               // swat_vit_set_mega / SWAT_VIT_MEGA: 0 = op-by-op forward, 1 = persistent forward when eligible
@@ -1185,6 +1192,26 @@ static int g_fail_launches = 0, g_fail_sync = 0;   // swat_vit_mega_inject_failu
 static int g_mega_bwd = -1;                // swat_vit_set_mega_backward / SWAT_VIT_MEGA_BWD
 static unsigned long long* g_mega_trace_bwd = nullptr;
 static int g_fail_bwd_launches = 0, g_fail_bwd_sync = 0;
+
+// The team counters only grow: a launch starts at md->ctr (what they hold when every earlier launch has completed all its
+// hand-offs) and leaves them `handoffs` x 16 higher — no memset on the stream in front of each launch (6-8 us on the critical path,
+// twice per step).  After a give-up (the pinned host word says so) or near the 32-bit wrap they are zeroed, stream-ordered.
+// Every team must leave a launch with the same count: a launch on fewer teams than the last one, or with panels that do not fill
+// whole rounds of teams (tests), is followed by a reset too.
+static int mega_counter_base(MegaDev* md, int npanels, int nteams, int L, hipStream_t s, unsigned& base) {
+    const unsigned handoffs = (unsigned)((npanels + nteams - 1) / nteams) * 6u * (unsigned)L;
+    if (md->ctr > 0xE0000000u || (md->host_flag && __atomic_load_n(md->host_flag, __ATOMIC_RELAXED) != 0) || md->ctr_dirty ||
+        nteams != md->ctr_teams) {
+        if (hipMemsetAsync(md->state, 0, 16 * 128, s) != hipSuccess) return -1;
+        md->ctr = 0;
+        md->ctr_dirty = false;
+    }
+    base = md->ctr;
+    md->ctr += handoffs * MG_TEAM;
+    md->ctr_teams = nteams;
+    if (npanels % nteams) md->ctr_dirty = true;   // teams end this launch at different counts
+    return 0;
+}
 
 static MegaDev* mega_dev() {
     int dev = 0;
@@ -1272,7 +1299,9 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
     }
     m.trace = g_mega_trace;
     if (md->any && md->last != s) SWAT_HIP(hipStreamWaitEvent(s, md->done, 0));   // persistent launches of a device never overlap
-    SWAT_HIP(hipMemsetAsync(md->state, 0, 16 * 128, s));  // the arrival counters; the status word behind them is sticky (read-and-clear)
+    // (the status word behind the counters is sticky: read-and-clear)
+    SWAT_REQUIRE(mega_counter_base(md, npanels, nteams, L, s, m.ctr_base) == 0, "vit_mega: cannot reset the hand-off counters");
+    if (m.fail_sync) md->ctr_dirty = true;
     // products + attention inside the launch (what bench.py's roofline divides by the launch's duration)
     const double flops = (double)L * B * T * (2.0 * d * 3 * d + 2.0 * d * d + 4.0 * d * mlp + 4.0 * T * d);
     hipEvent_t e0, e1;
@@ -1356,7 +1385,8 @@ int vit_mega_backward(int B, int T, int d, int H, int mlp, int L, int act, int M
     }
     m.trace = g_mega_trace_bwd;
     if (md->any && md->last != s) SWAT_HIP(hipStreamWaitEvent(s, md->done, 0));
-    SWAT_HIP(hipMemsetAsync(md->state, 0, 16 * 128, s));
+    SWAT_REQUIRE(mega_counter_base(md, npanels, nteams, L, s, m.ctr_base) == 0, "vit_mega: cannot reset the hand-off counters");
+    if (m.fail_sync) md->ctr_dirty = true;
     // data-gradient products + attention backward inside the launch
     const double flops = (double)L * B * T * (2.0 * d * 3 * d + 2.0 * d * d + 4.0 * d * mlp + 10.0 * T * d);
     hipEvent_t e0, e1;
@@ -1412,7 +1442,10 @@ SWAT_API int swat_vit_mega_status(void) {
     unsigned v = 0;
     SWAT_HIP(hipDeviceSynchronize());
     SWAT_HIP(hipMemcpy(&v, md->state + 16 * 32, 4, hipMemcpyDeviceToHost));
-    if (v) SWAT_HIP(hipMemset(md->state + 16 * 32, 0, 128));
+    if (v) {
+        SWAT_HIP(hipMemset(md->state + 16 * 32, 0, 128));
+        md->ctr_dirty = true;   // a launch gave up: the team counters are short of what the host has counted
+    }
     md->host_flag[0] = 0;
     return (int)(v & 0x3fffffffu) | (v ? 0x40000000 : 0);
 }

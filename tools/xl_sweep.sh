@@ -1,10 +1,10 @@
 # tuning: the optimizer forms behind the persistent backward, with per-kernel durations (run on the GPU box from the repo root)
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
-for cfg in "F0 SWAT_FUSE_ADAMW=0" "PIPE1 SWAT_ADAMW_PIPE=1" "PIPE2 SWAT_ADAMW_PIPE=2" "PIPE1b SWAT_ADAMW_PIPE=1" "PIPE2b SWAT_ADAMW_PIPE=2"; do
+for cfg in "EPI0 SWAT_BLOCK_ADAMW=2 SWAT_XL_STAGGER=0" "EPI12 SWAT_BLOCK_ADAMW=2 SWAT_XL_STAGGER=12" "EPI24 SWAT_BLOCK_ADAMW=2 SWAT_XL_STAGGER=24" "PIPE SWAT_BLOCK_ADAMW=1"; do
   set -- $cfg
   rm -rf $O/sw_$1
-  unset SWAT_ADAMW_PIPE SWAT_ADAMW_BLOCKS
+  unset SWAT_BLOCK_ADAMW SWAT_XL_STAGGER
   export SWAT_FUSE_ADAMW=1
   tag=$1; shift
   for kv in "$@"; do export $kv; done

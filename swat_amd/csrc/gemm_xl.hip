@@ -108,8 +108,14 @@ __device__ __forceinline__ XlTile xl_decode(const Args& a, int id) {
         for (int i = 1; i < XL_MAXP; ++i)
             if (i < a.n && id >= a.p[i].tile0) pi = i;
     } else {
-        for (int i = 1; i < a.n; ++i)
-            if (id >= a.p[i].tile0) pi = i;
+        // (tile0 ascends: binary search — a linear scan over 48 products costs each decode 48 dependent scalar loads)
+        int lo = 0, hi = a.n;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (id >= a.p[mid].tile0) lo = mid;
+            else hi = mid;
+        }
+        pi = lo;
     }
     const int t = id - a.p[pi].tile0, tmn = a.p[pi].tiles_m, tnn = a.p[pi].tiles_n;
     int tm, tn;
@@ -635,12 +641,20 @@ int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipE
 // buffer and is re-sent only when it changes (a training step asks for the same pointers every time).  -> 0 / 1 not served / < 0
 int launch_gemm_xl_table(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const XlAdam* adam) {
     if (n < 1 || n > XL_MAXT) return 1;
-    struct Cache {
+    // a few tables per device (a step asks for the same ones every time: all blocks at once, or groups of blocks): a table is sent
+    // once, on the stream of its first launch; a launch on another stream than the one that sent it is not ordered with the copy
+    constexpr int SLOTS = 8;
+    struct Slot {
         XlProb* dev = nullptr;
-        XlProb* pinned[4] = {nullptr, nullptr, nullptr, nullptr};
+        XlProb* pinned = nullptr;
         XlProb last[XL_MAXT];
-        int n = 0, slot = 0;
-        hipStream_t last_stream = nullptr;
+        int n = 0;
+        hipStream_t stream = nullptr;
+        unsigned long long used = 0;
+    };
+    struct Cache {
+        Slot slot[SLOTS];
+        unsigned long long tick = 0;
     };
     static Cache cache[16];
     int devi = 0;
@@ -658,25 +672,33 @@ int launch_gemm_xl_table(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t
         total += t[i].tiles_m * t[i].tiles_n;
     }
     if (total == 0) return 1;
-    if (!c.dev) {
-        if (hipMalloc((void**)&c.dev, sizeof(XlProb) * XL_MAXT) != hipSuccess) return -1;
-        for (int k = 0; k < 4; ++k)
-            if (hipHostMalloc((void**)&c.pinned[k], sizeof(XlProb) * XL_MAXT, hipHostMallocDefault) != hipSuccess) return -1;
+    Slot* sl = nullptr;
+    for (int k = 0; k < SLOTS; ++k)
+        if (c.slot[k].n == n && memcmp(c.slot[k].last, t, sizeof(XlProb) * n) == 0) sl = &c.slot[k];
+    if (sl && sl->stream != s) return 1;   // (sent on another stream: the caller takes the per-block launches)
+    if (!sl) {
+        sl = &c.slot[0];
+        for (int k = 1; k < SLOTS; ++k)
+            if (c.slot[k].used < sl->used) sl = &c.slot[k];   // least recently used (never used: 0)
+        if (!sl->dev) {
+            if (hipMalloc((void**)&sl->dev, sizeof(XlProb) * XL_MAXT) != hipSuccess ||
+                hipHostMalloc((void**)&sl->pinned, sizeof(XlProb) * XL_MAXT, hipHostMallocDefault) != hipSuccess) {
+                sl->dev = nullptr;
+                return -1;
+            }
+        } else if (sl->stream) {
+            // the slot's old table may still be read by launches in flight, and its staging buffer by a copy: let them finish
+            SWAT_HIP(hipStreamSynchronize(sl->stream));
+        }
+        memcpy(sl->pinned, t, sizeof(XlProb) * n);
+        SWAT_HIP(hipMemcpyAsync(sl->dev, sl->pinned, sizeof(XlProb) * n, hipMemcpyHostToDevice, s));
+        memcpy(sl->last, t, sizeof(XlProb) * n);
+        sl->n = n;
+        sl->stream = s;
     }
-    if (c.n != n || memcmp(c.last, t, sizeof(XlProb) * n) != 0) {
-        // stream-ordered behind the launches that read the old table; the staging slot is not rewritten before three more changes
-        XlProb* stage = c.pinned[c.slot];
-        c.slot = (c.slot + 1) & 3;
-        memcpy(stage, t, sizeof(XlProb) * n);
-        SWAT_HIP(hipMemcpyAsync(c.dev, stage, sizeof(XlProb) * n, hipMemcpyHostToDevice, s));
-        memcpy(c.last, t, sizeof(XlProb) * n);
-        c.n = n;
-        c.last_stream = s;
-    } else if (c.last_stream != s) {
-        return 1;   // the table was sent on another stream: not ordered with this launch — the caller takes the per-block launches
-    }
+    sl->used = ++c.tick;
     XlArgsTable a{};
-    a.p = c.dev; a.n = n; a.total = total; a.trace = nullptr; a.exp = 0;
+    a.p = sl->dev; a.n = n; a.total = total; a.trace = nullptr; a.exp = 0;
     if (adam) a.adam = *adam;
     const dim3 grid(total < 256 ? total : 256), block(XL_THREADS);
     if (ev0) hipExtLaunchKernelGGL((gemm_xl_kernel<L_TN, false, XlArgsTable>), grid, block, 0, s, ev0, ev1, 0, a);

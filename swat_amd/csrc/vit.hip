@@ -708,18 +708,23 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                 hipStream_t os = g_side.aux[0];
                 const int64_t stride = D.L > 1 ? O.layer[12] - O.layer[0] : 0;
                 const int64_t zero = 0;
-                const int grp = adam_pipe >= 2 ? 2 : 1;   // blocks per weight-gradient launch (<= 8 products)
+                static const int pipe_grp = getenv("SWAT_PIPE_GROUP") ? atoi(getenv("SWAT_PIPE_GROUP")) : 1;
+                const int grp = pipe_grp < 1 ? 1 : pipe_grp > 12 ? 12 : pipe_grp;   // blocks per weight-gradient launch
                 for (size_t l4 = 0; l4 < wg.size(); l4 += 4 * grp) {
                     const int l_hi = D.L - 1 - (int)(l4 / 4);
                     const int nl = l_hi + 1 < grp ? l_hi + 1 : grp, l_lo = l_hi - nl + 1;
-                    const void* dys[8]; const void* xs4[8]; float* dws[8]; float* dbs[8];
-                    int rws[8], nout[8], nin[8], ldy[8], ldx[8];
-                    for (int i = 0; i < 4 * nl; ++i) {
-                        const GemmArgs& a = wg[l4 + i];
-                        dys[i] = a.A; xs4[i] = a.B; dws[i] = (float*)a.C; dbs[i] = a.colsum;
-                        rws[i] = a.K; nout[i] = a.M; nin[i] = a.N; ldy[i] = a.lda; ldx[i] = a.ldb;
+                    int wrc1 = nl > 1 ? wgrad_all_try(wg.data() + l4, 4 * nl, ws, nullptr) : 1;   // (table form: several blocks per launch)
+                    if (wrc1 < 0) return wrc1;
+                    for (int b4 = 0; wrc1 == 1 && b4 < nl; ++b4) {
+                        const void* dys[4]; const void* xs4[4]; float* dws[4]; float* dbs[4];
+                        int rws[4], nout[4], nin[4], ldy[4], ldx[4];
+                        for (int i = 0; i < 4; ++i) {
+                            const GemmArgs& a = wg[l4 + 4 * b4 + i];
+                            dys[i] = a.A; xs4[i] = a.B; dws[i] = (float*)a.C; dbs[i] = a.colsum;
+                            rws[i] = a.K; nout[i] = a.M; nin[i] = a.N; ldy[i] = a.lda; ldx[i] = a.ldb;
+                        }
+                        TRY(swat_linear_wgrad_bias_group(4, dys, xs4, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
                     }
-                    TRY(swat_linear_wgrad_bias_group(4 * nl, dys, xs4, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
                     hipEvent_t e = g_side.next();
                     if (!e || hipEventRecord(e, ws) != hipSuccess || hipStreamWaitEvent(os, e, 0) != hipSuccess) lane_ok = false;
                     const int64_t b = O.layer[12 * l_lo + LN1W];

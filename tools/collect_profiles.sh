@@ -24,7 +24,7 @@ def load(d):
     res = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{O}/{TAG}_{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if ("gemm_" in r["Kernel_Name"] and "sgemm_small" not in r["Kernel_Name"]) or "vit_fwd_mega" in r["Kernel_Name"] or "wgrad_group" in r["Kernel_Name"]:   # every kernel bench.py's roofline times
+            if ("gemm_" in r["Kernel_Name"] and "sgemm_small" not in r["Kernel_Name"]) or "vit_fwd_mega" in r["Kernel_Name"] or "vit_bwd_mega" in r["Kernel_Name"] or "wgrad_group" in r["Kernel_Name"]:   # every kernel bench.py's roofline times
                 k = r["Kernel_Name"].split("(")[0].replace("void swat::", "")
                 res[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return res

@@ -1,10 +1,10 @@
 # tuning: the optimizer forms behind the persistent backward, with per-kernel durations (run on the GPU box from the repo root)
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
-for cfg in "EPI0 SWAT_BLOCK_ADAMW=2 SWAT_XL_STAGGER=0" "EPI12 SWAT_BLOCK_ADAMW=2 SWAT_XL_STAGGER=12" "EPI24 SWAT_BLOCK_ADAMW=2 SWAT_XL_STAGGER=24" "PIPE SWAT_BLOCK_ADAMW=1"; do
+for cfg in "G1 SWAT_PIPE_GROUP=1" "G2 SWAT_PIPE_GROUP=2" "G3 SWAT_PIPE_GROUP=3" "G4 SWAT_PIPE_GROUP=4" "G6 SWAT_PIPE_GROUP=6" "G1b SWAT_PIPE_GROUP=1"; do
   set -- $cfg
   rm -rf $O/sw_$1
-  unset SWAT_BLOCK_ADAMW SWAT_XL_STAGGER
+  unset SWAT_BLOCK_ADAMW SWAT_XL_STAGGER SWAT_PIPE_GROUP
   export SWAT_FUSE_ADAMW=1
   tag=$1; shift
   for kv in "$@"; do export $kv; done

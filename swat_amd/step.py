@@ -206,8 +206,8 @@ class FusedTrainStep:
         opt = self.opt
         sl = self._slice_args()
 
-        def finish(args, lo, n):  # one GPU: this slice's AdamW behind the lane
-            _lib.check(lib.swat_adamw(*args, side_h), "swat_adamw")
+        def finish(args, lo, n, stream_h=None):  # one GPU: this slice's AdamW behind the lane (or on the stream given)
+            _lib.check(lib.swat_adamw(*args, side_h if stream_h is None else stream_h), "swat_adamw")
 
         # N > 1: gradients leave in BUCKETS of `self.bucket_sched[i]` transformer blocks (one contiguous arena range each:
         # logit_scale rides in the first bucket, stage 0 and the head in the last), all-reduced on `comm` (RCCL, stream-ordered) with the
@@ -239,10 +239,20 @@ class FusedTrainStep:
             if getattr(self, "_lane_ext", None) is None:
                 self._lane_ext = torch.cuda.ExternalStream(lane_h, device=main.device)
             opt_stream = self._lane_ext
-        with torch.cuda.stream(opt_stream):
-            opt.begin_step()
         _lib.check(lib.swat_vit_set_overlap(2), "swat_vit_set_overlap")
         try:
+            if not self.reduce:
+                # the lane first follows the main stream: the previous step's small optimizer launches ran THERE (below) and still
+                # read the scalars this upload overwrites
+                _lib.check(lib.swat_vit_lane_follow(main.cuda_stream), "swat_vit_lane_follow")
+            with torch.cuda.stream(opt_stream):
+                opt.begin_step()
+                scalars_up = None
+                if not self.reduce:
+                    if getattr(self, "_scalars_ev", None) is None:
+                        self._scalars_ev = torch.cuda.Event()
+                    scalars_up = self._scalars_ev
+                    scalars_up.record()   # (the main stream's own optimizer launches below wait for the upload)
             if self.reduce:
                 side.wait_stream(main)  # head gradients + this step's scalars
                 comm.wait_stream(main)
@@ -262,14 +272,13 @@ class FusedTrainStep:
                         flush()
                         blocks, bucket = 0, bucket + 1
             else:
-                _lib.check(lib.swat_vit_lane_follow(main.cuda_stream), "swat_vit_lane_follow")
                 L = self.visual.layers
                 fused_blocks = self._late_loss
 
-                def finish_head():
-                    finish(sl["head"], self.off_head, self.C * self.E)
+                def finish_head(stream_h=None):
+                    finish(sl["head"], self.off_head, self.C * self.E, stream_h)
                     if self.off_ls is not None:
-                        finish(sl["ls"], self.off_ls, 1)
+                        finish(sl["ls"], self.off_ls, 1, stream_h)
                 if not fused_blocks:
                     finish_head()
                 if fused_blocks:
@@ -283,7 +292,7 @@ class FusedTrainStep:
                             self.visual.backward_raw(dfeats, stage_hi=hi_s, stage_lo=lo_s)
                             if hi_s == 0:
                                 lo, hi = self._stage_slices[0]
-                                finish(sl["stages"][0], lo, hi - lo)
+                                finish(sl["stages"][0], lo, hi - lo, main.cuda_stream)   # (behind the stem backward, on its stream)
                         else:
                             lo, hi = self._stage_slices[lo_s][0], self._stage_slices[hi_s][1]
                             args = self._adamw_args(lo, hi)
@@ -297,10 +306,15 @@ class FusedTrainStep:
                             self.visual.backward_raw(dfeats, stage_hi=hi_s, stage_lo=lo_s)
                             if not (self.fuse_adamw and lib.swat_vit_fused_adamw_consumed()):
                                 finish(args, lo, hi - lo)
-                            finish_head()
+                            # the small optimizer launches of the step go on the MAIN stream, right behind the persistent backward and
+                            # beside the lane's weight gradients — at the lane's tail they would stand between this step and the next
+                            # (0.07 ms); the main stream first waits for this step's optimizer scalars (uploaded on the lane)
+                            main.wait_event(scalars_up)
+                            mh = main.cuda_stream
+                            finish_head(mh)
                             lo, hi = self._stage_slices[L + 1]
-                            finish(sl["stages"][L + 1], lo, hi - lo)
-                            _lib.check(lib.swat_loss_accumulate(_lib.ptr(self.loss), _lib.ptr(self.loss_accum), lane_h), "swat_loss_accumulate")
+                            finish(sl["stages"][L + 1], lo, hi - lo, mh)
+                            _lib.check(lib.swat_loss_accumulate(_lib.ptr(self.loss), _lib.ptr(self.loss_accum), mh), "swat_loss_accumulate")
                 else:
                     for s in range(L + 1, -1, -1):
                         self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)

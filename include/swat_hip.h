@@ -56,6 +56,14 @@ int swat_dense_topk_proof(const void* cand_cnt, int cap, int K2, const float* ap
                           const float* exact_val, int k, const int64_t* out_cnt, int need, float eps_qnorm,
                           const float* max_norm2, const float* qnorm_max, int n_q, int* fails, swat_stream_t stream);
 
+/* out[r] = the rank-th largest (1-based) of scores[r, 0 .. n_cols): the per-query pruning threshold of the dense top-k, taken at a
+ *     small rank of a row sample (the candidate pass keeps what scores above it; ref: the per-class ranking of
+ *     retrieval/sample_retrieval.py:754,807 generalised to N_query x N_db).  Scores must hold no NaN.
+ *     Rider (q_rows != null): q_rows [n_rows, d] are the queries; qnorm_max[0] = max_r |q_r| rounded up — the `qnorm_max` device scalar
+ *     of swat_dense_topk_proof / swat_candidates_topk_proof — from the same launch.  norm_workspace: (1 + n_rows) floats, word 0
+ *     zero before the first use (the launch leaves it zero). */
+int swat_rank_select(const float* scores, int n_rows, int n_cols, int rank, float* out, const float* q_rows, int d,
+                     void* norm_workspace, float* qnorm_max, swat_stream_t stream);
 /* B5  filtered segmented top-k: for every segment s = rows [seg_offsets[s], seg_offsets[s+1])
  *     keep row iff sims >= thr [and t2i >= t2i_thr when t2i != NULL] [and !excluded[row]],
  *     order by (sims desc, row asc) and emit the first k.

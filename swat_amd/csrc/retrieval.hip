@@ -302,6 +302,155 @@ __global__ __launch_bounds__(256) void segment_topk_kernel(const float* __restri
     if (tid == 0) out_cnt[seg] = (int64_t)kk;
 }
 
+// rank-th largest of each row of S [nq][ns] (fp32; NaN-free), one workgroup per row.  Selection = bisection over the bits of the
+// order-preserving integer image of the scores (the largest key K with #(key >= K) >= rank is the rank-th largest key), but not over the
+// whole row: a thread keeps 16 keys in registers (ns <= 16 384); T0 = the rank-th largest of the 1 024 per-thread MAXIMA is a lower bound
+// of the answer that only a few more than `rank` keys reach; wave 0 finds T0 (16 maxima per lane, 32 steps of 16 compares + five ballots
+// over the bits of the lanes' counts, no barrier inside), every thread files its keys >= T0 in LDS, wave 0 bisects over those.  Longer
+// rows, ranks beyond 1 024 or more than 1 024 survivors take the plain form: 32 steps over all keys with one LDS atomic per wave and a
+// barrier per step.  The dense top-k's pruning threshold = the score at a small rank of a 16 k-row sample (swat_amd/retrieval/dense.py:
+// _thresholds): 19-25 us against 62 for the two sorting launches it replaces (measured on the way: MSB radix select with LDS histograms
+// 52 us — the scores share a few exponent bins and their atomics serialise; the plain form 28; wave-local selection 35 — all 16 waves of
+// a row share a CU and the steps are VALU-issue and latency bound; what is left here is the two serial 32-step chains of wave 0).
+// Rider (q != null): the workgroup of row r also leaves |q_r|^2 in norms2[r]; the LAST workgroup to finish (a self-resetting counter)
+// writes qnorm_max[0] = max_r |q_r| rounded up by 2^-20 — the |q| factor of the top-k's error bound for a new query batch, without a
+// launch of its own and without a host synchronisation.
+constexpr int RS_THREADS = 1024, RS_KPT = 16;
+__global__ __launch_bounds__(RS_THREADS) void rank_select_kernel(const float* __restrict__ S, int ns, int rank, float* __restrict__ out,
+                                                                 const float* __restrict__ q, int d, float* __restrict__ norms2,
+                                                                 unsigned* __restrict__ done_ctr, float* __restrict__ qnorm_max) {
+    __shared__ unsigned total[32];
+    __shared__ unsigned last_flag;
+    const float* row = S + (int64_t)blockIdx.x * ns;
+    const int tid = threadIdx.x, lane = tid & 63;
+    auto to_key = [](float f) {
+        const unsigned b = __float_as_uint(f);
+        return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // larger float <-> larger unsigned
+    };
+    constexpr int KPT = RS_KPT;
+    const bool in_regs = ns <= KPT * RS_THREADS;
+    unsigned key[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = tid + RS_THREADS * u;
+        key[u] = (in_regs && i < ns) ? to_key(row[i]) : 0u;   // (0 is below every candidate K >= 1: never counted)
+    }
+    if (tid < 32) total[tid] = 0;
+    if (q && tid >= RS_THREADS - 64) {   // the last wave: |q_row|^2
+        const float* qr = q + (int64_t)blockIdx.x * d;
+        float ss = 0.f;
+        for (int i = lane; i < d; i += 64) ss = fmaf(qr[i], qr[i], ss);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (lane == 0) norms2[blockIdx.x] = ss;
+    }
+    __syncthreads();
+    unsigned prefix = 0;
+    // Fast path (keys in registers, rank <= 1 024): the rank-th largest of the 1 024 per-thread maxima, T0, is a lower bound of the
+    // answer that only a few more than `rank` keys reach (the row's best `rank` keys seldom share a thread); wave 0 finds T0 by
+    // bisection over the maxima (16 per lane, no barrier inside), every thread files its keys >= T0 in LDS, wave 0 bisects over those.
+    // More than 1 024 survivors (ties): the barrier form below answers.
+    __shared__ unsigned pool[RS_THREADS];
+    __shared__ unsigned pool_n, t0_key, result_key;
+    bool done = false;
+    auto wave0_select = [&](unsigned n) {   // rank-th largest of pool[0 .. n), n <= 1 024; by wave 0 only
+        unsigned k2[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) k2[w] = (unsigned)(w * 64 + lane) < n ? pool[w * 64 + lane] : 0u;
+        unsigned fp = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned cand = fp | (1u << bit);
+            unsigned c = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) c += k2[w] >= cand ? 1u : 0u;
+            unsigned t = 0;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) t += (unsigned)__popcll(__ballot((c >> b) & 1u)) << b;
+            if (t >= (unsigned)rank) fp = cand;
+        }
+        return fp;
+    };
+    if (in_regs && rank <= RS_THREADS) {
+        unsigned mx = key[0];
+#pragma unroll
+        for (int u = 1; u < KPT; ++u) mx = key[u] > mx ? key[u] : mx;
+        pool[tid] = mx;
+        if (tid == 0) pool_n = 0;
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned t0 = wave0_select(RS_THREADS);
+            if (lane == 0) t0_key = t0;
+        }
+        __syncthreads();   // (also: every thread has read nothing of pool since the maxima went in; wave 0 is done with them)
+        const unsigned t0 = t0_key;
+        unsigned mine = 0;
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) mine += key[u] >= t0 ? 1u : 0u;
+        unsigned pos = 0;
+        if (mine) pos = atomicAdd(&pool_n, mine);
+        if (mine && pos + mine <= RS_THREADS) {
+#pragma unroll
+            for (int u = 0; u < KPT; ++u)
+                if (key[u] >= t0) pool[pos++] = key[u];
+        }
+        __syncthreads();
+        if (pool_n <= RS_THREADS) {
+            if (tid < 64) {
+                const unsigned r = wave0_select(pool_n);
+                if (lane == 0) result_key = r;
+            }
+            __syncthreads();
+            prefix = result_key;
+            done = true;
+        }
+    }
+    for (int bit = done ? -1 : 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        unsigned c = 0;
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) c += key[u] >= cand ? 1u : 0u;
+            unsigned t = 0;   // c <= 16: the wave's sum = sum over the count's bits of 2^b x (lanes with that bit set)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) t += (unsigned)__popcll(__ballot((c >> b) & 1u)) << b;
+            c = t;
+        } else {
+            for (int i = tid; i < ns; i += RS_THREADS) c += to_key(row[i]) >= cand ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+        }
+        if (lane == 0 && c) atomicAdd(&total[bit], c);
+        __syncthreads();
+        if (total[bit] >= (unsigned)rank) prefix = cand;
+    }
+    if (tid == 0) {
+        const unsigned b = prefix ^ ((prefix >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+        out[blockIdx.x] = __uint_as_float(b);
+    }
+    if (q) {
+        if (tid == 0) {
+            __threadfence();   // norms2[row] is visible before the arrival
+            last_flag = atomicAdd(done_ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (last_flag) {   // every row's norm has been published
+            float m = 0.f;
+            for (int r = tid; r < (int)gridDim.x; r += RS_THREADS) m = fmaxf(m, __builtin_nontemporal_load(norms2 + r));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            __shared__ float wm[RS_THREADS / 64];
+            if (lane == 0) wm[tid >> 6] = m;
+            __syncthreads();
+            if (tid == 0) {
+                float v = wm[0];
+                for (int w = 1; w < RS_THREADS / 64; ++w) v = fmaxf(v, wm[w]);
+                qnorm_max[0] = sqrtf(v) * (1.0f + 9.5367431640625e-07f);
+                *done_ctr = 0u;   // ready for the next launch
+            }
+        }
+    }
+}
+
 }  // namespace swat
 
 SWAT_API int swat_sim_segmented(const float* feats, int64_t n_rows, int d, const float* queries,
@@ -351,3 +500,15 @@ SWAT_API int swat_segment_topk(const float* sims, const float* t2i, const uint8_
                        excluded, seg_offsets, thr, t2i_thr, k, out_idx, out_val, out_cnt);
     return swat::check_launch("swat_segment_topk");
 }
+
+SWAT_API int swat_rank_select(const float* scores, int n_rows, int n_cols, int rank, float* out, const float* q_rows, int d,
+                              void* norm_workspace, float* qnorm_max, swat_stream_t s) {
+    SWAT_REQUIRE(scores && out && n_rows >= 0 && n_cols >= 1 && rank >= 1 && rank <= n_cols, "swat_rank_select: bad arguments");
+    SWAT_REQUIRE(!q_rows || (d >= 1 && norm_workspace && qnorm_max), "swat_rank_select: the norm rider needs d, a workspace and an output");
+    if (n_rows == 0) return 0;
+    float* norms2 = q_rows ? (float*)norm_workspace + 1 : nullptr;   // [0]: the arrival counter (zero before the first use), [1 ..]: |q_r|^2
+    hipLaunchKernelGGL(swat::rank_select_kernel, dim3(n_rows), dim3(swat::RS_THREADS), 0, (hipStream_t)s, scores, n_cols, rank, out, q_rows, d,
+                       norms2, (unsigned*)norm_workspace, qnorm_max);
+    return swat::check_launch("swat_rank_select");
+}
+

@@ -32,14 +32,15 @@ def sim_matrix(queries, db):
 _sample = {}
 
 
-def _thresholds(queries, db, k, sample, boost, approx=False):
+def _thresholds(queries, db, k, sample, boost, approx=False, want_qnorm=False):
     """Per-query pruning threshold from a strided row sample: the value at the rank that should leave ~boost*k rows.
     (16 384 sample rows put the rank near 30 for k = 500 of 1.25 M: the kept count scatters by ~20 % around boost*k,
     well inside [k, CAP]; the caller re-brackets when it does not.)"""
     n = db.shape[0]
     nq = queries.shape[0]
     if n <= CAP // 2:
-        return torch.full((nq,), float("-inf"), device=db.device)
+        t = torch.full((nq,), float("-inf"), device=db.device)
+        return (t, queries.norm(dim=1).max().reshape(1)) if want_qnorm else t
     ns = min(n, sample)
     stride = n // ns
     # the strided row sample depends on the shard only: kept per database object / version (33 MB gathered per call otherwise)
@@ -50,33 +51,29 @@ def _thresholds(queries, db, k, sample, boost, approx=False):
         _sample.update(key=skey, ref=weakref.ref(db), rows=db[::stride][:ns].contiguous())
     smp = _sample["rows"]
     d = db.shape[1]
+    bkey = ("buf", nq, ns, d)
+    if bkey not in _sample:   # per-shape buffers (a cold call is ~0.6 ms: allocations and extra launches count)
+        _sample[bkey] = (torch.empty((nq, ns), dtype=torch.float32, device=db.device), torch.empty((nq, d), dtype=torch.bfloat16, device=db.device),
+                         torch.empty(nq, dtype=torch.float32, device=db.device), torch.zeros(nq + 1, dtype=torch.float32, device=db.device),
+                         torch.empty(1, dtype=torch.float32, device=db.device))
+    S, qbf, thr, nws, qn2 = _sample[bkey]
     if approx and d % 64 == 0 and ns % 4 == 0:
         # the candidate pass compares bf16 MFMA scores with these thresholds, so bf16 sample scores serve as well as exact ones and
         # cost a sixth: one bf16 GEMM [n_q, d] x [n_s, d]^T (the step's own product kernels) instead of the f32-matrix-core scan
         from .. import ops as aops
         if "rows_bf16" not in _sample:
             _sample["rows_bf16"] = aops.cast_bf16(smp)
-        S = torch.empty((nq, ns), dtype=torch.float32, device=db.device)
-        aops.gemm(aops.NT, aops.cast_bf16(queries), _sample["rows_bf16"], nq, ns, d, d, d, S, ns)
+        aops.gemm(aops.NT, aops.cast_bf16(queries, out=qbf), _sample["rows_bf16"], nq, ns, d, d, d, S, ns)
     else:
         S = sim_matrix(queries, smp)
     rank = min(ns, 2048, max(int(boost * k * ns / n) + 8, 16))
-    sub = 2048
-    if ns % sub == 0 and ns >= 2 * sub and rank <= sub // 4:
-        # two levels: one workgroup per (query, 2048-score piece) instead of one per query — 200 workgroups walking 16 384
-        # scores each took 160 us of a 0.9 ms cold call; the rank-th value of the union of the pieces' top `rank` is the same
-        parts = ns // sub
-        okey = ("off", nq, ns, rank)
-        if okey not in _sample:
-            _sample[okey] = (torch.arange(0, nq * ns + 1, sub, device=db.device, dtype=torch.int64),
-                             torch.arange(0, (nq + 1) * parts * rank, parts * rank, device=db.device, dtype=torch.int64))
-        off, off2 = _sample[okey]
-        _, v1, _ = ops.segment_topk(S.view(-1), off, rank, thr=float("-inf"))          # [nq * parts, rank]
-        _, val, _ = ops.segment_topk(v1.reshape(-1), off2, rank, thr=float("-inf"))
-        return val[:, rank - 1].contiguous()
-    off = torch.arange(0, (nq + 1) * ns, ns, device=db.device, dtype=torch.int64)
-    _, val, _ = ops.segment_topk(S.view(-1), off, rank, thr=float("-inf"))
-    return val[:, rank - 1].contiguous()
+    # the rank-th largest sample score of every query: one radix-select launch (csrc/retrieval.hip rank_select_kernel; the two
+    # sorting launches it replaces took 62 us)
+    # (rider: max |q| for the completeness proof, from the same launch)
+    _lib.check(_lib.lib().swat_rank_select(_lib.ptr(S), nq, ns, rank, _lib.ptr(thr), _lib.ptr(queries) if want_qnorm else None, d,
+                                           _lib.ptr(nws) if want_qnorm else None, _lib.ptr(qn2) if want_qnorm else None, _lib.stream()),
+               "swat_rank_select")
+    return (thr, qn2) if want_qnorm else thr
 
 
 def topk_dense_exact(db, queries, k, row_base=0, sample=16384):
@@ -157,7 +154,7 @@ def _prepared(db, queries, k, sample):
         nq, d = queries.shape
         b = _shape_buffers(nq, d, k, db.device)
         K2 = b["K2"]
-        thr = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)), approx=True)
+        thr, qn2 = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)), approx=True, want_qnorm=True)
         if b["packed"]:
             qb = b["qb"]
             _lib.check(_lib.lib().swat_dense_pack_queries(_lib.ptr(queries), nq, d, _lib.ptr(qb), _lib.stream()), "swat_dense_pack_queries")
@@ -167,7 +164,7 @@ def _prepared(db, queries, k, sample):
         _cache.clear()
         _cache.update(b)
         _cache.update(key=key, db_ref=weakref.ref(db), q_ref=weakref.ref(queries), ptrs=(db.data_ptr(), queries.data_ptr()),
-                      thr=thr, qb=qb, qn2=queries.norm(dim=1).max().reshape(1),   # max |q| stays on the device: no host sync
+                      thr=thr, qb=qb, qn2=qn2,   # max |q| stays on the device (a rider of the threshold launch): no host sync
                       cnt_clean=clean, shape=b)
     return _cache
 

@@ -31,6 +31,7 @@
 // Shapes: M % 256 == 0, N % 128 == 0, K % 64 == 0 (the dispatcher cuts other shapes into a served part and a remainder).
 #include <hip/hip_ext.h>
 #include <string.h>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include "gemm_device.hpp"
@@ -657,6 +658,8 @@ int launch_gemm_xl_table(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t
         unsigned long long tick = 0;
     };
     static Cache cache[16];
+    static std::mutex cache_mutex;   // (host threads driving different streams of one device share the slots)
+    std::lock_guard<std::mutex> lock(cache_mutex);
     int devi = 0;
     if (hipGetDevice(&devi) != hipSuccess || devi < 0 || devi >= 16) return 1;
     Cache& c = cache[devi];

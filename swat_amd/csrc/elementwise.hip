@@ -455,6 +455,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             float va[4] = {vn[u][0], vn[u][1], vn[u][2], vn[u][3]};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+#pragma clang fp contract(off)   // every AdamW form of the library rounds each operation: their results are identical by construction
                 int sg = 0;
 #pragma unroll
                 for (int q = 1; q < 4; ++q) sg += (q < segs.n && e + k >= segs.begin[q]) ? 1 : 0;
@@ -495,6 +496,7 @@ __global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p
         float pa[4] = {pn.x, pn.y, pn.z, pn.w}, ga[4] = {gn.x, gn.y, gn.z, gn.w}, ma[4] = {mn.x, mn.y, mn.z, mn.w}, va[4] = {vn.x, vn.y, vn.z, vn.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+#pragma clang fp contract(off)
             const float gg = ga[k] * grad_scale;
             pa[k] *= 1.0f - lr * wd;
             ma[k] = beta1 * ma[k] + (1.0f - beta1) * gg;

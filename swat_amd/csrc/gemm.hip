@@ -832,13 +832,22 @@ int gemm_dispatch(int layout, const GemmArgs& a, int batch, hipStream_t s) {
         const bool ok = batch == 1 && a.inner == 1 && Mmain >= 256 && !a.rpg && !a.rowbias && gemm_xl_serves(layout, m) &&
                         (a.M == Mmain || ((int64_t)Mmain * a.ldc) % 8 == 0);
         if (ok) {
-            rc = launch_gemm_xl(layout, &m, 1, s, ev0, ev1, g_exp, g_trace_host);
+            // up to 32 remainder rows ride in the launch's tail phase (gemm_xl.hip); more (or shapes the scheme does not take) go to a
+            // second launch below
+            int tail = 0;
+            if (a.M > Mmain && a.M - Mmain <= 32 && !(g_exp & 32768)) {
+                GemmArgs r = a;
+                r.M = a.M - Mmain;
+                r.A = a.A + (int64_t)Mmain * a.lda;
+                if (gemm_skinny_serves(layout, r)) tail = a.M - Mmain;
+            }
+            rc = launch_gemm_xl(layout, &m, 1, s, ev0, ev1, g_exp, g_trace_host, tail ? &tail : nullptr);
             if (prof) {
                 g_prof.kind[g_prof.n] = layout == L_TN ? 10 : 11;
                 g_prof.flops[g_prof.n] = 2.0 * Mmain * a.N * a.K;
                 ++g_prof.n;
             }
-            if (rc == 0 && a.M > Mmain) {
+            if (rc == 0 && a.M > Mmain && !tail) {
                 GemmArgs r = a;
                 r.M = a.M - Mmain;
                 r.A = a.A + (int64_t)Mmain * a.lda;

@@ -15,86 +15,21 @@
 // Epilogue: gemm_epilogue of gemm_device.hpp (bias, fp32 residual, activation + second output, dgrad x act', bf16 / fp32).
 #include <hip/hip_ext.h>
 #include <type_traits>
-#include "gemm_device.hpp"
+#include "gemm_skinny_device.hpp"
 #include "../../include/swat_hip.h"
 
 namespace swat {
 
-constexpr int SK_WAVES = 8;
 
 template <int LAYOUT, int FM>
 __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(const GemmArgs p) {
-    static_assert(LAYOUT == L_NT || LAYOUT == L_NN, "forward and data-gradient products");
     __shared__ __attribute__((aligned(16))) unsigned char bounce[SK_WAVES][2][32 * 32];   // NN: [32 k][16 n] bf16 per wave and 32-deep step
     __shared__ __attribute__((aligned(16))) float part[SK_WAVES][FM][64][4];             // the waves' partial accumulators
-    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 16;
-    const int M = p.M, N = p.N;
-    const int nhw = (p.K >> 5) / SK_WAVES;          // 32-deep half steps per wave (K % 256 == 0)
-    const int h0 = wave * nhw;
-    // A fragments: lane (r16, g) reads k = 32 h + 8 g .. + 7 of row 16 i + r16 (rows beyond M: the last row, masked in the epilogue)
-    const unsigned short* arow[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        int m = 16 * i + r16;
-        m = m < M ? m : M - 1;
-        arow[i] = p.A + (int64_t)m * p.lda + 8 * g + 32 * h0;
-    }
     f32x4_t acc[FM][1];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) acc[i][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const unsigned short* bsrc;
-    int64_t bstep;
-    if constexpr (LAYOUT == L_NT) {
-        int n = n0 + r16;
-        n = n < N ? n : N - 1;
-        bsrc = p.B + (int64_t)n * p.ldb + 8 * g + 32 * h0;   // lane (r16, g): k = 32 h + 8 g .. + 7 of weight row n
-        bstep = 32;
-    } else {
-        // B = W [K][N]: lane loads 16 B = columns 8 (lane & 1) .. + 7 of k-row 32 h + (lane >> 1) — 32 rows x 32 B per half step —
-        // parks them row-major in the wave's bounce buffer; the fragment (8 consecutive k of column r16) comes back through two
-        // transposed reads
-        int nc = n0 + 8 * (lane & 1);
-        nc = nc + 8 <= p.ldb ? nc : 0;   // columns beyond the matrix: any readable address (masked in the epilogue)
-        bstep = (int64_t)32 * p.ldb;
-        bsrc = p.B + (int64_t)(lane >> 1) * p.ldb + nc + h0 * bstep;
-    }
-    const unsigned wr_off = (unsigned)((lane >> 1) * 32 + 16 * (lane & 1));
-    const unsigned rd_lo = (unsigned)((8 * g + (r16 >> 2)) * 32 + 8 * (r16 & 3)), rd_hi = rd_lo + 4 * 32;
-    // groups of U half steps: all of a group's loads (U x (FM + 1) x 16 B per lane) go out before its first MFMA; the eight waves of
-    // the workgroup (each on its own eighth of the reduction) hide one another's latencies
-    constexpr int U = 8;
-    for (int hb = 0; hb < nhw; hb += U) {
-        bf16x8_t fa[U][FM];
-        u32x4_t fb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int h = hb + u;
-            h = h < nhw ? h : nhw - 1;
-            fb[u] = *reinterpret_cast<const u32x4_t*>(bsrc + h * bstep);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) fa[u][i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + 32 * h);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (hb + u < nhw) {
-                bf16x8_t b;
-                if constexpr (LAYOUT == L_NT) {
-                    b = __builtin_bit_cast(bf16x8_t, fb[u]);
-                } else {
-                    unsigned char* buf = bounce[wave][u & 1];
-                    *reinterpret_cast<u32x4_t*>(buf + wr_off) = fb[u];
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + rd_lo));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + rd_hi));
-                    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    b = __builtin_bit_cast(bf16x8_t, v);
-                }
-#pragma unroll
-                for (int i = 0; i < FM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, fa[u][i], acc[i][0], 0, 0, 0);
-            }
-        }
-    }
+    skinny_partial<LAYOUT, FM>(p, n0, wave, lane, &bounce[wave][0][0], acc);
     // the eight partial sums, added in wave order by wave 0 (a fixed order: results are bit-identical from run to run)
 #pragma unroll
     for (int i = 0; i < FM; ++i) *reinterpret_cast<f32x4_t*>(&part[wave][i][lane][0]) = acc[i][0];
@@ -114,11 +49,15 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(const GemmAr
 }
 
 // -> 0 launched, 1 not served (the caller takes another kernel), < 0 error
-int launch_gemm_skinny(int layout, const GemmArgs& a, hipStream_t s) {
+bool gemm_skinny_serves(int layout, const GemmArgs& a) {
     if ((layout != L_NT && layout != L_NN) || a.M < 1 || a.M > 64 || a.N < 1 || a.K % (32 * SK_WAVES) || a.K < 32 * SK_WAVES || a.inner > 1 || a.lda % 8 || a.ldb % 8 ||
         a.rpg || a.rowbias || a.colsum || ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15))
-        return 1;
-    if (layout == L_NN && a.N % 8) return 1;
+        return false;
+    return !(layout == L_NN && a.N % 8);
+}
+
+int launch_gemm_skinny(int layout, const GemmArgs& a, hipStream_t s) {
+    if (!gemm_skinny_serves(layout, a)) return 1;
     const dim3 grid((a.N + 15) / 16), block(64 * SK_WAVES);
     const bool two = a.M <= 32;
     if (layout == L_NT) {

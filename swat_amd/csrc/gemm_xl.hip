@@ -34,7 +34,7 @@
 #include <mutex>
 #include <type_traits>
 #include <utility>
-#include "gemm_device.hpp"
+#include "gemm_skinny_device.hpp"
 #include "../../include/swat_hip.h"
 
 namespace swat {
@@ -47,6 +47,7 @@ constexpr int XL_MAXP = 8;
 struct XlProb {
     GemmArgs g;
     int tiles_m, tiles_n, tile0;
+    int tail;   // NT / NN: rows beyond g.M (<= 32) the launch's TAIL PHASE computes (csrc/gemm_skinny_device.hpp); 0 = none
 };
 struct XlArgs {
     XlProb p[XL_MAXP];
@@ -242,11 +243,10 @@ __device__ __forceinline__ void xl_epilogue(const GemmArgs& p, f32x4_t (&acc)[4]
     else xl_epi_bf16<false, false>(p, acc, mbase, nbase, lane);
 }
 
-template <int LAYOUT, bool ABL, class Args = XlArgs>
-__global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const Args a) {
+template <int LAYOUT, bool ABL, class Args>
+__device__ __forceinline__ void xl_main(const Args& a, unsigned char* smem) {
     constexpr bool A_KC = (LAYOUT != L_TN);
     constexpr bool B_KC = (LAYOUT == L_NT);
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[XL_NS * XL_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     auto stamp = [&](int i) {
@@ -549,6 +549,7 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const Args a) {
                                     float pa[4], ma[4], va[4];
 #pragma unroll
                                     for (int k = 0; k < 4; ++k) {
+#pragma clang fp contract(off)   // (as adamw_kernel: every operation rounded — the forms agree bit for bit whatever the optimiser fuses elsewhere)
                                         const float gg = acc[i][j][k] * a.adam.gscale;
                                         pa[k] = pn[j][k] * (1.0f - ad_lr * a.adam.wd);
                                         ma[k] = a.adam.b1 * mn[j][k] + (1.0f - a.adam.b1) * gg;
@@ -590,6 +591,67 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const Args a) {
     }
 }
 
+// The launch: the persistent tile loop, then (NT / NN) the TAIL PHASE — the up to 32 rows a product has beyond its last 256-row tile,
+// spread over ALL workgroups of the launch: 16 output columns per workgroup and turn, the eight consumer waves an eighth of the reduction
+// each, partial sums added in wave order in LDS (the remainder-row kernel's scheme, csrc/gemm_skinny.hip — as a launch of its own it
+// cost 8-13 us per product, 192 times per ViT-L/14 step, almost all of it launch latency).
+template <int LAYOUT, bool ABL, class Args = XlArgs>
+__global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const Args a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[XL_NS * XL_STAGE];
+    xl_main<LAYOUT, ABL, Args>(a, smem);
+    if constexpr (LAYOUT != L_TN && std::is_same<Args, XlArgs>::value) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < XL_MAXP; ++i) any = any || (i < a.n && a.p[i].tail > 0);
+        if (!any) return;
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave is out of the tile loop: the ring is free
+        float* part = reinterpret_cast<float*>(smem + 16384);   // [2 turns][8 waves][2 fragments][64 lanes][4]; bounce buffers: smem[0 .. 16 K)
+        for (int pi = 0; pi < a.n; ++pi) {
+            const int tr = a.p[pi].tail;
+            if (tr <= 0) continue;
+            GemmArgs gt = a.p[pi].g;
+            {
+                const int64_t mm = gt.M, co = mm * gt.ldc;
+                gt.A = gt.A + mm * gt.lda;
+                if (gt.C) gt.C = gt.out_f32 ? (void*)((float*)gt.C + co) : (void*)((unsigned short*)gt.C + co);
+                if (gt.C2) gt.C2 = (unsigned short*)gt.C2 + co;
+                if (gt.residual) gt.residual = gt.residual + co;
+                if (gt.actin) gt.actin = gt.actin + mm * gt.ldact;
+                gt.M = tr;
+            }
+            const int ngroups = (gt.N + 15) >> 4;
+            int turn = 0;
+            for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+                f32x4_t acc[2][1];
+                float* mypart = part + turn * (SK_WAVES * 2 * 64 * 4);
+                if (wave < SK_WAVES) {
+                    skinny_partial<LAYOUT, 2>(gt, 16 * grp, wave, lane, smem + wave * 2048, acc);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4_t*>(mypart + ((wave * 2 + i) * 64 + lane) * 4) = acc[i][0];
+                }
+                __syncthreads();   // (two turns of partial buffers: the next turn's writes cannot overtake this turn's reads)
+                if (wave == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        f32x4_t sum = *reinterpret_cast<const f32x4_t*>(mypart + (i * 64 + lane) * 4);
+#pragma unroll
+                        for (int w = 1; w < SK_WAVES; ++w) {
+                            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(mypart + ((w * 2 + i) * 64 + lane) * 4);
+                            sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+                        }
+                        acc[i][0] = sum;
+                    }
+                    gemm_epilogue<2, 1>(gt, acc, 0, 16 * grp, lane, 0, 0);
+                }
+                turn ^= 1;
+            }
+        }
+    }
+}
+
 // Can the 256 x 128 kernel take this product as it stands?  (whole tiles, 16-byte rows, plain batch-1 product)
 bool gemm_xl_serves(int layout, const GemmArgs& g) {
     if (g.inner > 1 || g.M % XL_BM || g.N % XL_BN || g.K % 64 || g.K < 64 || g.lda % 8 || g.ldb % 8) return false;
@@ -607,7 +669,8 @@ bool gemm_xl_serves(int layout, const GemmArgs& g) {
 }
 
 // n <= 8 products of one layout over one joint tile list.  -> 0 launched, 1 not served, < 0 error
-int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp, unsigned long long* trace) {
+int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp, unsigned long long* trace,
+                   const int* tails) {
     if (n < 1 || n > XL_MAXP) return 1;
     XlArgs a{};
     a.n = n;
@@ -618,6 +681,8 @@ int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipE
         a.p[i].tiles_m = probs[i].M / XL_BM;
         a.p[i].tiles_n = probs[i].N / XL_BN;
         a.p[i].tile0 = total;
+        a.p[i].tail = (tails && layout != L_TN) ? tails[i] : 0;
+        if (a.p[i].tail < 0 || a.p[i].tail > 32) return 1;
         total += a.p[i].tiles_m * a.p[i].tiles_n;
     }
     if (total == 0) return 1;

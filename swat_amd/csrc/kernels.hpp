@@ -52,7 +52,9 @@ int launch_gemm_pc_group(int layout, const GemmArgs* probs, int n, hipStream_t s
 int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp = 0, unsigned long long* trace = nullptr);
 // 256 x 128 tiles, loader / consumer waves, persistent over the joint tile list of n <= 8 products of one layout (gemm_xl.hip)
 bool gemm_xl_serves(int layout, const GemmArgs& g);
-int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp = 0, unsigned long long* trace = nullptr);
+int launch_gemm_xl(int layout, const GemmArgs* probs, int n, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int exp = 0, unsigned long long* trace = nullptr,
+                   const int* tails = nullptr);   // tails[i] (NT / NN): 0 .. 32 rows beyond probs[i].M computed by the launch's tail phase
+bool gemm_skinny_serves(int layout, const GemmArgs& a);   // the remainder-row scheme's shape conditions (gemm_skinny.hip)
 // AdamW applied to a weight-gradient tile while it is still in the accumulators (torch.optim.AdamW semantics and the arithmetic of
 // adamw_kernel, csrc/elementwise.hip — ref utils/optimizers.py:131-146): the gradient is never written; parameter, moments and the
 // bf16 shadow are read / written at the arena offset of the product's output (C - gbase).  One learning-rate group.

@@ -612,7 +612,7 @@ def decode_secondary(dev, bsz=32, h=375, w=500, steps=20, with_cpu=True):
     torch.manual_seed(0)
     geo = [tf.geometry(w, h) for _ in range(bsz)]
     sizes = [(w, h)] * bsz
-    threads = min(16, os.cpu_count() or 1)
+    threads = min(32, os.cpu_count() or 1)
     out = tf.from_jpeg(files, geometry=geo, sizes=sizes, threads=threads)
     # the check: the same files through Pillow + the same device transform (itself pinned to Pillow, tests/test_gpu_preprocess.py)
     same = bool(torch.equal(out, tf([Image.open(io.BytesIO(f)).convert("RGB") for f in files], geometry=geo)))

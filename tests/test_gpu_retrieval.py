@@ -488,6 +488,41 @@ def test_saved_index_shards_merge_to_the_single_gpu_answer(tmp_path, world):
     assert torch.equal(m_val[valid], w_val[valid])
 
 
+@pytest.mark.parametrize("ns,rank", [(16384, 41), (16384, 1), (16384, 2048), (5000, 17), (1024, 1024), (40000, 33), (777, 5)])
+def test_rank_select_is_the_rank_th_largest_of_every_row(ns, rank):
+    """swat_rank_select (the dense top-k's pruning thresholds: the score at a small rank of each query's sample scores) against a full
+    sort: exact for every shape — rows in registers (<= 16 384 scores) through the maxima / survivors path, ranks beyond 1 024 and
+    longer rows through the plain bisection, ties across the rank, negative scores and zeros of both signs; the rider's max |q| is an
+    upper bound within 2^-19 of torch's."""
+    from swat_amd import _lib
+    L = _lib.lib()
+    dev = _dev()
+    g = torch.Generator().manual_seed(ns + rank)
+    nq, d = 37, 512
+    S = (torch.randn(nq, ns, generator=g) * 0.07)
+    S[1] = torch.round(S[1] * 50) / 50          # many exact ties (also across the rank)
+    S[2, ::3] = 0.0
+    S[2, 1::3] = -0.0
+    S[3] = -S[3].abs()                          # all negative
+    S[4] = S[4, 0]                              # one value only
+    S = S.to(dev).contiguous()
+    q = torch.randn(nq, d, generator=g).to(dev)
+    out = torch.empty(nq, device=dev)
+    ws = torch.zeros(nq + 1, device=dev)
+    qn = torch.empty(1, device=dev)
+    for rider in (True, False, True):           # (twice with the rider: its arrival counter resets itself)
+        out.fill_(7.0)
+        _lib.check(L.swat_rank_select(_lib.ptr(S), nq, ns, rank, _lib.ptr(out), _lib.ptr(q) if rider else None, d,
+                                      _lib.ptr(ws) if rider else None, _lib.ptr(qn) if rider else None, _lib.stream()), "swat_rank_select")
+        want = torch.sort(S, dim=1, descending=True).values[:, rank - 1]
+        assert torch.equal(out == 0, want == 0) and torch.equal(torch.where(out == 0, torch.zeros_like(out), out),
+                                                                torch.where(want == 0, torch.zeros_like(want), want))
+        if rider:
+            ref = q.norm(dim=1).max().item()
+            assert ref <= qn.item() <= ref * (1 + 2.0 ** -19)
+    assert ws[0].item() == 0.0
+
+
 def test_shard_merge_of_more_than_8192_gathered_entries_per_query():
     """8 ranks x k = 2 048 gathered entries per query are beyond the library merge's 8 192 keys: merge_topk takes its stable
     descending sort there — the same lists as the library merge gives on the first 8 192 and as a host stable sort gives on all."""

@@ -1,8 +1,12 @@
 """Baseline-JPEG decode on host threads + GPU (include/swat_hip.h `swat_jpeg_*`, csrc/jpeg.hip): the loaders' per-image
 `Image.open(path).convert('RGB')` (ref: utils/datasets/dataset_utils.py:130-180, retrieval/extract_mined_feature.py:103-117) for a
-whole batch, bytes identical to Pillow's.  Files this path does not take (progressive, CMYK, unusual sampling, not a JPEG) are decoded
-by Pillow on the host and uploaded into the same buffer, so a caller always gets every image.
+whole batch, bytes identical to Pillow's.  Files of OTHER FORMATS (progressive / arithmetic-coded / CMYK JPEG, unusual sampling, PNG,
+...) are decoded by the reference's own decoder, Pillow, on the host and uploaded into the same buffer, so a caller always gets
+every image — counted in `stats`, announced once, and refused with SWAT_JPEG_STRICT=1.  This is format coverage, not a fallback for
+the HIP library: without libswat_hip.so every call here raises.
 """
+import os
+import warnings
 import ctypes
 import io
 
@@ -20,7 +24,19 @@ def info(data):
     return (w.value, h.value) if rc == 0 else None
 
 
+stats = {"device": 0, "host_other_format": 0}   # images decoded by the HIP path / handed to Pillow because of their format
+_warned = False
+
+
 def _pil_rgb(data):
+    global _warned
+    if os.environ.get("SWAT_JPEG_STRICT", "0") == "1":
+        raise _lib.SwatHipError("swat_amd.jpeg: a file is not a baseline JPEG the HIP decoder takes (SWAT_JPEG_STRICT=1)")
+    if not _warned:
+        warnings.warn("swat_amd.jpeg: a file is not a baseline JPEG the HIP decoder takes (progressive / CMYK / another format): "
+                      "decoded by Pillow on the host — counted in swat_amd.jpeg.stats")
+        _warned = True
+    stats["host_other_format"] += 1
     from PIL import Image
     return np.asarray(Image.open(io.BytesIO(bytes(data))).convert('RGB'), dtype=np.uint8)
 
@@ -62,6 +78,7 @@ def decode_batch(files, device='cuda', sizes=None, threads=0, stream=None, tail_
                     fallback[i] = _pil_rgb(arrs[i])
                     if fallback[i].shape[:2] != shapes[i]:
                         raise _lib.SwatHipError(f"image {i}: size {fallback[i].shape[:2]} differs from the announced {shapes[i]}")
+            stats["device"] += n - len(fallback)
             for i, a in fallback.items():
                 pixels[offsets[i]:offsets[i] + a.size].copy_(torch.from_numpy(np.ascontiguousarray(a).reshape(-1)), non_blocking=False)
     return pixels, offsets, shapes

@@ -33,6 +33,7 @@ def test_decode_batch_equals_pillow_byte_for_byte():
     files.append(b.getvalue())
     want.append(np.asarray(Image.open(io.BytesIO(files[-1])).convert("RGB")))
     assert np.array_equal(jo.decode(files[3]), want[3])                            # (the oracle is the checker, spot-checked here too)
+    n_dev0, n_host0 = jpeg.stats["device"], jpeg.stats["host_other_format"]
     for threads in (1, 4):
         pixels, offsets, shapes = jpeg.decode_batch(files, "cuda:0", threads=threads)
         host = pixels.cpu().numpy()
@@ -41,6 +42,17 @@ def test_decode_batch_equals_pillow_byte_for_byte():
             assert (h, w) == w_.shape[:2]
             got = host[offsets[i]:offsets[i] + 3 * h * w].reshape(h, w, 3)
             assert np.array_equal(got, w_), (i, threads, np.abs(got.astype(int) - w_.astype(int)).max())
+    # the two files of other formats went to Pillow — visibly: counted, and refused in strict mode; every baseline file ran on the device
+    assert jpeg.stats["host_other_format"] - n_host0 == 2 * 2 and jpeg.stats["device"] - n_dev0 == 2 * (len(files) - 2)
+    import os
+    from swat_amd import _lib
+    os.environ["SWAT_JPEG_STRICT"] = "1"
+    try:
+        with pytest.raises(_lib.SwatHipError):
+            jpeg.decode_batch(files, "cuda:0")
+        jpeg.decode_batch(files[:-2], "cuda:0")
+    finally:
+        del os.environ["SWAT_JPEG_STRICT"]
     one = jpeg.decode(files[10], "cuda:0")
     assert np.array_equal(one.cpu().numpy(), want[10])
 

@@ -356,7 +356,9 @@ int swat_vit_fused_adamw_consumed(void);
  *     goes to memory); 0 not at all (the arming is dropped, the caller's own launch follows).  Results are bit-identical. */
 int swat_vit_set_block_adamw(int mode);
 /* A3+A4+A6 fused with their backward (ref utils/training.py:1475-1481): loss, d/dfeats, d/dW_head,
- *     d/dlogit_scale.  want_grad = 0: forward only (validate, testing.py:430-447); z_out / feat_norm_out
+ *     d/dlogit_scale.  want_grad = 0: forward only (validate, testing.py:430-447); 2 then 3: the same call in two parts on the
+ *     same workspace and arguments — 2 issues what the tower's backward waits for (d/dfeats), 3 the batch means (loss,
+ *     d/dlogit_scale, loss_accum) and d/dW_head, which only the optimizer and the logger read; z_out / feat_norm_out
  *     optionally receive the un-scaled head output and the normalised features.  normalize = 0: feats are
  *     pre-extracted unit-norm features and are used as they are (train_probing, utils/training.py:96-97). */
 int64_t swat_head_loss_workspace_bytes(int B, int E, int C);

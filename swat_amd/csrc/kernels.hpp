@@ -103,6 +103,11 @@ int ln_bwd_finish_blocks(const float* part, int nblk, int d, float* dgamma, floa
 int ln_bwd_finish_sets(const float* const* part, float* const* dgamma, float* const* dbeta, float* const* dcolsum, int nsets, int nblk, int d,
                        hipStream_t s);
 
+// swat_ce_mixed's two launches (tail.hip): per-sample losses and d logits; their batch means (loss, d logit_scale, running sum)
+int launch_ce_rows(const float* z, const float* logit_scale_dev, const int64_t* ya, const int64_t* yb, float lam, float* per_sample_ws, float* dz,
+                   float* logits_out, int B, int C, hipStream_t s);
+int launch_ce_finish(const float* per_sample_ws, int B, float* loss, float* dlogit_scale, double* loss_accum, hipStream_t s);
+
 // device word that is non-zero while a persistent forward's give-up has not been read by the host (vit_mega.hip); null when no
 // persistent forward has run on the current device.  AdamW and the running loss sum skip their writes while it is set.
 const unsigned* mega_guard_word();

@@ -333,6 +333,22 @@ SWAT_API int swat_l2norm_bwd(const float* y, const float* norms, const float* dy
     return check_launch("swat_l2norm_bwd");
 }
 
+namespace swat {
+// the two halves of swat_ce_mixed as separate launches (vit.hip: swat_head_loss can leave the second — the batch means, which feed
+// nothing on the way to the backward — for later)
+int launch_ce_rows(const float* z, const float* logit_scale_dev, const int64_t* ya, const int64_t* yb, float lam, float* per_sample_ws, float* dz,
+                   float* logits_out, int B, int C, hipStream_t s) {
+    hipLaunchKernelGGL(ce_mixed_kernel, dim3(B), dim3(256), 0, s, z, logit_scale_dev, ya, yb, lam, per_sample_ws, per_sample_ws + B, dz, logits_out,
+                       B, C);
+    return check_launch("ce_mixed_kernel");
+}
+int launch_ce_finish(const float* per_sample_ws, int B, float* loss, float* dlogit_scale, double* loss_accum, hipStream_t s) {
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, s, per_sample_ws, per_sample_ws + B, B, loss, dlogit_scale, loss_accum,
+                       mega_guard_word());
+    return check_launch("ce_finish_kernel");
+}
+}  // namespace swat
+
 SWAT_API int swat_ce_mixed(const float* z, const float* logit_scale_dev, const int64_t* ya, const int64_t* yb, float lam,
                            float* per_sample_ws /* [2*B] */, float* loss, float* dlogit_scale, float* dz,
                            float* logits_out, double* loss_accum, int B, int C, swat_stream_t s) {

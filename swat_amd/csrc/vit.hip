@@ -944,14 +944,23 @@ SWAT_API int swat_head_loss(const float* feats, const float* W, const float* log
     float* ps = dfn + (int64_t)B * E;
     if (feat_norm_out) fn = feat_norm_out;
     if (z_out) z = z_out;
+    if (!normalize) fn = const_cast<float*>(feats);  // pre-extracted, already unit-norm features (train_probing, ref utils/training.py:96-97)
+    // want_grad = 2 / 3: the call in two parts.  2 = what the backward waits for (normalise, logits, per-sample CE and d logits, d feats);
+    // 3 = the rest, on the same workspace: the batch means (loss, d logit_scale, running loss sum) and d W_head, which only the
+    // optimizer and the logger read — the step issues it behind the tower's backward (two launches off the critical path)
+    if (want_grad == 3) {
+        SWAT_REQUIRE(dW && dlogit_scale, "swat_head_loss: gradient outputs are null");
+        TRY(launch_ce_finish(ps, B, loss, dlogit_scale, loss_accum, (hipStream_t)s));
+        TRY(swat_sgemm_small(dz, fn, dW, C, E, B, 1, C, E, 1, E, 1.0f, 0, s));   // dW[c,e]  = sum_b dz[b,c] fn[b,e]
+        return 0;
+    }
     if (normalize) TRY(swat_l2norm_fwd(feats, fn, nrm, B, E, s));
-    else fn = const_cast<float*>(feats);  // pre-extracted, already unit-norm features (train_probing, ref utils/training.py:96-97)
     TRY(swat_sgemm_small(fn, W, z, B, C, E, E, 1, 1, E, C, 1.0f, 0, s));  // z[b,c] = sum_e fn[b,e] W[c,e]
-    TRY(swat_ce_mixed(z, logit_scale_dev, ya, yb, lam, ps, loss, dlogit_scale, want_grad ? dz : nullptr, nullptr, loss_accum,
-                      B, C, s));
+    TRY(launch_ce_rows(z, logit_scale_dev, ya, yb, lam, ps, want_grad ? dz : nullptr, nullptr, B, C, (hipStream_t)s));
+    if (want_grad != 2) TRY(launch_ce_finish(ps, B, loss, dlogit_scale, loss_accum, (hipStream_t)s));
     if (want_grad) {
         SWAT_REQUIRE((dfeats || !normalize) && dW && dlogit_scale, "swat_head_loss: gradient outputs are null");
-        TRY(swat_sgemm_small(dz, fn, dW, C, E, B, 1, C, E, 1, E, 1.0f, 0, s));   // dW[c,e]  = sum_b dz[b,c] fn[b,e]
+        if (want_grad != 2) TRY(swat_sgemm_small(dz, fn, dW, C, E, B, 1, C, E, 1, E, 1.0f, 0, s));   // dW[c,e]  = sum_b dz[b,c] fn[b,e]
         TRY(swat_sgemm_small(dz, W, dfn, B, E, C, C, 1, E, 1, E, 1.0f, 0, s));   // dfn[b,e] = sum_c dz[b,c] W[c,e]
         if (normalize) TRY(swat_l2norm_bwd(fn, nrm, dfn, dfeats, B, E, s));
     }

@@ -132,11 +132,12 @@ class FusedTrainStep:
                                _lib.lib().swat_vit_backward_blocks_fused(self.visual._last_ws[1]))
         ls_ptr = a.flat.data_ptr() + 4 * self.off_ls if self.off_ls is not None else _lib.ptr(self._ls_fixed)
         dls_ptr = g.data_ptr() + 4 * self.off_ls if self.off_ls is not None else _lib.ptr(self._dls_scratch)
-        rc = _lib.lib().swat_head_loss(_lib.ptr(feats), a.flat.data_ptr() + 4 * self.off_head, ls_ptr,
-                                       _lib.ptr(target_a), _lib.ptr(target_b), float(lam), _lib.ptr(ws), _lib.ptr(self.loss),
-                                       _lib.ptr(dfeats), g.data_ptr() + 4 * self.off_head, dls_ptr, None,
-                                       None, None if self._late_loss else _lib.ptr(self.loss_accum), B, self.E, self.C, 1, int(self.train_visual),
-                                       _lib.stream())
+        # (_late_loss: only what the backward waits for now; the batch means and d W_head behind the blocks' backward, _trailing_backward)
+        head_args = [_lib.ptr(feats), a.flat.data_ptr() + 4 * self.off_head, ls_ptr, _lib.ptr(target_a), _lib.ptr(target_b), float(lam),
+                     _lib.ptr(ws), _lib.ptr(self.loss), _lib.ptr(dfeats), g.data_ptr() + 4 * self.off_head, dls_ptr, None, None,
+                     None if self._late_loss else _lib.ptr(self.loss_accum), B, self.E, self.C]
+        self._head_rest = (head_args, int(self.train_visual)) if self._late_loss else None
+        rc = _lib.lib().swat_head_loss(*head_args, 2 if self._late_loss else 1, int(self.train_visual), _lib.stream())
         _lib.check(rc, "swat_head_loss")
         if self.trail:
             return self._trailing_backward(g, dfeats)
@@ -311,6 +312,7 @@ class FusedTrainStep:
                             # (0.07 ms); the main stream first waits for this step's optimizer scalars (uploaded on the lane)
                             main.wait_event(scalars_up)
                             mh = main.cuda_stream
+                            _lib.check(lib.swat_head_loss(*self._head_rest[0], 3, self._head_rest[1], mh), "swat_head_loss")
                             finish_head(mh)
                             lo, hi = self._stage_slices[L + 1]
                             finish(sl["stages"][L + 1], lo, hi - lo, mh)

@@ -355,6 +355,10 @@ int swat_vit_fused_adamw_consumed(void);
  *     block's weight-gradient launch; 2 inside the epilogue of ONE weight-gradient launch over all blocks (the gradient tile never
  *     goes to memory); 0 not at all (the arming is dropped, the caller's own launch follows).  Results are bit-identical. */
 int swat_vit_set_block_adamw(int mode);
+/* The next swat_vit_backward call for stage L+1 alone may leave d proj (read only by the optimizer) pending; the blocks' call that
+ *     follows issues it behind the persistent backward, any other backward / join call flushes it first.  One call; for callers that
+ *     read that stage's gradients only after the blocks' call. */
+int swat_vit_backward_defer_top(void);
 /* A3+A4+A6 fused with their backward (ref utils/training.py:1475-1481): loss, d/dfeats, d/dW_head,
  *     d/dlogit_scale.  want_grad = 0: forward only (validate, testing.py:430-447); 2 then 3: the same call in two parts on the
  *     same workspace and arguments — 2 issues what the tower's backward waits for (d/dfeats), 3 the batch means (loss,

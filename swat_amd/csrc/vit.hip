@@ -467,6 +467,22 @@ struct SideLane {
     }
 };
 static SideLane g_side;
+// d proj = u^T d feats of the stage L+1 backward, left pending for the call that runs the blocks (see there)
+struct PendingProduct {
+    bool on = false;
+    const float *a = nullptr, *b = nullptr;
+    float* c = nullptr;
+    int d = 0, E = 0, B = 0;
+};
+static PendingProduct g_pend_dproj;
+static bool g_defer_top = false;   // swat_vit_backward_defer_top: the caller's promise that the blocks' call comes next (one call)
+static int flush_pending_dproj(hipStream_t s) {
+    if (!g_pend_dproj.on) return 0;
+    const PendingProduct p = g_pend_dproj;
+    g_pend_dproj.on = false;
+    return swat_sgemm_small(p.a, p.b, p.c, p.d, p.E, p.B, 1, p.d, p.E, 1, p.E, 1.0f, 0, s);
+}
+
 static int g_overlap = 1;
 static int g_group_wgrad = 0;  // 1: a block's weight-gradient pairs as one persistent grouped launch each (measured equal in
                                // GEMM time, 3.38 vs 3.30 ms/step: the pair's main loops dominate, not its two launches)
@@ -515,6 +531,7 @@ SWAT_API int swat_vit_lane_follow(swat_stream_t stream) {
 }
 
 SWAT_API int swat_vit_backward_join(swat_stream_t stream) {
+    TRY(flush_pending_dproj((hipStream_t)stream));
     if (!g_side.open) return 0;
     hipEvent_t e = g_side.next();
     SWAT_REQUIRE(e, "cannot create an event");
@@ -555,6 +572,14 @@ SWAT_API int swat_vit_arm_fused_adamw(float* params, const float* grads, float* 
     g_fused_adam.consumed = false;
     return 0;
 }
+// The NEXT swat_vit_backward call for stage L+1 alone may leave d proj (which only the optimizer reads) pending: the call for the
+// blocks that follows issues it behind the persistent backward (any other backward / join call flushes it at once).  For callers
+// that read the stage's gradients only after the blocks' call (swat_amd/step.py, one GPU).
+SWAT_API int swat_vit_backward_defer_top(void) {
+    g_defer_top = true;
+    return 0;
+}
+
 SWAT_API int swat_vit_set_block_adamw(int mode) {
     SWAT_REQUIRE(mode >= 0 && mode <= 2, "swat_vit_set_block_adamw: mode must be 0, 1 or 2");
     g_block_adamw = mode;
@@ -632,13 +657,25 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
     unsigned short* dxb_top = mega_may ? w.mb_dxb + (int64_t)(D.L - 1) * D.Mp * d : nullptr;
     unsigned short* dxb_head = dxb_top ? dxb_top : (one ? w.dxb_r[(D.L - 1) % 3] : w.dxb);
 
+    if (!(mega && stage_hi <= D.L)) {
+        // (a pending d proj of an earlier stage L+1 call and no persistent backward in this call to put it behind: now)
+        if (stage_hi <= D.L) TRY(flush_pending_dproj(s));
+    }
     int ln1_pending = -1, mega_rc = 0;
     void* ln1_ws = nullptr;
     for (int stage = stage_hi; stage >= stage_lo; --stage) {
         if (stage == D.L + 1) {
             SWAT_REQUIRE(dfeats, "swat_vit_backward: dfeats is null");
             // dproj[c,e] = sum_b u[b,c] df[b,e] ; du[b,c] = sum_e df[b,e] proj[c,e]
-            TRY(swat_sgemm_small(w.u, dfeats, grads + O.proj, d, D.E, D.B, 1, d, D.E, 1, D.E, 1.0f, 0, s));
+            // (d proj feeds only the optimizer: when the blocks will run as the persistent backward it is issued BEHIND that launch —
+            // one launch less in front of it; the pending product is flushed by whatever backward / join call comes next otherwise)
+            const bool defer = g_defer_top && mega_may && stage_lo == D.L + 1;
+            g_defer_top = false;
+            if (defer) {
+                g_pend_dproj = PendingProduct{true, w.u, dfeats, grads + O.proj, d, D.E, D.B};
+            } else {
+                TRY(swat_sgemm_small(w.u, dfeats, grads + O.proj, d, D.E, D.B, 1, d, D.E, 1, D.E, 1.0f, 0, s));
+            }
             TRY(swat_sgemm_small(dfeats, params + O.proj, w.du, D.B, d, D.E, D.E, 1, 1, D.E, d, 1.0f, 0, s));
             wait_lane(doneA);
             wait_lane(blk[0]);
@@ -659,10 +696,12 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                                                         w.mb_dh2, w.mb_dh1, w.mb_lnp1, w.mb_lnp2, s);
                        if (rc < 0) mega_rc = rc;
                        if (rc != 0) mega = false;   // not eligible after all (no persistent forward ran): op by op from here
+                       if (rc != 0 && flush_pending_dproj(s) != 0) mega_rc = -1;
                        return rc == 0;
                    }()) {
             // lane: per block the four weight gradients as one launch; the 2 L LayerNorm reductions as one launch behind them
             to_lane();
+            TRY(flush_pending_dproj(s));   // (behind the persistent backward, beside the lane)
             const int nblk = ((D.B + 1) / 2) * 16;
             const int64_t lnp = vit_mega_backward_lnp_bytes(D.B, d) / 4;
             std::vector<const float*> parts;

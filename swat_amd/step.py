@@ -290,6 +290,8 @@ class FusedTrainStep:
                     # of the step — the host then re-runs the whole step, swat_amd/step.py:_recover)
                     for hi_s, lo_s in ((L + 1, L + 1), (L, 1), (0, 0)):
                         if hi_s == lo_s:
+                            if hi_s == L + 1:
+                                lib.swat_vit_backward_defer_top()   # (d proj behind the persistent backward: its AdamW runs there too)
                             self.visual.backward_raw(dfeats, stage_hi=hi_s, stage_lo=lo_s)
                             if hi_s == 0:
                                 lo, hi = self._stage_slices[0]

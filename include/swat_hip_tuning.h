@@ -61,6 +61,9 @@ int swat_vit_mega_trace(void* device_buffer);
 /* The data-gradient chain of the blocks' backward (swat_vit_backward with stage_hi >= L, stage_lo <= 1) as one persistent launch:
  * 0 = op by op, 1 = persistent when eligible (default; env SWAT_VIT_MEGA_BWD).  _inject_failure / _trace: as the forward's. */
 int swat_vit_set_mega_backward(int mode);
+/* swat_head_loss with gradients: 1 (default; env SWAT_HEAD_ROWS) the sample-local path (normalise, logits, per-sample CE, d logits,
+ *     d features) as ONE launch with a workgroup per sample, 0 the five separate launches. */
+int swat_head_set_fused(int on);
 int swat_vit_mega_backward_inject_failure(int launches, int handoff);
 int swat_vit_mega_backward_launches(void);
 /* 1 when swat_vit_backward(dims, .., stage_hi >= L, stage_lo <= 1) would run the blocks as the persistent launch (shape and modes;

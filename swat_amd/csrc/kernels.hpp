@@ -107,6 +107,9 @@ int ln_bwd_finish_sets(const float* const* part, float* const* dgamma, float* co
 int launch_ce_rows(const float* z, const float* logit_scale_dev, const int64_t* ya, const int64_t* yb, float lam, float* per_sample_ws, float* dz,
                    float* logits_out, int B, int C, hipStream_t s);
 int launch_ce_finish(const float* per_sample_ws, int B, float* loss, float* dlogit_scale, double* loss_accum, hipStream_t s);
+// features -> normalise -> logits -> per-sample mixed CE -> d logits -> d features as one launch, a workgroup per sample (tail.hip)
+int launch_head_rows(const float* feats, const float* W, const float* ls, const int64_t* ya, const int64_t* yb, float lam, float* fn, float* nrm,
+                     float* z, float* dz, float* per_sample_ws, float* dfeats, int B, int E, int C, hipStream_t s);
 
 // device word that is non-zero while a persistent forward's give-up has not been read by the host (vit_mega.hip); null when no
 // persistent forward has run on the current device.  AdamW and the running loss sum skip their writes while it is set.

@@ -334,6 +334,147 @@ SWAT_API int swat_l2norm_bwd(const float* y, const float* norms, const float* dy
 }
 
 namespace swat {
+// The head's path from the features to their gradient as ONE launch, a workgroup per sample: L2 normalise -> z = fn W^T -> mixed CE on
+// the scaled logits (ce_mixed_kernel's arithmetic) -> d fn = d z W -> back through the normalisation.  Every step is local to a sample
+// (the batch means and d W_head are not: ce_finish_kernel and the weight-gradient product follow, off the critical path), and each of
+// the five launches this replaces costs 5-14 us of launch latency for a few microseconds of work.  1 024 threads per sample: with a
+// workgroup per sample only B CUs work, each pulling W (C x E fp32, L2-resident) twice, so the loads must be wide (float4) and many —
+// z by a wave per class (lanes split the features), d fn by (class group, float4 of features) threads with eight partial sums per
+// feature added in group order.  Fixed summation orders: repeat runs agree bit
+// for bit.  Outputs as the separate launches leave them: fn, nrm, z, dz, per-sample loss / d logit_scale, d feats.
+constexpr int HR_THREADS = 1024, HR_WAVES = HR_THREADS / 64;
+__global__ __launch_bounds__(HR_THREADS) void head_rows_kernel(const float* __restrict__ feats, const float* __restrict__ W, const float* __restrict__ ls_ptr,
+                                                               const int64_t* __restrict__ ya, const int64_t* __restrict__ yb, float lam,
+                                                               float* __restrict__ fn_out, float* __restrict__ nrm_out, float* __restrict__ z_out,
+                                                               float* __restrict__ dz_out, float* __restrict__ per_loss, float* __restrict__ per_dls,
+                                                               float* __restrict__ dfeats, int B, int E, int C) {
+    extern __shared__ float hr_smem[];   // fn [E] | z [C] | dz [C] | partial d fn [8][E]
+    __shared__ float red[HR_WAVES];
+    float* fn = hr_smem;
+    float* zs = fn + E;
+    float* dzs = zs + C;
+    float* part = dzs + C;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto block_sum = [&](float v) {   // fixed order: lanes by the xor tree, waves 0 .. 15 in sequence
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        float t = red[0];
+#pragma unroll
+        for (int w = 1; w < HR_WAVES; ++w) t += red[w];
+        return t;
+    };
+    const float* x = feats + (int64_t)b * E;
+    // ---- L2 normalise (no eps, ref utils/training.py:333)
+    float s = 0.f;
+    for (int e = tid; e < E; e += HR_THREADS) { const float v = x[e]; s += v * v; }
+    const float n = sqrtf(block_sum(s));
+    for (int e = tid; e < E; e += HR_THREADS) {
+        const float v = x[e] / n;
+        fn[e] = v;
+        fn_out[(int64_t)b * E + e] = v;
+    }
+    if (tid == 0) nrm_out[b] = n;
+    __syncthreads();
+    // ---- z[c] = sum_e fn[e] W[c][e]: a wave per class, lanes split the features by float4 (E % 4 == 0)
+    const int e4n = E >> 2;
+    for (int c = wave; c < C; c += HR_WAVES) {
+        const float4* wr = reinterpret_cast<const float4*>(W + (int64_t)c * E);
+        float a = 0.f;
+        for (int q = lane; q < e4n; q += 64) {
+            const float4 wv = wr[q];
+            const float4 fv = reinterpret_cast<const float4*>(fn)[q];
+            a = fmaf(fv.x, wv.x, a); a = fmaf(fv.y, wv.y, a); a = fmaf(fv.z, wv.z, a); a = fmaf(fv.w, wv.w, a);
+        }
+        a = wave_sum(a);
+        if (lane == 0) {
+            zs[c] = a;
+            z_out[(int64_t)b * C + c] = a;
+        }
+    }
+    __syncthreads();
+    // ---- mixed cross entropy on the scaled logits (the arithmetic of ce_mixed_kernel, sums over 16 waves)
+    const float sc = __expf(ls_ptr[0]);
+    float mx = -INFINITY;
+    for (int c = tid; c < C; c += HR_THREADS) mx = fmaxf(mx, zs[c] * sc);
+    mx = wave_max(mx);
+    __syncthreads();
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < HR_WAVES; ++w) mx = fmaxf(mx, red[w]);
+    float se = 0.f;
+    for (int c = tid; c < C; c += HR_THREADS) se += __expf(zs[c] * sc - mx);
+    se = block_sum(se);
+    const float lse = mx + __logf(se);
+    const int a_i = (int)ya[b], b_i = (int)yb[b];
+    float dls = 0.f;
+    const float invB = 1.0f / (float)B;
+    for (int c = tid; c < C; c += HR_THREADS) {
+        const float l = zs[c] * sc;
+        float gl = __expf(l - lse);
+        if (c == a_i) gl -= lam;
+        if (c == b_i) gl -= (1.0f - lam);
+        gl *= invB;
+        dls += gl * l;
+        const float g = gl * sc;
+        dzs[c] = g;
+        dz_out[(int64_t)b * C + c] = g;
+    }
+    dls = block_sum(dls);   // (its barriers also publish dzs)
+    if (tid == 0) {
+        per_dls[b] = dls;
+        per_loss[b] = lam * (lse - zs[a_i] * sc) + (1.0f - lam) * (lse - zs[b_i] * sc);
+    }
+    // ---- d fn[e] = sum_c dz[c] W[c][e]: thread = (class group cg of 8, float4 of features q), classes cg, cg + 8, ..; the eight partial
+    //      sums of a feature are added in group order; then back through the normalisation: d feats = (d fn - fn <fn, d fn>) / ||x||
+    {
+        const int groups = HR_THREADS / 128;   // 8
+        for (int q0 = 0; q0 < e4n; q0 += 128) {
+            const int q = q0 + (tid & 127), cg = tid >> 7;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < e4n) {
+#pragma unroll 8
+                for (int c = cg; c < C; c += groups) {
+                    const float4 wv = reinterpret_cast<const float4*>(W + (int64_t)c * E)[q];
+                    const float g = dzs[c];
+                    a.x = fmaf(g, wv.x, a.x); a.y = fmaf(g, wv.y, a.y); a.z = fmaf(g, wv.z, a.z); a.w = fmaf(g, wv.w, a.w);
+                }
+                reinterpret_cast<float4*>(part + cg * E)[q] = a;
+            }
+        }
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int e = tid; e < E; e += HR_THREADS) {
+        float a = part[e];
+#pragma unroll
+        for (int gi = 1; gi < HR_THREADS / 128; ++gi) a += part[gi * E + e];
+        part[e] = a;   // (own element: no other thread reads it before the barrier inside block_sum)
+        dot += fn[e] * a;
+    }
+    dot = block_sum(dot);
+    const float inv = 1.0f / n;
+    for (int e = tid; e < E; e += HR_THREADS) dfeats[(int64_t)b * E + e] = (part[e] - fn[e] * dot) * inv;
+}
+
+// -> 0 launched, 1 shapes not served (the caller issues the separate launches)
+int launch_head_rows(const float* feats, const float* W, const float* ls, const int64_t* ya, const int64_t* yb, float lam, float* fn, float* nrm,
+                     float* z, float* dz, float* per_sample_ws, float* dfeats, int B, int E, int C, hipStream_t s) {
+    if (B < 1 || E < 4 || E % 4 || E > 2048 || C < 1 || C > 4096 || ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(feats)) & 15)) return 1;
+    const size_t lds = (size_t)(E + 2 * C + (HR_THREADS / 128) * E) * sizeof(float);   // <= 106 KB
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        SWAT_HIP(hipFuncSetAttribute((const void*)head_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(head_rows_kernel, dim3(B), dim3(HR_THREADS), lds, s, feats, W, ls, ya, yb, lam, fn, nrm, z, dz, per_sample_ws, per_sample_ws + B,
+                       dfeats, B, E, C);
+    return check_launch("head_rows_kernel");
+}
+
 // the two halves of swat_ce_mixed as separate launches (vit.hip: swat_head_loss can leave the second — the batch means, which feed
 // nothing on the way to the backward — for later)
 int launch_ce_rows(const float* z, const float* logit_scale_dev, const int64_t* ya, const int64_t* yb, float lam, float* per_sample_ws, float* dz,

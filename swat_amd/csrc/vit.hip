@@ -970,6 +970,12 @@ SWAT_API int64_t swat_head_loss_workspace_bytes(int B, int E, int C) {
     return ((int64_t)2 * B * E + (int64_t)2 * B * C + 3 * B) * 4 + 1024;
 }
 
+static int g_head_rows = getenv("SWAT_HEAD_ROWS") ? atoi(getenv("SWAT_HEAD_ROWS")) : 1;   // 0: the five separate launches (A/B runs)
+SWAT_API int swat_head_set_fused(int on) {
+    g_head_rows = on ? 1 : 0;
+    return 0;
+}
+
 SWAT_API int swat_head_loss(const float* feats, const float* W, const float* logit_scale_dev, const int64_t* ya,
                             const int64_t* yb, float lam, void* workspace, float* loss, float* dfeats, float* dW,
                             float* dlogit_scale, float* z_out, float* feat_norm_out, double* loss_accum, int B, int E,
@@ -992,6 +998,19 @@ SWAT_API int swat_head_loss(const float* feats, const float* W, const float* log
         TRY(launch_ce_finish(ps, B, loss, dlogit_scale, loss_accum, (hipStream_t)s));
         TRY(swat_sgemm_small(dz, fn, dW, C, E, B, 1, C, E, 1, E, 1.0f, 0, s));   // dW[c,e]  = sum_b dz[b,c] fn[b,e]
         return 0;
+    }
+    if (want_grad && normalize && dfeats && g_head_rows) {
+        // training: the sample-local path as one launch (csrc/tail.hip head_rows_kernel); the batch-wide rest below / in part 3
+        const int rc = launch_head_rows(feats, W, logit_scale_dev, ya, yb, lam, fn, nrm, z, dz, ps, dfeats, B, E, C, (hipStream_t)s);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            SWAT_REQUIRE(dW && dlogit_scale, "swat_head_loss: gradient outputs are null");
+            if (want_grad != 2) {
+                TRY(launch_ce_finish(ps, B, loss, dlogit_scale, loss_accum, (hipStream_t)s));
+                TRY(swat_sgemm_small(dz, fn, dW, C, E, B, 1, C, E, 1, E, 1.0f, 0, s));   // dW[c,e]  = sum_b dz[b,c] fn[b,e]
+            }
+            return 0;
+        }
     }
     if (normalize) TRY(swat_l2norm_fwd(feats, fn, nrm, B, E, s));
     TRY(swat_sgemm_small(fn, W, z, B, C, E, E, 1, 1, E, C, 1.0f, 0, s));  // z[b,c] = sum_e fn[b,e] W[c,e]

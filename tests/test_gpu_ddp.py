@@ -102,7 +102,10 @@ def test_two_ranks_match_one_process_on_the_whole_batch(tmp_path, wire, coll):
     # forward / backward is row-wise identical in both jobs; only the order of the sums over rows differs.
     g2, g1 = got[0][1] / 2, want[1]
     # bf16 wire: every rank's gradient rounded to 8 significant bits and the sum rounded again (2^-7 relative per element)
-    assert ((g2 - g1).norm() / g1.norm()).item() < (2e-3 if wire == "fp32" else 6e-3)
+    # (since round 4 the one-process job runs the persistent backward and the one-launch head at B = 32 while the ranks, at 16 images each,
+    # run op by op: the two differ in the summation order of a few products, which moves ~1 % of the bf16 gradient-stream elements by one
+    # ulp — 2e-3 relative in the norm on its own, tools/mega_bwd_check.py)
+    assert ((g2 - g1).norm() / g1.norm()).item() < (4e-3 if wire == "fp32" else 8e-3)
     got = {r: t[0] for r, t in got.items()}
     want = want[0]
     # weights after three warm-up AdamW steps: Adam's m / sqrt(v) turns a gradient that is zero up to rounding into a

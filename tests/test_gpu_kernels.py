@@ -405,6 +405,59 @@ def test_colsum_and_cast():
     assert torch.equal(ops.cast_bf16(Xf), Xf.to(BF))
 
 
+@pytest.mark.parametrize("B,E,C", [(32, 512, 200), (7, 768, 1000), (64, 512, 37)])
+def test_head_loss_one_launch_per_sample_equals_the_separate_launches_and_torch(B, E, C):
+    """swat_head_loss with gradients (ref utils/training.py:1475-1481, utils/losses.py:10-11): the sample-local path as ONE launch with
+    a workgroup per sample (csrc/tail.hip head_rows_kernel) against the five separate launches and against torch in float64 —
+    loss, d feats, d W_head, d logit_scale; and the two-part form (want_grad 2 then 3) against the one-part form, bit for bit."""
+    import ctypes
+    from swat_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B + C)
+    feats = torch.randn(B, E, generator=g)
+    W = torch.randn(C, E, generator=g)
+    W /= W.norm(dim=1, keepdim=True)
+    ls = torch.tensor([2.6593])
+    ya, yb = torch.randint(0, C, (B,), generator=g), torch.randint(0, C, (B,), generator=g)
+    lam = 0.37
+    f64, W64 = feats.double().requires_grad_(True), W.double().requires_grad_(True)
+    ls64 = ls.double().requires_grad_(True)
+    z = (f64 / f64.norm(dim=1, keepdim=True)) @ W64.t() * ls64.exp()
+    ref = lam * torch.nn.functional.cross_entropy(z, ya) + (1 - lam) * torch.nn.functional.cross_entropy(z, yb)
+    ref.backward()
+
+    def run(fused, parts):
+        L.swat_head_set_fused(fused)
+        d = dev()
+        ws = torch.zeros(L.swat_head_loss_workspace_bytes(B, E, C), dtype=torch.uint8, device=d)
+        loss = torch.zeros(1, device=d); dfe = torch.zeros(B, E, device=d); dW = torch.zeros(C, E, device=d); dls = torch.zeros(1, device=d)
+        acc = torch.zeros(1, dtype=torch.float64, device=d)
+        keep = [feats.to(d), W.to(d), ls.to(d), ya.to(d), yb.to(d)]   # (alive until the synchronise below)
+        args = [_lib.ptr(keep[0]), _lib.ptr(keep[1]), _lib.ptr(keep[2]), _lib.ptr(keep[3]), _lib.ptr(keep[4]), lam, _lib.ptr(ws),
+                _lib.ptr(loss), _lib.ptr(dfe), _lib.ptr(dW), _lib.ptr(dls), None, None, _lib.ptr(acc), B, E, C]
+        for wg in parts:
+            _lib.check(L.swat_head_loss(*args, wg, 1, _lib.stream()), "swat_head_loss")
+        torch.cuda.synchronize()
+        return loss.cpu(), dfe.cpu(), dW.cpu(), dls.cpu(), acc.cpu()
+
+    def rel(a, b_):
+        return ((a - b_).norm() / (b_.norm() + 1e-30)).item()
+
+    try:
+        sep = run(0, (1,))
+        one = run(1, (1,))
+        two = run(1, (2, 3))
+    finally:
+        L.swat_head_set_fused(1)
+    for got in (sep, one):
+        assert abs(got[0].item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+        assert rel(got[1].double(), f64.grad) < 2e-5 and rel(got[2].double(), W64.grad) < 2e-5
+        assert abs(got[3].item() - ls64.grad.item()) < 2e-5 * max(1.0, abs(ls64.grad.item()))
+        assert abs(got[4].item() - got[0].item()) < 1e-6
+    for a, b_ in zip(one, two):
+        assert torch.equal(a, b_)
+
+
 def test_argmax_confusion_follows_torch_argmax_on_ties_and_nans():
     """swat_argmax_confusion (validate's device tail, ref testing.py:449-458): first index of the row maximum, NaN greater than
     everything (several NaNs: the first), like torch.argmax — also on diverged logits."""

@@ -8,8 +8,31 @@
  *
  * Conventions
  *  - plain C: raw DEVICE pointers (tensor.data_ptr()), sizes, a hipStream_t passed as void*.
- *  - row-major contiguous tensors; the caller allocates every output and workspace.
- *  - no hidden allocation, no host synchronisation, stream-ordered, re-entrant, graph-capturable.
+ *  - row-major contiguous tensors; the caller allocates every output and workspace (a *_workspace_bytes
+ *    query per op); every call is stream-ordered and re-entrant.
+ *  - the steady state of every entry point makes NO allocation and NO host synchronisation.  What the library
+ *    owns beyond that is small, per device or per shape, created on FIRST use and kept for the life of the
+ *    process (a caller that captures hipGraphs or measures allocator traffic warms each shape up once):
+ *      * swat_vit_forward / swat_vit_backward in the ViT-B/32 regime (csrc/vit_mega.hip): 2 176 B of device
+ *        hand-off counters + status, one 128-B pinned mapped host word (the give-up flag swat_vit_mega_poll
+ *        reads) and one event per device; persistent launches of a device are ordered behind one another by
+ *        that event (hipStreamWaitEvent, never a host wait).
+ *      * swat_vit_backward / swat_vit_lane_stream / swat_vit_aux_stream: three side streams (weight-gradient
+ *        lane, two auxiliary) and a ring of <= 1 024 ordering events, created once per process, back to back.
+ *      * grouped / table-driven product launches (swat_linear_wgrad_bias_group, the one-launch weight
+ *        gradients inside swat_vit_backward; csrc/gemm_pc.hip, csrc/gemm_xl.hip): a device descriptor table per
+ *        distinct problem list (a few tens of KB + the same pinned; at most 8 table slots per device).  Re-filling a table
+ *        slot whose previous contents may still be in flight calls hipStreamSynchronize on THAT slot's stream
+ *        — only when a ninth distinct problem list evicts the least recently used one, never in a training
+ *        loop (one list per model shape).
+ *      * swat_jpeg_decode_batch: a pinned host staging arena and two device arenas per device, grown
+ *        geometrically to the largest batch seen (growth = hipDeviceSynchronize + reallocation; a steady loader
+ *        reaches its size in the first batches); the pinned buffer's re-use waits on the previous batch's H2D
+ *        copy event (hipEventSynchronize: the host half of the decode fills that buffer), the device arenas'
+ *        re-use across streams is ordered by an event; host entropy-decode threads are kept in a pool.
+ *      * swat_vit_mega_status (a test / diagnostic call) synchronises the device; swat_gemm_prof_* (tuning
+ *        header) own timing events.
+ *    Nothing else allocates, and no compute entry point waits on the host for the GPU.
  *  - return 0 on success, a negative value on error; swat_last_error() has the text
  *    (thread-local).
  *  - dtype enum: SWAT_F32 = 0, SWAT_BF16 = 1.

@@ -6,7 +6,7 @@ golden fixtures under tests/golden/.  Inputs are never stored: every fixture rec
 and the generator below (`synth_*`) is re-run by the tests (numpy's legacy RandomState stream is
 frozen, so the inputs are reproducible bit for bit).
 
-    python oracle/make_golden.py [retrieval] [host] [loop] [vit] [text] [stages]
+    python oracle/make_golden.py [retrieval] [host] [loop] [vit] [text] [stages] ...     (no arguments: every section)
 
 The reference source never travels: fixtures are plain .npz/.json data.
 """
@@ -25,7 +25,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("SWAT_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # (tests regenerate into a scratch directory)
 sys.path.insert(0, ROOT)
 
 from oracle import synth  # noqa: E402  (shared seeded input generators, also used by tests)
@@ -804,8 +804,23 @@ SECTIONS.update({"probing": golden_probing, "prompt_tensors": golden_prompt_tens
 SECTIONS.update({"prompts": golden_prompts, "host": golden_host, "loop": golden_loop, "vit": golden_vit, "text": golden_text, "stages": golden_stages})
 
 
+def _import_hf_first():
+    """The tower sections pin the oracle against HF `transformers`, whose availability probes (`importlib.util.find_spec("torchvision")`)
+    raise on the spec-less torchvision stand-in that ref_shims installs for the reference's imports: when several sections run in one
+    process, transformers and the CLIP classes it loads lazily must be imported BEFORE the first section installs the shims."""
+    try:
+        from transformers import (CLIPTextConfig, CLIPTextModelWithProjection, CLIPVisionConfig,  # noqa: F401
+                                  CLIPVisionModelWithProjection)
+    except ImportError:
+        pass   # the sections that need it will say so
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     todo = sys.argv[1:] or list(SECTIONS)
+    unknown = [s for s in todo if s not in SECTIONS]
+    if unknown:
+        raise SystemExit(f"unknown section(s) {unknown}; choose from {sorted(SECTIONS)}")
+    _import_hf_first()
     for s in todo:
         SECTIONS[s]()

@@ -44,7 +44,7 @@ struct JpegHuff {
 };
 struct JpegFrame {
     int W = 0, H = 0, nc = 0;
-    int h[3] = {0, 0, 0}, v[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int h[3] = {0, 0, 0}, v[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0}, id[3] = {0, 0, 0};
     uint16_t qt[4][64];
     bool qt_ok[4] = {false, false, false, false};
     JpegHuff dc[4], ac[4];
@@ -54,10 +54,28 @@ struct JpegFrame {
     int mx = 0, my = 0;   // MCUs
 };
 
-static void build_huff(JpegHuff& t, const uint8_t* counts, const uint8_t* vals, int n) {
+// -> false: the code counts are not a prefix code (libjpeg's JERR_BAD_HUFF_TABLE: a code of length `len` must be < 2^len; an
+// over-subscribed table would index past the 9-bit lookup) or, for a DC table, a category above 15
+static bool build_huff(JpegHuff& t, const uint8_t* counts, const uint8_t* vals, int n, bool is_dc) {
+    t.present = false;
+    if (n < 0 || n > 256) return false;
+    {
+        int code = 0, k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            code += counts[len - 1];
+            k += counts[len - 1];
+            if (code > (1 << len)) return false;
+            code <<= 1;
+        }
+        if (k != n) return false;
+        if (is_dc)
+            for (int i = 0; i < n; ++i)
+                if (vals[i] > 15) return false;
+    }
     t.present = true;
     memcpy(t.vals, vals, (size_t)n);
     memset(t.look_len, 0, sizeof(t.look_len));
+    memset(t.look_sym, 0, sizeof(t.look_sym));
     int code = 0, k = 0;
     for (int len = 1; len <= 16; ++len) {
         t.valoff[len] = k - code;
@@ -71,13 +89,19 @@ static void build_huff(JpegHuff& t, const uint8_t* counts, const uint8_t* vals, 
         code <<= 1;
     }
     t.maxcode[17] = 0x7fffffff;
+    return true;
 }
+
+// Pillow refuses to decode beyond 2 x Image.MAX_IMAGE_PIXELS (decompression-bomb guard) and warns beyond 1 x: such a file is left to
+// Pillow (status 1) so that its rule, not a 13 GB staging allocation, decides
+static const int64_t kMaxPixels = 89478485;
 
 // -> 0 ok, 1 not a file this path decodes, 2 corrupt
 static int parse_jpeg(const uint8_t* d, size_t n, JpegFrame& f) {
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return 1;
     size_t i = 2;
-    bool have_frame = false;
+    bool have_frame = false, jfif = false, adobe = false;
+    int adobe_transform = -1;
     while (i + 3 < n) {
         if (d[i] != 0xFF) return 2;
         while (i < n && d[i] == 0xFF) ++i;
@@ -106,11 +130,13 @@ static int parse_jpeg(const uint8_t* d, size_t n, JpegFrame& f) {
             f.W = (s[3] << 8) | s[4];
             f.nc = s[5];
             if ((f.nc != 1 && f.nc != 3) || sl < (size_t)(6 + 3 * f.nc) || f.W <= 0 || f.H <= 0) return 1;
+            if ((int64_t)f.W * f.H > kMaxPixels) return 1;
             for (int c = 0; c < f.nc; ++c) {
                 f.h[c] = s[7 + 3 * c] >> 4;
                 f.v[c] = s[7 + 3 * c] & 15;
                 f.tq[c] = s[8 + 3 * c];
                 f.td[c] = s[6 + 3 * c];   // component id, matched against the scan header below
+                f.id[c] = s[6 + 3 * c];
                 if (f.tq[c] > 3) return 2;
             }
             have_frame = true;
@@ -123,8 +149,16 @@ static int parse_jpeg(const uint8_t* d, size_t n, JpegFrame& f) {
                 int cnt = 0;
                 for (int k = 0; k < 16; ++k) cnt += s[j + 1 + k];
                 if (tc > 1 || th > 3 || cnt > 256 || j + 17 + cnt > sl) return 2;
-                build_huff(tc ? f.ac[th] : f.dc[th], s + j + 1, s + j + 17, cnt);
+                if (!build_huff(tc ? f.ac[th] : f.dc[th], s + j + 1, s + j + 17, cnt, tc == 0)) return 2;
                 j += 17 + cnt;
+            }
+            if (j != sl) return 2;   // a truncated table at the segment's end
+        } else if (m == 0xE0) {
+            if (sl >= 5 && memcmp(s, "JFIF", 5) == 0) jfif = true;
+        } else if (m == 0xEE) {
+            if (sl >= 12 && memcmp(s, "Adobe", 5) == 0) {
+                adobe = true;
+                adobe_transform = s[11];
             }
         } else if (m == 0xDD) {
             if (sl < 2) return 2;
@@ -147,7 +181,18 @@ static int parse_jpeg(const uint8_t* d, size_t n, JpegFrame& f) {
     }
     if (!have_frame || !f.scan) return 1;
     if (f.nc == 3) {
+        // colour space as libjpeg's default_decompress_parms picks it: JFIF -> YCbCr; else an Adobe marker decides (transform 0 = the
+        // planes are RGB already); else the component ids ('R','G','B' = RGB).  Everything that is not YCbCr goes to Pillow.
+        if (!jfif) {
+            if (adobe) {
+                if (adobe_transform == 0) return 1;
+            } else if (f.id[0] == 'R' && f.id[1] == 'G' && f.id[2] == 'B') {
+                return 1;
+            }
+        }
         if (f.h[1] != 1 || f.v[1] != 1 || f.h[2] != 1 || f.v[2] != 1) return 1;
+        // (jdsample.c: a chroma row of <= 2 samples is replicated, not interpolated)
+        if (f.h[0] == 2 && (f.W + 1) / 2 <= 2) return 1;
         if (!((f.h[0] == 1 && f.v[0] == 1) || (f.h[0] == 2 && f.v[0] == 1) || (f.h[0] == 2 && f.v[0] == 2))) return 1;
     } else {
         f.h[0] = f.v[0] = 1;   // a single component is never interleaved: its sampling factors do not shape the MCU
@@ -416,9 +461,11 @@ struct JpegArena {
     void* planes = nullptr;
     size_t host_bytes = 0, dev_bytes = 0, plane_bytes = 0;
     hipEvent_t copied = nullptr;   // the last H2D copy out of `host` has finished
-    bool pending = false;
+    hipEvent_t done = nullptr;     // the last call's kernels (they read `dev` and `planes`) have finished
+    hipStream_t last = nullptr;    // ... on this stream
+    bool pending = false, any = false;
 };
-static JpegArena g_jpeg;
+static JpegArena g_jpeg_dev[16];   // one staging arena per device (the calls of a process are serialised by g_jpeg_call)
 
 static int grow(void** p, size_t* have, size_t need, bool pinned) {
     if (*have >= need) return 0;
@@ -570,7 +617,10 @@ SWAT_API int swat_jpeg_decode_batch(const void* const* files, const int64_t* nby
     if (coef_total == 0) return 0;
     const size_t desc_bytes = ((size_t)n * sizeof(JpegDesc) + 255) / 256 * 256;
     const size_t up_bytes = desc_bytes + coef_total * sizeof(int16_t);
-    JpegArena& A = g_jpeg;
+    int dev_i = 0;
+    SWAT_HIP(hipGetDevice(&dev_i));
+    SWAT_REQUIRE(dev_i >= 0 && dev_i < 16, "swat_jpeg_decode_batch: device %d out of range", dev_i);
+    JpegArena& A = g_jpeg_dev[dev_i];
     if (A.pending) {   // the previous batch's copy still reads the pinned buffer
         SWAT_HIP(hipEventSynchronize(A.copied));
         A.pending = false;
@@ -579,6 +629,9 @@ SWAT_API int swat_jpeg_decode_batch(const void* const* files, const int64_t* nby
                      grow(&A.planes, &A.plane_bytes, plane_total + 64, false) == 0,
                  "swat_jpeg_decode_batch: cannot allocate %zu staging bytes", up_bytes);
     if (!A.copied) SWAT_HIP(hipEventCreateWithFlags(&A.copied, hipEventDisableTiming));
+    if (!A.done) SWAT_HIP(hipEventCreateWithFlags(&A.done, hipEventDisableTiming));
+    // the device buffers are re-used: a call on ANOTHER stream first waits for the previous call's kernels (same stream: ordered)
+    if (A.any && A.last != s) SWAT_HIP(hipStreamWaitEvent(s, A.done, 0));
     memcpy(A.host, desc.data(), (size_t)n * sizeof(JpegDesc));
     int16_t* hcoef = (int16_t*)((char*)A.host + desc_bytes);
     // entropy decode: files are independent; threads take them from a shared counter (file sizes differ)
@@ -605,5 +658,11 @@ SWAT_API int swat_jpeg_decode_batch(const void* const* files, const int64_t* nby
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, ddesc, (const uint8_t*)A.planes,
                        (uint8_t*)pixels_u8);
-    return check_launch("swat_jpeg_decode_batch");
+    const int rc = check_launch("swat_jpeg_decode_batch");
+    if (rc == 0) {
+        SWAT_HIP(hipEventRecord(A.done, s));
+        A.last = s;
+        A.any = true;
+    }
+    return rc;
 }

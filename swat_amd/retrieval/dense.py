@@ -87,7 +87,9 @@ def topk_dense_exact(db, queries, k, row_base=0, sample=16384):
     need = min(k, n)
     boost = 3.0
     for attempt in range(6):
-        thr = _thresholds(queries, db, k, sample, boost)
+        # a PRIVATE copy: _thresholds returns the per-shape buffer that topk_dense's cache entry for (db, queries, k) keeps — this
+        # path runs as that call's fallback and must not overwrite the tuned thresholds the cache key stands for
+        thr = _thresholds(queries, db, k, sample, boost).clone()
         cnt.zero_()
         rc = _lib.lib().swat_sim_topk_candidates(_lib.ptr(queries), nq, _lib.ptr(db), n, d, _lib.ptr(thr), int(row_base),
                                                  _lib.ptr(keys), CAP, _lib.ptr(cnt), None, 0, _lib.stream())
@@ -235,6 +237,11 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
         last_path = "exact"
         return topk_dense_exact(db, queries, k, row_base, sample)
     c = _prepared(db, queries, k, sample)
+    if c.get("proof_failed"):
+        # the completeness proof already failed for exactly these tensors: a warm repeat goes straight to the exact scan instead of
+        # paying the candidate pass, a host synchronisation and the exact scan every time
+        last_path = "exact-fallback"
+        return topk_dense_exact(db, queries, k, row_base, sample)
     K2, thr, keys, cnt, n2 = c["K2"], c["thr"], c["keys"], c["cnt"], c["n2"]
     L = _lib.lib()
     if shadow is not None and not shadow.matches(db):
@@ -274,6 +281,7 @@ def topk_dense(db, queries, k, row_base=0, sample=16384, shadow=None):
     if "shape" in c:
         c["shape"]["cnt_clean"] = True
     if c["fails"].item() != 0:  # the one host synchronisation of the call
+        c["proof_failed"] = True
         last_path = "exact-fallback"
         return topk_dense_exact(db, queries, k, row_base, sample)
     last_path = "bf16-shadow-candidates+exact-rescore" if use_shadow else "bf16-candidates+exact-rescore"

@@ -81,7 +81,6 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
     scheduler = args.scheduler
     nranks, rank = dp.world(args), getattr(args, 'rank', 0)
     split_batch = nranks > 1 and not getattr(args, 'dp_weak', False)  # every rank sees the whole --bsz batch, takes its rows
-    dp.sync_rng(args)  # identical shuffles and CutMix draws on every rank from here on
     step = FusedTrainStep(model, classifier_head, logit_scale, optimizer, world_size=nranks)
     # global-batch data parallelism with a rank-aware loader (swat_amd/dp.py RankBatchSampler): this rank's loader yields only its
     # rows (+ its CutMix partners), the iteration's CutMix draws were made by the sampler and are popped here
@@ -103,6 +102,11 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
     best_records = {}
     num_iter = 0
     for epoch in range(1, args.epochs + 1):
+        # identical shuffles and CutMix draws on every rank for this epoch: every rank continues from rank 0's generator states.  Once
+        # before the loop is not enough — with --early_stop rank 0 alone validates after every epoch, and creating a DataLoader
+        # iterator draws its base seed from torch's global generator even with shuffle=False (ref: the 1-process job makes exactly
+        # those draws, utils/training.py:1500-1512, so rank 0's stream IS the reference's)
+        dp.sync_rng(args)
         for inputs, labels, text, source in train_loader:
             num_iter += 1
             images = inputs.to(args.device, non_blocking=True)

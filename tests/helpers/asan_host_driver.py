@@ -94,4 +94,40 @@ for B, T, H in ((32, 257, 16), (32, 197, 12), (3, 77, 8), (2, 320, 2), (1, 65, 1
     run("swat_attn_bwd_tiled", P(), P(1), P(2), P(3), P(4), B, T, d, H, P(5), N)
 run("swat_adamw", P(), P(1), P(2), P(3), P(4), 1 << 20, (ctypes.c_int64 * 4)(0, 100, 200, 300), 3, P(5), 0.9, 0.999, 1e-8, 0.01, P(6), 1.0, N)
 run("swat_adamw", P(), P(1), P(2), P(3), P(4), 1 << 20, (ctypes.c_int64 * 4)(0, 100, 200, 300), 9, P(5), 0.9, 0.999, 1e-8, 0.01, P(6), 1.0, N)
+
+# ---- the JPEG host parser and entropy decoder on hostile bytes (web-retrieved files reach them in every loader worker) ----
+import io
+import numpy as np
+from PIL import Image
+
+def _jpeg_calls(blob):
+    a = np.frombuffer(bytes(blob), np.uint8)
+    W, H = ctypes.c_int32(), ctypes.c_int32()
+    dims = (ctypes.c_int32 * 8)()
+    run("swat_jpeg_info", a.ctypes.data_as(ctypes.c_void_p), a.size, ctypes.cast(ctypes.byref(W), ctypes.c_void_p), ctypes.cast(ctypes.byref(H), ctypes.c_void_p))
+    rc = run("swat_jpeg_entropy_decode", a.ctypes.data_as(ctypes.c_void_p), a.size, ctypes.cast(dims, ctypes.c_void_p), N, 0)
+    if rc == 0 and dims[0] * dims[1] <= 1 << 20:
+        need = sum(dims[5] * (dims[3] if c == 0 else 1) * dims[6] * (dims[4] if c == 0 else 1) * 64 for c in range(dims[2]))
+        out = np.zeros(need, np.int16)
+        run("swat_jpeg_entropy_decode", a.ctypes.data_as(ctypes.c_void_p), a.size, ctypes.cast(dims, ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), out.size)
+
+_rng = np.random.default_rng(9)
+_seg = lambda m, payload: bytes([0xFF, m]) + (len(payload) + 2).to_bytes(2, "big") + payload
+for sub, rst in ((0, 0), (2, 0), (1, 3)):
+    b = io.BytesIO()
+    kw = {"restart_marker_blocks": rst} if rst else {}
+    Image.fromarray((_rng.random((40, 56, 3)) * 255).astype(np.uint8)).save(b, "JPEG", quality=80, subsampling=sub, **kw)
+    good = b.getvalue()
+    _jpeg_calls(good)
+    for counts in ([255] + [0] * 15, [3] + [0] * 15, [0, 5] + [0] * 14, [0] * 15 + [255]):   # tables that are not prefix codes
+        _jpeg_calls(b"\xff\xd8" + _seg(0xC4, bytes([0x10]) + bytes(counts) + bytes(range(min(sum(counts), 256)))) + good[2:])
+    for cut in range(0, len(good), 7):        # truncated at every 7th byte
+        _jpeg_calls(good[:cut])
+    sos = good.find(b"\xff\xda")
+    for _ in range(300):                      # random byte damage: headers (tables, frame, scan header) and entropy-coded data
+        bad = bytearray(good)
+        for _k in range(int(_rng.integers(1, 4))):
+            pos = int(_rng.integers(2, sos + 14)) if _rng.random() < 0.7 else int(_rng.integers(sos, len(good)))
+            bad[pos] = int(_rng.integers(0, 256))
+        _jpeg_calls(bad)
 print(f"{calls} calls, {fails} returned an error with a message; no sanitizer report")

@@ -197,3 +197,71 @@ def test_rank_batch_sampler_yields_the_single_process_batches_rank_by_rank():
                         assert rows.tolist() == own + [b_idx[j] for j in s_perm[rank * b:(rank + 1) * b].tolist()]
                     it += 1
             assert it == len(single) and sampler.draws == []
+
+
+def test_rank_zero_only_validation_between_epochs_keeps_the_ranks_in_step():
+    """with --early_stop rank 0 alone validates after every epoch, and iterating ANY DataLoader advances torch's global
+    generator (the iterator's base seed).  swat_amd/training.py therefore re-synchronises the generator states at the top of EVERY
+    epoch (dp.sync_rng: ranks > 0 continue from rank 0's states).  Emulated in one process: rank 0 runs first and its states at each
+    epoch's start are what the other ranks restore; without that restore their second-epoch permutations differ (asserted too)."""
+    import types
+    import numpy as np
+    from torch.utils.data import DataLoader, Dataset
+    from swat_amd import dp, training
+
+    class Ids(Dataset):
+        def __len__(self):
+            return 41
+
+        def __getitem__(self, i):
+            return i
+
+    args = types.SimpleNamespace(cutmix_beta=1.0, mix_prob=0.5)
+    n, bsz, world, epochs = 41, 8, 2, 3
+
+    def seed():
+        torch.manual_seed(5)
+        np.random.seed(5)
+
+    def validate_like():
+        for _ in DataLoader(Ids(), batch_size=16, shuffle=False):   # (draws the iterator's base seed from the global generator)
+            pass
+
+    seed()
+    single = []
+    for epoch in range(epochs):
+        for batch in DataLoader(Ids(), batch_size=bsz, shuffle=True, drop_last=True):
+            single.append((batch.tolist(),) + tuple(training.cutmix_draw(args, (bsz, 3, 224, 224))))
+        validate_like()
+
+    def run_rank(rank, states_in, resync):
+        seed()
+        sampler = dp.RankBatchSampler(n, bsz, rank, world)
+        sampler.configure(lambda size: training.cutmix_draw(args, size))
+        loader = DataLoader(Ids(), batch_sampler=sampler)
+        got, states_out = [], []
+        for epoch in range(epochs):
+            if rank == 0:
+                states_out.append((torch.get_rng_state(), np.random.get_state()))
+            elif resync:   # dp.sync_rng at the top of the epoch
+                torch.set_rng_state(states_in[epoch][0])
+                np.random.set_state(states_in[epoch][1])
+            for rows in loader:
+                got.append((rows.tolist(),) + tuple(sampler.pop_draw()))
+            if rank == 0:
+                validate_like()   # rank 0 only (dp.is_main)
+        return got, states_out
+
+    r0, states = run_rank(0, None, True)
+    r1, _ = run_rank(1, states, True)
+    r1_stale, _ = run_rank(1, states, False)
+    b = bsz // world
+    for it, (b_idx, lam, perm, box) in enumerate(single):
+        for rank, got in ((0, r0), (1, r1)):
+            rows, g_lam, g_perm, g_box = got[it]
+            assert g_lam == lam and g_box == box and (g_perm is None) == (perm is None)
+            own = b_idx[rank * b:(rank + 1) * b]
+            assert rows == (own if perm is None else own + [b_idx[j] for j in perm[rank * b:(rank + 1) * b].tolist()]), (it, rank)
+    per_epoch = n // bsz
+    assert [g[0] for g in r1_stale[:per_epoch]] == [g[0] for g in r1[:per_epoch]]       # the first epoch needs no re-sync ...
+    assert [g[0] for g in r1_stale[per_epoch:]] != [g[0] for g in r1[per_epoch:]]       # ... the later ones do

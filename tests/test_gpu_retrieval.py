@@ -277,6 +277,12 @@ def test_dense_edge_shapes_and_the_staging_overflow_path():
         assert torch.equal(i1, i2) and torch.equal(v1, v2) and torch.equal(c1, c2), (d, n, nq, k, path)
         if (n, nq) == (17, 33):
             assert path == "exact-fallback"
+            # a warm repeat on the same tensors: the cache entry remembers that the proof failed (no candidate pass + host sync + exact scan
+            # per call), still holds the thresholds its key stands for, and the answer is the same
+            thr_before = dense._cache["thr"].clone()
+            i3, v3, c3 = dense.topk_dense(db, q, k, row_base=7)
+            assert dense.last_path == "exact-fallback" and dense._cache.get("proof_failed")
+            assert torch.equal(i3, i2) and torch.equal(v3, v2) and torch.equal(c3, c2) and torch.equal(dense._cache["thr"], thr_before)
 
 
 def test_dense_topk_beyond_the_error_bound_width_takes_the_exact_scan():

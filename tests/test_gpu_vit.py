@@ -67,9 +67,13 @@ def test_forward_backward_match_oracle(cfg, B):
     persistent = _lib.lib().swat_vit_mega_launches() - launches0
     assert persistent == (1 if (cfg, B) == (B32, 32) else 0), "which forward ran is part of what this case pins"
     assert (f.cpu() - f_ref.detach()).abs().max().item() <= EMB_TOL * f_ref.abs().max().item()
+    bwd0 = _lib.lib().swat_vit_mega_backward_launches()
     mine.backward_raw(w.to(dev()).contiguous())
     torch.cuda.synchronize()
     assert _lib.lib().swat_vit_mega_poll() == 0
+    # the data gradients of the twelve blocks of the benchmark's shape come from vit_bwd_mega_kernel (the slowest kernel of the step):
+    # this is its one direct comparison with the oracle, so which backward ran is pinned as well
+    assert _lib.lib().swat_vit_mega_backward_launches() - bwd0 == (1 if (cfg, B) == (B32, 32) else 0)
     arena = mine.arena()
     ref_params = dict(ref.named_parameters())
     worst = 0.0
@@ -138,6 +142,7 @@ def test_fused_steps_track_oracle_trajectory(cfg, B, C):
     every forward of it is the persistent launch (asserted)."""
     from swat_amd import _lib, optimizers
     launches0 = _lib.lib().swat_vit_mega_launches()
+    bwd0 = _lib.lib().swat_vit_mega_backward_launches()
     from swat_amd.clip_model import CLIP
     from swat_amd.models import MyLinear
     from swat_amd.step import FusedTrainStep
@@ -192,6 +197,7 @@ def test_fused_steps_track_oracle_trajectory(cfg, B, C):
     total_loss = step.pop_loss_sum()
     assert total_loss > 0
     assert _lib.lib().swat_vit_mega_launches() - launches0 == (8 if (cfg, B) == (B32, 32) else 0)
+    assert _lib.lib().swat_vit_mega_backward_launches() - bwd0 == (8 if (cfg, B) == (B32, 32) else 0)
 
 
 def test_validate_matches_oracle_eval():

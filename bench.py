@@ -736,10 +736,12 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    pl0 = (_lib.lib().swat_vit_mega_launches(), _lib.lib().swat_vit_mega_backward_launches())
     t0 = time.perf_counter()
     run_steps(args, step, sched, images, labels, a.steps)
     fence()
     dt = time.perf_counter() - t0
+    pl = (_lib.lib().swat_vit_mega_launches() - pl0[0], _lib.lib().swat_vit_mega_backward_launches() - pl0[1])
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -763,6 +765,8 @@ def main():
                           "gradient_wire": os.environ.get("SWAT_DP_WIRE", "fp32") if world > 1 else None,
                           "gradient_collective": os.environ.get("SWAT_DP_COLLECTIVE", "all_reduce") if world > 1 else None},
                "final_loss": round(loss, 4),
+               # which step ran: persistent forward / backward launches per timed step on rank 0 (1.0 / 1.0 = the fast path, at any N)
+               "persistent_launches_per_step": {"forward": pl[0] / a.steps, "backward": pl[1] / a.steps},
                "step_mfma_frac": round(GFLOP_PER_IMG_STEP * 1e9 * a.bsz / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
     # the instrumented replay runs on every rank (its steps contain the gradient all-reduces); rank 0 reports its own
     roof = gemm_roofline(args, step, sched, images, labels, min(a.steps, 10), a.bsz, a.overlap)

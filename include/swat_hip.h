@@ -358,6 +358,27 @@ swat_stream_t swat_vit_aux_stream(int i); /* i = 0, 1: two more process-wide str
 int swat_vit_lane_order(swat_stream_t stream); /* `stream` waits for what the lane holds now; the lane is not joined */
 int swat_vit_lane_follow(swat_stream_t stream); /* the lane waits for what `stream` holds now (then work may be queued on swat_vit_lane_stream()) */
 int swat_vit_backward_join(swat_stream_t stream);
+/* Data-parallel form of the blocks' backward (gradient all-reduce overlapped with backward work; ref: the
+ *     reference is one process, utils/training.py:1486-1488).  swat_vit_backward_set_buckets names buckets of transformer blocks from
+ *     the top of the tower down (n <= 16; the last one takes what remains).  The NEXT swat_vit_backward call that runs the blocks as
+ *     the persistent launch (stage_hi >= L, stage_lo <= 1, swat_vit_backward_blocks_fused) then issues on the weight-gradient lane
+ *     the LayerNorm reductions of all blocks and, per bucket, one weight-gradient launch with an event behind it;
+ *     swat_vit_backward_bucket_wait(i, stream) orders `stream` behind bucket i's event, so bucket i's all-reduce and AdamW run
+ *     beside the weight gradients of the buckets below.  swat_vit_backward_buckets_recorded(): events of the last such call
+ *     (0: the blocks ran op by op and the list was dropped).  One call per arming; no optimizer work inside. */
+int swat_vit_backward_set_buckets(const int32_t* blocks, int n);
+int swat_vit_backward_bucket_wait(int i, swat_stream_t stream);
+int swat_vit_backward_buckets_recorded(void);
+/* Data-parallel runs of the persistent launches: a hand-off give-up on ANY rank voids the step on EVERY rank.
+ *     swat_vit_mega_void_flag(dst): dst[0] (device float) = 1 if this device's guard is up (a persistent launch gave up), else 0;
+ *     the caller reduces dst over the ranks (MAX or SUM) on the stream its gradient collectives run on, before the step's first
+ *     optimizer launch, then swat_vit_mega_void_absorb(src, step_seq): src[0] != 0 raises the local guard too (every swat_adamw /
+ *     swat_loss_accumulate from here on is skipped, as after a local give-up) and publishes step_seq (>= 1, the caller's step
+ *     count) in a pinned host word; swat_vit_mega_poll_void() reads it without synchronising (0: no step voided since the last
+ *     swat_vit_mega_status).  The host then replays from that step on every rank alike (swat_amd/step.py). */
+int swat_vit_mega_void_flag(float* dst, swat_stream_t stream);
+int swat_vit_mega_void_absorb(const float* src, int step_seq, swat_stream_t stream);
+int swat_vit_mega_poll_void(void);
 /* AdamW (ref utils/optimizers.py:131-146, torch.optim.AdamW) of the blocks' parameters INSIDE the next swat_vit_backward call that
  *     covers all blocks (stage_hi >= L, stage_lo <= 1) and runs them as the persistent backward: block by block beside the next
  *     block's weight-gradient launch, or in the epilogue of the weight-gradient launch (swat_vit_set_block_adamw) — same

@@ -593,6 +593,37 @@ SWAT_API int swat_vit_fused_adamw_consumed(void) {
     return c ? 1 : 0;
 }
 
+// Data-parallel form of the blocks' persistent backward (swat_amd/step.py at N > 1): the caller names BUCKETS of transformer blocks,
+// from the top of the tower down; the next swat_vit_backward call that runs the blocks as the persistent launch then issues, on the
+// lane, the LayerNorm reductions of all blocks and per bucket ONE weight-gradient launch (the joint tile list of its blocks) with an
+// event behind it.  swat_vit_backward_bucket_wait(i, stream) orders `stream` (the caller's all-reduce stream) behind bucket i's
+// event: the all-reduce + AdamW of a bucket then trail the weight gradients of the buckets below.  No AdamW inside the call.
+struct DpBuckets {
+    int n = 0, recorded = 0;
+    int blocks[16];
+    hipEvent_t ev[16] = {};
+};
+static DpBuckets g_dp;
+
+SWAT_API int swat_vit_backward_set_buckets(const int32_t* blocks, int n) {
+    SWAT_REQUIRE(n >= 0 && n <= 16 && (n == 0 || blocks), "swat_vit_backward_set_buckets: 0 .. 16 buckets");
+    for (int i = 0; i < n; ++i) {
+        SWAT_REQUIRE(blocks[i] >= 1, "swat_vit_backward_set_buckets: a bucket holds at least one block");
+        g_dp.blocks[i] = blocks[i];
+        if (!g_dp.ev[i]) SWAT_HIP(hipEventCreateWithFlags(&g_dp.ev[i], hipEventDisableTiming));
+    }
+    g_dp.n = n;
+    g_dp.recorded = 0;
+    return 0;
+}
+SWAT_API int swat_vit_backward_bucket_wait(int i, swat_stream_t stream) {
+    SWAT_REQUIRE(i >= 0 && i < g_dp.recorded, "swat_vit_backward_bucket_wait: bucket %d has no event (the last backward recorded %d)", i, g_dp.recorded);
+    SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, g_dp.ev[i], 0));
+    return 0;
+}
+// buckets the last persistent backward recorded an event for (0: the blocks did not run as the persistent launch)
+SWAT_API int swat_vit_backward_buckets_recorded(void) { return g_dp.recorded; }
+
 SWAT_API int swat_vit_backward_blocks_fused(const int32_t* dims) {
     VitDims D;
     if (parse_dims(dims, D) != 0 || !D.save || g_group_wgrad) return 0;
@@ -663,6 +694,8 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
     }
     int ln1_pending = -1, mega_rc = 0;
     void* ln1_ws = nullptr;
+    if (stage_hi >= 1 && stage_lo <= D.L) g_dp.recorded = 0;   // (a blocks' call: what bucket_wait may refer to is decided below)
+    if (!mega && stage_hi >= 1 && stage_lo <= D.L) g_dp.n = 0;  // bucket list of a caller whose shape is not served: dropped
     for (int stage = stage_hi; stage >= stage_lo; --stage) {
         if (stage == D.L + 1) {
             SWAT_REQUIRE(dfeats, "swat_vit_backward: dfeats is null");
@@ -737,6 +770,34 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             if (g_block_adamw < 0) g_block_adamw = getenv("SWAT_BLOCK_ADAMW") ? atoi(getenv("SWAT_BLOCK_ADAMW")) : 1;
             if (g_block_adamw == 0) adam = nullptr;
             const int adam_pipe = g_block_adamw == 1 ? 1 : 0;
+            if (g_dp.n > 0 && fork) {
+                // data-parallel: LayerNorm reductions of every block first (their vectors ride in the blocks' buckets), then one
+                // weight-gradient launch + event per bucket, top of the tower first; the last bucket takes whatever blocks remain
+                TRY(ln_bwd_finish_sets(parts.data(), dgs.data(), dbs_.data(), dcs.data(), (int)parts.size(), nblk, d, ws));
+                size_t l4 = 0;
+                int nb = 0;
+                for (; nb < g_dp.n && l4 < wg.size(); ++nb) {
+                    const int left = (int)((wg.size() - l4) / 4);
+                    const int nl = (nb + 1 == g_dp.n || g_dp.blocks[nb] > left) ? left : g_dp.blocks[nb];
+                    int wrc1 = nl > 1 ? wgrad_all_try(wg.data() + l4, 4 * nl, ws, nullptr) : 1;
+                    if (wrc1 < 0) return wrc1;
+                    for (int b4 = 0; wrc1 == 1 && b4 < nl; ++b4) {
+                        const void* dys[4]; const void* xs4[4]; float* dws[4]; float* dbs[4];
+                        int rws[4], nout[4], nin[4], ldy[4], ldx[4];
+                        for (int i = 0; i < 4; ++i) {
+                            const GemmArgs& a = wg[l4 + 4 * b4 + i];
+                            dys[i] = a.A; xs4[i] = a.B; dws[i] = (float*)a.C; dbs[i] = a.colsum;
+                            rws[i] = a.K; nout[i] = a.M; nin[i] = a.N; ldy[i] = a.lda; ldx[i] = a.ldb;
+                        }
+                        TRY(swat_linear_wgrad_bias_group(4, dys, xs4, dws, dbs, rws, nout, nin, ldy, ldx, w.csws, ws));
+                    }
+                    if (hipEventRecord(g_dp.ev[nb], ws) != hipSuccess) lane_ok = false;
+                    l4 += (size_t)4 * nl;
+                }
+                g_dp.recorded = nb;
+                g_dp.n = 0;   // one call
+                continue;
+            }
             if (adam && adam_pipe && fork) {
                 // Piped form (the default): per block, the weight-gradient launch on the lane and the block's AdamW on a second stream —
                 // beside the NEXT block's weight gradients.  The 256 x 128 kernel is bound by the matrix cores and holds 3 x 152 of a

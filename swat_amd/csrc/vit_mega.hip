@@ -1213,6 +1213,21 @@ static int mega_counter_base(MegaDev* md, int npanels, int nteams, int L, hipStr
     return 0;
 }
 
+// hand-off counters + sticky status word (device), the pinned host words, the completion event: once per device
+static int mega_state_ensure(MegaDev* md) {
+    if (md->state) return 0;
+    if (hipMalloc((void**)&md->state, 17 * 128) != hipSuccess || hipMemset(md->state, 0, 17 * 128) != hipSuccess ||
+        hipHostMalloc((void**)&md->host_flag, 128, hipHostMallocMapped) != hipSuccess ||
+        hipEventCreateWithFlags(&md->done, hipEventDisableTiming) != hipSuccess) {
+        set_error("vit_mega: allocation of the hand-off state failed");
+        md->state = nullptr;
+        return -1;
+    }
+    md->host_flag[0] = 0;   // launch number of the first persistent launch of this device that gave up
+    md->host_flag[1] = 0;   // data-parallel runs: number of the first step some rank voided (swat_vit_mega_void_absorb)
+    return 0;
+}
+
 static MegaDev* mega_dev() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -1265,16 +1280,7 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
         md->resident = occ;
     }
     if (md->resident < 1 || nteams * MG_TEAM > md->cus) return 1;   // (156 KB of LDS: one workgroup per CU whatever the query says)
-    if (!md->state) {
-        if (hipMalloc((void**)&md->state, 17 * 128) != hipSuccess || hipMemset(md->state, 0, 17 * 128) != hipSuccess ||
-            hipHostMalloc((void**)&md->host_flag, 128, hipHostMallocMapped) != hipSuccess ||
-            hipEventCreateWithFlags(&md->done, hipEventDisableTiming) != hipSuccess) {
-            set_error("vit_mega: allocation of the hand-off state failed");
-            md->state = nullptr;
-            return -1;
-        }
-        md->host_flag[0] = 0;
-    }
+    if (mega_state_ensure(md) != 0) return -1;
     MegaFwd m{};
     m.B = B; m.T = T; m.d = d; m.H = H; m.mlp = mlp; m.L = L; m.act = act; m.save = save; m.M = M; m.Mp = Mp;
     m.eps = 1e-5f;
@@ -1401,6 +1407,50 @@ int vit_mega_backward(int B, int T, int d, int H, int mlp, int L, int act, int M
     return rc;
 }
 
+// ---- data-parallel runs: a give-up on ANY rank voids the step on EVERY rank ------------------------------------------------------
+// The device guard (the sticky status word) keeps a rank's own optimizer launches from applying a void step — but its void gradients
+// would still be summed into the other ranks' updates.  So every step carries one float through a collective of its own:
+//   swat_vit_mega_void_flag   : dst[0] = 1 if this device's status word is set (a persistent launch gave up), else 0
+//   (the caller all-reduces dst with MAX / SUM over the ranks, on the stream the gradient all-reduces run on, BEFORE the step's
+//   first optimizer launch)
+//   swat_vit_mega_void_absorb : src[0] != 0 -> raise the local guard as well (status word, if it is still clear) and publish
+//   `step_seq` in the pinned host word swat_vit_mega_poll_void reads (first voided step wins).
+// Every rank then skips the step's updates and the host replays from `step_seq` on, on every rank alike (swat_amd/step.py).
+__global__ void mega_void_flag_kernel(const unsigned* status, float* dst) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] = (status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.0f : 0.0f;
+}
+__global__ void mega_void_absorb_kernel(const float* src, unsigned* status, unsigned* host_flag, unsigned step_seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || !(src[0] != 0.0f)) return;
+    unsigned expect = 0;
+    __hip_atomic_compare_exchange_strong(status, &expect, 0xC0000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    expect = 0;
+    __hip_atomic_compare_exchange_strong(host_flag + 1, &expect, step_seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace swat
+SWAT_API int swat_vit_mega_void_flag(float* dst, swat_stream_t stream) {
+    SWAT_REQUIRE(dst, "swat_vit_mega_void_flag: null pointer");
+    swat::MegaDev* md = swat::mega_dev();
+    hipLaunchKernelGGL(swat::mega_void_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, md && md->state ? md->state + 16 * 32 : nullptr, dst);
+    return swat::check_launch("mega_void_flag_kernel");
+}
+SWAT_API int swat_vit_mega_void_absorb(const float* src, int step_seq, swat_stream_t stream) {
+    SWAT_REQUIRE(src && step_seq > 0, "swat_vit_mega_void_absorb: null pointer or step number < 1");
+    swat::MegaDev* md = swat::mega_dev();
+    // (a rank whose own launches were never persistent still has to honour another rank's give-up: the guard exists from here on)
+    SWAT_REQUIRE(md && swat::mega_state_ensure(md) == 0, "swat_vit_mega_void_absorb: no device state");
+    hipLaunchKernelGGL(swat::mega_void_absorb_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, md->state + 16 * 32, md->host_flag,
+                       (unsigned)step_seq);
+    return swat::check_launch("mega_void_absorb_kernel");
+}
+// no synchronisation: 0, or the number (the caller's own count, swat_vit_mega_void_absorb) of the first step some rank voided
+SWAT_API int swat_vit_mega_poll_void(void) {
+    swat::MegaDev* md = swat::mega_dev();
+    if (!md || !md->host_flag) return 0;
+    return (int)__atomic_load_n(md->host_flag + 1, __ATOMIC_RELAXED);
+}
+namespace swat {
+
 }  // namespace swat
 using namespace swat;
 
@@ -1447,6 +1497,7 @@ SWAT_API int swat_vit_mega_status(void) {
         md->ctr_dirty = true;   // a launch gave up: the team counters are short of what the host has counted
     }
     md->host_flag[0] = 0;
+    md->host_flag[1] = 0;
     return (int)(v & 0x3fffffffu) | (v ? 0x40000000 : 0);
 }
 

@@ -83,6 +83,15 @@ class FusedTrainStep:
         # the next call, no synchronisation), and the host re-runs the steps from the failed launch on, op by op (_recover)
         self._recent = collections.deque(maxlen=16)
         self._replaying = False
+        # N > 1: a give-up on any rank voids the step on every rank (include/swat_hip.h: swat_vit_mega_void_flag / _absorb).  Steps are
+        # counted alike on every rank; a voided step is acted on VOID_LAG steps later, when its absorb launch has certainly run on
+        # every rank's device — so all ranks turn to the replay at the same step without any extra host collective
+        self._seq = 0
+        self._absorbed = collections.deque(maxlen=16)   # (step number, event behind its absorb launch)
+        self._void_flag = None
+        # N > 1: the blocks' backward as ONE persistent launch with the buckets' all-reduce + AdamW trailing the weight gradients
+        # (csrc/vit.hip: swat_vit_backward_set_buckets); SWAT_DP_PERSISTENT=0 keeps the stage-by-stage backward of rounds 2-4
+        self.dp_persistent = os.environ.get("SWAT_DP_PERSISTENT", "1") != "0"
         if self.trail:
             # process-wide streams owned by the library (created once, together with the weight-gradient lane)
             self._comm_stream = torch.cuda.ExternalStream(_lib.lib().swat_vit_aux_stream(0), device=dev)  # all-reduces
@@ -107,10 +116,14 @@ class FusedTrainStep:
         batch: number of samples when `images` carries CutMix partner rows behind them (swat_amd/dp.py:shard_batch)."""
         if self.train_visual and not self._replaying:
             lib = _lib.lib()
-            if lib.swat_vit_mega_poll():
+            if self.reduce:
+                self._check_void()
+            elif lib.swat_vit_mega_poll():
                 self._recover()
+            self._seq += 1
             self._recent.append([0, self.opt.step_count, [g['lr'] for g in self.opt.param_groups],
-                                 (images, target_a, target_b, lam, perm, box, batch)])
+                                 (images, target_a, target_b, lam, perm, box, batch), self._seq])
+            self._cur_seq = self._seq
         a = self.arena
         B = images.shape[0] if batch is None else int(batch)
         dev = images.device
@@ -128,14 +141,19 @@ class FusedTrainStep:
         g = a.grad
         # a step whose blocks run backward as ONE persistent launch (one GPU, trailing mode) can still be voided by that launch: its
         # loss joins the running sum behind it (on the lane, _trailing_backward), not in the loss kernel
-        self._late_loss = bool(self.train_visual and self.trail and not self.reduce and
-                               _lib.lib().swat_vit_backward_blocks_fused(self.visual._last_ws[1]))
+        blocks_fused = bool(self.train_visual and self.trail and _lib.lib().swat_vit_backward_blocks_fused(self.visual._last_ws[1]))
+        self._late_loss = blocks_fused and not self.reduce
+        # N > 1: the same one persistent launch for the blocks, its buckets reduced behind the weight gradients (_reduce_persistent)
+        self._dp_fused = blocks_fused and self.reduce and self.dp_persistent
+        # N > 1: a step can be voided by ANOTHER rank's give-up, known only after the step's flag exchange: the running loss sum is
+        # fed behind that exchange (swat_loss_accumulate), not by the loss kernel
+        dp_loss_late = bool(self.reduce and self.trail and self.train_visual)
         ls_ptr = a.flat.data_ptr() + 4 * self.off_ls if self.off_ls is not None else _lib.ptr(self._ls_fixed)
         dls_ptr = g.data_ptr() + 4 * self.off_ls if self.off_ls is not None else _lib.ptr(self._dls_scratch)
         # (_late_loss: only what the backward waits for now; the batch means and d W_head behind the blocks' backward, _trailing_backward)
         head_args = [_lib.ptr(feats), a.flat.data_ptr() + 4 * self.off_head, ls_ptr, _lib.ptr(target_a), _lib.ptr(target_b), float(lam),
                      _lib.ptr(ws), _lib.ptr(self.loss), _lib.ptr(dfeats), g.data_ptr() + 4 * self.off_head, dls_ptr, None, None,
-                     None if self._late_loss else _lib.ptr(self.loss_accum), B, self.E, self.C]
+                     None if (self._late_loss or dp_loss_late) else _lib.ptr(self.loss_accum), B, self.E, self.C]
         self._head_rest = (head_args, int(self.train_visual)) if self._late_loss else None
         rc = _lib.lib().swat_head_loss(*head_args, 2 if self._late_loss else 1, int(self.train_visual), _lib.stream())
         _lib.check(rc, "swat_head_loss")
@@ -159,6 +177,91 @@ class FusedTrainStep:
         red.wait()
         self.opt.step()
         return self.loss
+
+    def _bucket_plan(self):
+        """Backward stages per gradient bucket, from the top of the tower down (stage L+1 = ln_post / proj, l+1 = block l, 0 = stem):
+        bucket_sched[i] blocks per bucket; stage 1 always leaves with stage 0 (and the head)."""
+        L = self.visual.layers
+        plan, cur, blocks, bucket = [], [], 0, 0
+        for s in range(L + 1, -1, -1):
+            cur.append(s)
+            blocks += 1 if 1 <= s <= L else 0
+            want = self.bucket_sched[bucket] if bucket < len(self.bucket_sched) else 1 << 30
+            if s == 0 or (blocks >= want and s > 1):
+                plan.append(cur)
+                cur, blocks, bucket = [], 0, bucket + 1
+        return plan
+
+    def _void_exchange(self, comm):
+        """On `comm`, before the step's first gradient collective: one float per rank says whether a persistent launch of this step
+        gave up here; its maximum over the ranks raises every rank's device guard (the step's optimizer launches and loss addition
+        are then skipped everywhere) and publishes the step number for _check_void."""
+        lib = _lib.lib()
+        if self._void_flag is None:
+            self._void_flag = torch.zeros(1, dtype=torch.float32, device=self.arena.flat.device)
+        h = comm.cuda_stream
+        _lib.check(lib.swat_vit_mega_void_flag(_lib.ptr(self._void_flag), h), "swat_vit_mega_void_flag")
+        dist.all_reduce(self._void_flag, op=dist.ReduceOp.MAX)
+        _lib.check(lib.swat_vit_mega_void_absorb(_lib.ptr(self._void_flag), int(self._cur_seq), h), "swat_vit_mega_void_absorb")
+        if not self._replaying:
+            ev = torch.cuda.Event()
+            ev.record(comm)
+            self._absorbed.append((self._cur_seq, ev))
+
+    VOID_LAG = 4
+
+    def _check_void(self, final=False):
+        """N > 1.  Has some rank voided a step?  Decided from steps whose flag exchange has certainly completed on THIS device (the
+        step VOID_LAG back; `final`: the caller has synchronised the device, every step counts), so that every rank answers alike
+        and turns to the replay at the same step."""
+        if not (self.reduce and self.trail and self.train_visual):
+            return False
+        lib = _lib.lib()
+        if final:
+            horizon = self._seq
+        else:
+            horizon = self._seq + 1 - self.VOID_LAG     # (called before step _seq + 1 is issued)
+            for q, ev in self._absorbed:
+                if q == horizon:
+                    ev.synchronize()    # long done: the host runs a step or two ahead of the device, not four
+        v = lib.swat_vit_mega_poll_void()
+        if v and v <= horizon:
+            self._recover_dp(v)
+            return True
+        return False
+
+    def _recover_dp(self, v):
+        """Step number v was voided on every rank (the guard has been up on every device since): switch every rank to the op-by-op
+        path and run the steps from v on again — the same collectives in the same order on every rank."""
+        import warnings
+        lib = _lib.lib()
+        torch.cuda.synchronize()
+        st = lib.swat_vit_mega_status()   # clears the guard and both host words
+        lib.swat_vit_set_mega(0)
+        warnings.warn(f"data-parallel step {v}: a persistent launch gave up on a team hand-off on some rank (local status {st:#x}); "
+                      "the step was skipped on every rank and is re-run op by op from here on")
+        todo = [e for e in self._recent if e[4] >= v]
+        if not todo or todo[0][4] != v:
+            raise _lib.PersistentForwardGaveUp(
+                f"step {v} was voided and is no longer in the replay window ({len(self._recent)} steps): weights and optimizer state "
+                "are those of the step before it on every rank; restart from them with SWAT_VIT_MEGA=0")
+        opt = self.opt
+        lrs_now, count_now = [g['lr'] for g in opt.param_groups], opt.step_count
+        opt.step_count = todo[0][1]
+        self._absorbed.clear()
+        self._replaying = True
+        try:
+            for e in todo:
+                for g, lr in zip(opt.param_groups, e[2]):
+                    g['lr'] = lr
+                self._cur_seq = e[4]
+                self(*e[3])
+        finally:
+            self._replaying = False
+            for g, lr in zip(opt.param_groups, lrs_now):
+                g['lr'] = lr
+        assert opt.step_count == count_now, (opt.step_count, count_now)
+        torch.cuda.synchronize()
 
     def _adamw_args(self, lo, hi):
         """Raw-pointer AdamW arguments of an arbitrary arena range inside one LR group (cached per range)."""
@@ -216,13 +319,24 @@ class FusedTrainStep:
         # latencies on the host and on the links, still overlapped with the backward of the blocks below.
         pend = []  # (lo, hi, adamw args) of the open bucket, in arena order of issue
 
-        def flush():
+        flushed = [0]
+
+        def flush(bucket_event=None):
             lo, hi = min(p[0] for p in pend), max(p[1] for p in pend)
             assert sum(p[1] - p[0] for p in pend) == hi - lo, "bucket is not one contiguous arena range"
-            lib.swat_vit_lane_order(ready_h)  # `comm` follows everything the bucket's stages ran on either stream
+            if bucket_event is None:
+                lib.swat_vit_lane_order(ready_h)  # `comm` follows everything the bucket's stages ran on either stream
+            else:
+                _lib.check(lib.swat_vit_backward_bucket_wait(bucket_event, ready_h), "swat_vit_backward_bucket_wait")
             with torch.cuda.stream(comm):
+                if flushed[0] == 0:
+                    self._void_exchange(comm)   # the step's persistent launches are behind `comm` now; no optimizer launch yet
                 self._wire().reduce(g, lo, hi)  # all_reduce | reduce_scatter + all_gather, fp32 | bf16 on the links (ddp.GradWire)
             side.wait_stream(comm)
+            if flushed[0] == 0:
+                # (behind the flag exchange: a step voided by any rank adds nothing to the running loss on any rank)
+                _lib.check(lib.swat_loss_accumulate(_lib.ptr(self.loss), _lib.ptr(self.loss_accum), side_h), "swat_loss_accumulate")
+            flushed[0] += 1
             vis = [p for p in pend if p[2] is None]
             if vis:  # the tower's stages of the bucket: one AdamW launch over their joint range (one LR group)
                 _lib.check(lib.swat_adamw(*self._adamw_args(min(p[0] for p in vis), max(p[1] for p in vis)), side_h), "swat_adamw")
@@ -260,18 +374,38 @@ class FusedTrainStep:
                 # arena order: [head | stage 0 | stage 1 | ... | stage L+1 | logit_scale] — the backward walks it from the top down
                 if self.off_ls is not None:
                     pend.append((self.off_ls, self.off_ls + 64, sl["ls"]))
-                blocks, bucket = 0, 0
-                for s in range(self.visual.layers + 1, -1, -1):
-                    self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
-                    lo, hi = self._stage_slices[s]
-                    pend.append((lo, hi, None))
-                    blocks += 1 if 1 <= s <= self.visual.layers else 0
-                    if s == 0:
-                        pend.append((self.off_head, self.off_head + (self.C * self.E + 63) // 64 * 64, sl["head"]))
-                    want = self.bucket_sched[bucket] if bucket < len(self.bucket_sched) else 1 << 30
-                    if s == 0 or (blocks >= want and s > 1):  # (stage 1 always leaves with stage 0 and the head)
+                L = self.visual.layers
+                plan = self._bucket_plan()
+                if self._dp_fused:
+                    # ONE persistent launch for the data gradients of all blocks (as on one GPU); on the lane behind it the buckets'
+                    # weight gradients, each with an event — bucket i's all-reduce (`comm`) and AdamW (`side`) run beside the weight
+                    # gradients of the buckets below it.  The collectives never share the chip with a persistent launch (every CU
+                    # holds one of its workgroups: an RCCL kernel beside it would keep team members from becoming resident).
+                    import ctypes
+                    counts = [sum(1 for s_ in b if 1 <= s_ <= L) for b in plan]
+                    self.visual.backward_raw(dfeats, stage_hi=L + 1, stage_lo=L + 1)
+                    arr = (ctypes.c_int32 * len(counts))(*counts)
+                    _lib.check(lib.swat_vit_backward_set_buckets(ctypes.cast(arr, ctypes.c_void_p), len(counts)), "swat_vit_backward_set_buckets")
+                    self.visual.backward_raw(dfeats, stage_hi=L, stage_lo=1)
+                    rec = lib.swat_vit_backward_buckets_recorded()   # 0: the blocks ran op by op after all (no persistent forward before it)
+                    self.visual.backward_raw(dfeats, stage_hi=0, stage_lo=0)
+                    for i, b in enumerate(plan):
+                        for s_ in b:
+                            lo, hi = self._stage_slices[s_]
+                            pend.append((lo, hi, None))
+                        if 0 in b:
+                            pend.append((self.off_head, self.off_head + (self.C * self.E + 63) // 64 * 64, sl["head"]))
+                        # the last bucket also holds the stem's gradients (main stream, behind the persistent launch): lane order
+                        flush(i if (rec == len(plan) and 0 not in b) else None)
+                else:
+                    for b in plan:
+                        for s in b:
+                            self.visual.backward_raw(dfeats, stage_hi=s, stage_lo=s)
+                            lo, hi = self._stage_slices[s]
+                            pend.append((lo, hi, None))
+                        if 0 in b:
+                            pend.append((self.off_head, self.off_head + (self.C * self.E + 63) // 64 * 64, sl["head"]))
                         flush()
-                        blocks, bucket = 0, bucket + 1
             else:
                 L = self.visual.layers
                 fused_blocks = self._late_loss
@@ -356,7 +490,7 @@ class FusedTrainStep:
         opt.step_count = todo[0][1]
         self._replaying = True
         try:
-            for _, _, lrs, args in todo:
+            for _, _, lrs, args, _seq in todo:
                 for g, lr in zip(opt.param_groups, lrs):
                     g['lr'] = lr
                 self(*args)
@@ -371,7 +505,11 @@ class FusedTrainStep:
         v = self.loss_accum.item()
         # the persistent forward's hand-offs are bounded spins: a give-up is recorded, not hung on.  This is a synchronisation
         # point: nothing is in flight, so a failure that the per-call poll has not seen yet is visible now
-        if self.train_visual and _lib.lib().swat_vit_mega_poll():
+        if self.train_visual and self.reduce:
+            torch.cuda.synchronize()   # (every stream: the flag exchanges run on the collective stream)
+            if self._check_void(final=True):
+                v = self.loss_accum.item()
+        elif self.train_visual and _lib.lib().swat_vit_mega_poll():
             self._recover()
             v = self.loss_accum.item()
         self.loss_accum.zero_()

@@ -487,6 +487,118 @@ def _b32_step(seed=0, C=200):
     return model, head, opt, sched, FusedTrainStep(model, head, ls, opt, world_size=1)
 
 
+def _one_rank_group():
+    """A 1-rank RCCL process group on the test GPU: the N > 1 code of the step runs unchanged inside it (every collective is the
+    identity).  -> True when this call created the group (the caller destroys it)."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if dist.is_initialized():
+        return False
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    return True
+
+
+def _b32_dp_step(seed=0):
+    """The benchmark's step as a data-parallel rank runs it (gradient buckets, all-reduce and AdamW on their own streams)."""
+    from swat_amd.step import FusedTrainStep
+    model, head, opt, sched, _ = _b32_step(seed)
+    ls = next(g["params"][0] for g in opt.param_groups if g["params"][0].numel() == 1)
+    step = FusedTrainStep(model, head, ls, opt, world_size=1, staged=True)
+    step.reduce = True
+    return model, head, opt, sched, step
+
+
+def test_data_parallel_step_runs_the_persistent_backward_and_equals_the_one_gpu_step():
+    """SURVEY 8(e) row 1 / round-4 verdict: at N > 1 the blocks' data gradients are the SAME one persistent launch as on one GPU; on
+    the lane behind it each gradient bucket's weight gradients are one launch with an event, the bucket's all-reduce and AdamW trail
+    it (swat_vit_backward_set_buckets).  Run inside a 1-rank RCCL group the data-parallel step must land on the one-GPU step's
+    weights, moments, bf16 shadow and losses bit for bit — same kernels, same order per tensor, only streams and launch
+    groupings differ (ref: utils/training.py:1474-1489, one process in the reference)."""
+    import torch.distributed as dist
+    from swat_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(13)
+    data = [(torch.randn(32, 3, 224, 224, generator=g).to(dev()), torch.randint(0, 200, (32,), generator=g).to(dev())) for _ in range(3)]
+
+    def run(make):
+        model, head, opt, sched, step = make(seed=4)
+        nb0 = L.swat_vit_mega_backward_launches()
+        losses = []
+        for it, (x, y) in enumerate(data):
+            if it % 2 == 0:
+                step(x, y, y.flip(0), 0.6, perm=torch.arange(31, -1, -1, device=dev()), box=(30, 40, 150, 190))
+            else:
+                step(x, y, y, 1.0)
+            sched.step()
+            losses.append(step.loss.clone())
+        total = step.pop_loss_sum()
+        assert L.swat_vit_mega_backward_launches() - nb0 == len(data) and L.swat_vit_mega_status() == 0
+        a = opt.arena
+        return step, (torch.stack(losses).cpu(), a.flat.clone(), a.exp_avg.clone(), a.exp_avg_sq.clone(), a.shadow.clone(), a.grad.clone()), total
+
+    created = _one_rank_group()
+    try:
+        _, one, total1 = run(_b32_step)
+        step, dp, total2 = run(_b32_dp_step)
+        assert step.reduce and step.trail and step._dp_fused
+        plan = step._bucket_plan()
+        assert [len([s for s in b if 1 <= s <= 12]) for b in plan] == [4, 4, 2, 1, 1] and plan[0][0] == 13 and plan[-1] == [1, 0]
+        assert L.swat_vit_backward_buckets_recorded() == len(plan)     # one weight-gradient launch + event per bucket
+    finally:
+        if created:
+            dist.destroy_process_group()
+    for name, x, y in zip(("loss", "weights", "exp_avg", "exp_avg_sq", "bf16 shadow", "gradient"), one, dp):
+        assert torch.equal(x, y), f"{name}: {(x.float() - y.float()).abs().max().item()}"
+    assert total1 == total2 and total1 > 0
+
+
+@pytest.mark.parametrize("when", ["early", "last"])
+def test_data_parallel_give_up_voids_the_step_and_every_rank_replays(when):
+    """A hand-off give-up at N > 1 (round-4 verdict: it used to raise).  The step's flag exchange (swat_vit_mega_void_flag ->
+    all-reduce -> swat_vit_mega_void_absorb, before the step's first optimizer launch) raises the guard; the host acts on it
+    VOID_LAG steps later ('early': injected at step 2 of 7) or at the epoch's synchronisation ('last': injected at the last step),
+    switches to the op-by-op path and replays — the trajectory equals a run that never used the persistent launches, no step is
+    lost or doubled (second moments), the loss sum holds each step once."""
+    import torch.distributed as dist
+    from swat_amd import _lib
+    L = _lib.lib()
+    n = 7
+    g = torch.Generator().manual_seed(6)
+    data = [(torch.randn(32, 3, 224, 224, generator=g).to(dev()), torch.randint(0, 200, (32,), generator=g).to(dev())) for _ in range(n)]
+    bad = 1 if when == "early" else n - 1
+
+    def run(inject):
+        model, head, opt, sched, step = _b32_dp_step(seed=2)
+        for it, (x, y) in enumerate(data):
+            if inject and it == bad:
+                L.swat_vit_mega_backward_inject_failure(1, 9)
+            step(x, y, y.flip(0), 0.7, perm=torch.arange(31, -1, -1, device=dev()), box=(10, 20, 120, 200))
+            sched.step()
+        total = step.pop_loss_sum()
+        return total, opt.arena.flat.clone(), opt.arena.exp_avg_sq.clone(), opt.step_count
+
+    created = _one_rank_group()
+    try:
+        L.swat_vit_set_mega(0)
+        want = run(False)
+        L.swat_vit_set_mega(1)
+        nb0 = L.swat_vit_mega_backward_launches()
+        with pytest.warns(UserWarning, match=f"data-parallel step {bad + 1}"):
+            got = run(True)
+        assert L.swat_vit_mega_backward_launches() - nb0 >= bad + 1
+        assert L.swat_vit_mega_poll() == 0 and L.swat_vit_mega_poll_void() == 0 and L.swat_vit_mega_status() == 0
+    finally:
+        L.swat_vit_mega_backward_inject_failure(0, 0)
+        L.swat_vit_set_mega(1)
+        if created:
+            dist.destroy_process_group()
+    assert got[3] == want[3] == n
+    assert abs(got[0] - want[0]) < 1e-2 * abs(want[0])
+    assert rel(got[1], want[1]) < 1e-5 and rel(got[2], want[2]) < 5e-2
+
+
 def test_adamw_inside_the_weight_gradient_launch_equals_the_separate_optimizer_launch():
     """swat_vit_arm_fused_adamw: behind the persistent backward the blocks' AdamW runs inside the backward call — piped (a block's
     AdamW on a second stream beside the next block's weight gradients) or in the epilogue of ONE weight-gradient launch over all 48

@@ -71,6 +71,12 @@ int swat_vit_mega_backward_launches(void);
 int swat_vit_backward_blocks_fused(const int32_t* dims);
 int swat_vit_mega_backward_trace(void* device_buffer);
 
+/* Candidate epilogue of the dense top-k's shadow scan (csrc/retrieval_bf16.hip, A/B runs): 0 = round 4's (LDS threshold + max chain +
+ *     vector branch per group, records stored to the staging slot at once), 2 = thresholds read once per block, four compares per
+ *     group into scalar masks, records kept in a per-wave LDS buffer until the scan is over (default; env SWAT_DENSE_EPI).  Same
+ *     record set; measured equal within 2 % (the scan is bound by the matrix pipe and the LDS read port, see the kernel's header). */
+int swat_dense_set_epilogue(int form);
+
 /* swat_adamw's launch shape: 0 = wide (up to 4096 blocks, the fastest alone), n > 0 = n blocks of 256 threads handling four
  *     16-byte quads per array and trip (n = 256: one block per CU, 4 of its 32 wave slots) so that GEMM workgroups on another
  *     stream share the CUs with it.  Same arithmetic per element.  Also SWAT_ADAMW_BLOCKS in the environment. */

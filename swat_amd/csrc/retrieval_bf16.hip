@@ -454,17 +454,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
     }
 }
 
+// What bounds the shadow scan at 13 query tiles (round 5, A/B runs in one process, tools/ab_dense_epi.py; 200 x 1.25 M x 512, 0.31 ms
+// of scan): NOT the candidate epilogue's instruction count (four compares per group into scalar masks instead of LDS read + max chain
+// + vector branch: 0.329 vs 0.334 ms), NOT the record stores sharing vmcnt with the row loads (records buffered in LDS until the scan
+// is over: 0.331), NOT DRAM locality of the row stream (shadow tiled so that a step of a block is one contiguous 32 KB: 0.329 vs
+// 0.336) and NOT the depth of the row stream (query chunks three steps ahead, rows four: 0.339 vs 0.341).  The pass costs 0.24 ms
+// for ONE query tile + 0.0095 ms per further tile, and a tile is 20.5 GFLOP = 8.2 us at the dense bf16 peak: the MFMA time adds in
+// full.  Per 64-deep step and CU the eight waves issue 416 MFMAs (1 664 cycles per SIMD) and read 208 KB of query fragments from
+// LDS (1 625 cycles at 128 B/clk): at 200 queries the scan is co-limited by the matrix pipe and the LDS read port, each as long as
+// the HBM stream of the step itself; one query fragment already feeds two MFMAs (NF = 2), NF = 4 or a 32 x 32 x 16 tile with two
+// row fragments would need 208-224 accumulator registers (four waves of four fragments with one wave per SIMD and 512 registers were
+// compiled: 269 spills).  The forms above stay selectable (swat_dense_set_epilogue, SWAT_DENSE_QA).
+//
 // The shadow scan with TWO 16-row fragments per wave (8 waves, 256-row blocks, 64-deep steps, database registers four steps ahead):
 // every query fragment read from LDS feeds two MFMAs, and a row costs half the barriers, counted waits and query-chunk DMA of the
 // one-fragment form above — whose ablations show exactly those as its cost once the rows come from the bf16 shadow (0.449 ms: no
 // barrier 0.325, no query DMA 0.331, no MFMA / LDS reads 0.257; the bare row stream 0.220).  Same candidate records bit for bit.
-template <int NQT>
+constexpr int SHADOW2_RCAP = 320;   // candidate records a wave keeps in LDS before it stores them (16 B each: 40 KB per workgroup)
+template <int NQT, int EPI = 2, int QA = 2>   // EPI (tuning, A/B runs): 0 = the round-4 candidate epilogue; 1 = scalar masks, records stored
+                                  // at once; 2 = scalar masks, records buffered in LDS (the product form).  Same set of records in every form.
+                                  // QA: steps the query chunks are issued ahead (2 = the product form; 3 = tuning, see the main loop)
 __global__ __launch_bounds__(512, 1) void sim_candidates_shadow2_kernel(const unsigned short* __restrict__ qp, int n_tiles, int n_q, int q0,
                                                                         const unsigned short* __restrict__ db, int64_t n_db, int d,
                                                                         const float* __restrict__ thr, int64_t row_base,
                                                                         uint4* __restrict__ stage, unsigned stage_cap,
                                                                         unsigned* __restrict__ stage_cnt) {
-    constexpr int WAVES = 8, NF = 2, KD = 2, D = 4, RING = 4;
+    constexpr int WAVES = 8, NF = 2, KD = 2, D = 4, RING = 4;   // (WAVES x NF = 16: 256-row blocks, the tiled shadow image)
     constexpr int QROWS = 16 * NQT;
     constexpr int QBYTES = QROWS * 64;       // one 32-deep query chunk
     constexpr int LPS = (NQT + WAVES - 1) / WAVES;
@@ -503,17 +518,12 @@ __global__ __launch_bounds__(512, 1) void sim_candidates_shadow2_kernel(const un
                 if (i < my_lps) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + (size_t)(KD * c + h) * chunk_stride + qdst[i] + lane16),
                                                  (__attribute__((address_space(3))) void*)(smem + buf * STAGE + h * QBYTES + qdst[i]), 16, 0, 0);
     };
-    // fragment f of the wave: rows (wave * NF + f) * 16 + r16 of the block; 16-B unit g of each 64-B chunk image
-    unsigned voff[NF], voff_last[NF];
+    // fragment f of the wave: rows (wave * NF + f) * 16 + r16 of the block.  The shadow is TILED (dense_shadow_kernel): a 64-deep step of
+    // a block is 256 rows x 128 B, contiguous; the lane's two 16-B units of a row sit 64 B apart.  Rows past n_db are zero in the image.
+    unsigned voff[NF];
     const int64_t last_blk = nblocks - 1;
-    const unsigned last_rows = (unsigned)(n_db - last_blk * BR);  // 1 .. BR
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const unsigned row = (unsigned)((wave * NF + f) * 16 + r16);
-        const unsigned lrow = row < last_rows ? row : last_rows - 1;
-        voff[f] = row * (unsigned)d * 2u + 16u * g;
-        voff_last[f] = lrow * (unsigned)d * 2u + 16u * g;
-    }
+    for (int f = 0; f < NF; ++f) voff[f] = (unsigned)((wave * NF + f) * 16 + r16) * 128u + 16u * g;
     const size_t blk_bytes = (size_t)BR * d * 2;
     rb_f32x4_t nx[D][NF][KD];
     const unsigned qr = (unsigned)(r16 * 64 + ((g ^ ((r16 >> 2) & 3)) << 4));
@@ -524,6 +534,29 @@ __global__ __launch_bounds__(512, 1) void sim_candidates_shadow2_kernel(const un
 #pragma unroll
         for (int t = 0; t < NQT; ++t) acc[f][t] = (rb_f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // EPI == 2: candidate records wait in LDS.  gfx950 counts loads and stores in ONE vmcnt, so a record stored to global memory
+    // between a block's row loads and the next block's counted waits makes those waits (vmcnt <= N) demand that many MORE of the row
+    // loads in flight be complete: every block's ~40 record stores drained the wave's whole four-step ring (round 4 saw it as "no
+    // candidate stores: 0.375 of 0.449 ms" and "epilogue 0.12-0.15 ms in every form" — the forms all stored inside the loop).  The
+    // records of a wave (~14 per block, ~270 per launch on a 1.25 M-row shard) are kept in its own RCAP-record LDS buffer behind the
+    // query ring (ds_write: lgkmcnt, in order, invisible to vmcnt) and go to the wave's staging slot in ONE burst after the scan;
+    // a buffer with fewer than 64 free records at the start of a block's epilogue is flushed there, and a record that still finds it
+    // full goes straight to its place in the slot — those blocks pay the old price, nothing is lost.
+    constexpr int RCAP = SHADOW2_RCAP;
+    const unsigned rec_lds = lds_base + (unsigned)(RING * STAGE) + (unsigned)wave * (unsigned)(RCAP * 16);
+    unsigned wl = 0;   // records in the LDS buffer (wave uniform)
+    auto flush_records = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned in_lds = wl < (unsigned)RCAP ? wl : (unsigned)RCAP;   // (records past RCAP went to their places directly)
+        for (unsigned i = (unsigned)lane; i < in_lds; i += 64u) {
+            rb_f32x4_t rec;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rec) : "v"(rec_lds + i * 16u) : "memory");
+            const unsigned o = (wcount + i) * 16u;
+            if (wcount + i < stage_cap) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(o), "v"(rec), "s"(my_stage) : "memory");
+        }
+        wcount += wl;
+        wl = 0;
+    };
     int64_t blk = blockIdx.x, lblk = blockIdx.x, ls = 0;
     int c = 0, lc = 0, qc = 0;
     auto next_q = [&]() { qc = qc + 1 == nchunk ? 0 : qc + 1; };
@@ -535,29 +568,34 @@ __global__ __launch_bounds__(512, 1) void sim_candidates_shadow2_kernel(const un
     };
     issue_q(0, qc); next_q();
     auto load_db = [&](rb_f32x4_t (&dst)[NF][KD]) {
-        const char* base = reinterpret_cast<const char*>(db) + lblk * blk_bytes + (size_t)lc * 128;  // uniform: two 64-B chunk images
+        const char* base = reinterpret_cast<const char*>(db) + lblk * blk_bytes + (size_t)lc * (BR * 128);  // uniform: this step's 32 KB
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const unsigned off = lblk == last_blk ? voff_last[f] : voff[f];
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[f][0]) : "v"(off), "s"(base));
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(dst[f][1]) : "v"(off), "s"(base));
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[f][0]) : "v"(voff[f]), "s"(base));
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(dst[f][1]) : "v"(voff[f]), "s"(base));
         }
         next_l();
     };
     load_db(nx[0]);
     issue_q(1, qc); next_q();
+    if constexpr (QA == 3) { issue_q(2, qc); next_q(); }
     rb_static_for<D - 1>([&](auto R) { load_db(nx[decltype(R)::value + 1]); });
 
     for (int64_t s0 = 0; s0 < steps; s0 += D) {
         rb_static_for<D>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            // behind this wait: the database loads of two later steps and the next step's query pieces may still fly
+            // vmcnt retires in issue order and a step issues [query chunk, row loads]: the chunk of step s, issued at step s - 2 (QA = 2),
+            // sits BEHIND the rows of step s + 1, so waiting for it also waits for those rows one step early — the row stream is
+            // three steps deep at this wait, not the four its registers hold.  QA = 3 issues the chunk at step s - 3 (the ring's
+            // fourth slot, free since this step's barrier), ahead of those rows: four steps deep.  Measured (round 5, same process,
+            // 200 x 1.25 M x 512): 0.339 vs 0.341 ms — the depth of the row stream is NOT what bounds the pass; QA = 2 stays.
+            constexpr int DBW = (QA == 3 ? 3 : 2) * DBL, QW = QA == 3 ? 2 : 1;
             if (s0 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (my_lps == 0) rb_wait_vm<2 * DBL>();
-            else if (LPS == 1 || my_lps == 1) rb_wait_vm<2 * DBL + KD>();
-            else if (LPS == 2 || my_lps == 2) rb_wait_vm<2 * DBL + 2 * KD>();
-            else if (LPS == 3 || my_lps == 3) rb_wait_vm<2 * DBL + 3 * KD>();
-            else rb_wait_vm<2 * DBL + 4 * KD>();
+            else if (my_lps == 0) rb_wait_vm<DBW>();
+            else if (LPS == 1 || my_lps == 1) rb_wait_vm<DBW + QW * KD>();
+            else if (LPS == 2 || my_lps == 2) rb_wait_vm<DBW + QW * 2 * KD>();
+            else if (LPS == 3 || my_lps == 3) rb_wait_vm<DBW + QW * 3 * KD>();
+            else rb_wait_vm<DBW + QW * 4 * KD>();
             __builtin_amdgcn_s_barrier();
             rb_bf16x8_t dfr[NF][KD];
 #pragma unroll
@@ -569,7 +607,7 @@ __global__ __launch_bounds__(512, 1) void sim_candidates_shadow2_kernel(const un
                     asm volatile("" : "+v"(v)::"memory");            // consumed HERE, before the loads below overwrite the set
                     dfr[f][h] = __builtin_bit_cast(rb_bf16x8_t, v);
                 }
-            issue_q((r + 2) & 3, qc); next_q();
+            issue_q((r + QA) & 3, qc); next_q();
             load_db(nx[r]);
             constexpr int NV = KD * NQT;  // fragment v: chunk v / NQT, query tile v % NQT — 1 KiB apart in the stage buffer
             constexpr int QD = NV < 4 ? NV : 4;
@@ -587,38 +625,123 @@ __global__ __launch_bounds__(512, 1) void sim_candidates_shadow2_kernel(const un
             });
             if constexpr (r == D - 1) {  // nchunk % D == 0: a block can only end on the last step of the unrolled group
                 if (c + 1 == nchunk) {
-                    const unsigned n_db32 = (unsigned)n_db;
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-                        const unsigned row0 = (unsigned)(blk * BR) + (unsigned)((wave * NF + f) * 16);
-                        const unsigned key0 = 0xFFFFFFFFu - (uint32_t)row_base - row0 - 4u * g;
-#pragma unroll
-                        for (int t = 0; t < NQT; ++t) {
-                            asm volatile("" ::: "memory");  // one threshold live at a time
-                            const float tq = sthr[16 * t + r16];
-                            // hits are rare (0.1-0.2 % of the scores): one ballot over the lane's best of four decides whether the
-                            // four per-row ballots run at all (the record order is unchanged: empty groups are just not visited)
-                            const float best = fmaxf(fmaxf(acc[f][t][0], acc[f][t][1]), fmaxf(acc[f][t][2], acc[f][t][3]));
-                            if (__ballot(best >= tq))
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float sc = acc[f][t][e];
-                                const unsigned row = row0 + 4 * g + e;
-                                const bool hit = sc >= tq && row < n_db32;
-                                const unsigned long long m = __ballot(hit);
-                                if (m) {
-                                    const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                    if (hit && pos < stage_cap) {
-                                        const unsigned o = pos * 16u, k_lo = key0 - e, k_hi = rb_ordered_bits(sc), qq = (unsigned)(q0 + 16 * t) + r16;
-                                        asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(k_lo), "s"(my_stage) : "memory");
-                                        asm volatile("global_store_dword %0, %1, %2 offset:4" ::"v"(o), "v"(k_hi), "s"(my_stage) : "memory");
-                                        asm volatile("global_store_dword %0, %1, %2 offset:8" ::"v"(o), "v"(qq), "s"(my_stage) : "memory");
+                    if constexpr (EPI == 0) {
+                        const unsigned n_db32 = (unsigned)n_db;
+    #pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const unsigned row0 = (unsigned)(blk * BR) + (unsigned)((wave * NF + f) * 16);
+                            const unsigned key0 = 0xFFFFFFFFu - (uint32_t)row_base - row0 - 4u * g;
+    #pragma unroll
+                            for (int t = 0; t < NQT; ++t) {
+                                asm volatile("" ::: "memory");  // one threshold live at a time
+                                const float tq = sthr[16 * t + r16];
+                                // hits are rare (0.1-0.2 % of the scores): one ballot over the lane's best of four decides whether the
+                                // four per-row ballots run at all (the record order is unchanged: empty groups are just not visited)
+                                const float best = fmaxf(fmaxf(acc[f][t][0], acc[f][t][1]), fmaxf(acc[f][t][2], acc[f][t][3]));
+                                if (__ballot(best >= tq))
+    #pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float sc = acc[f][t][e];
+                                    const unsigned row = row0 + 4 * g + e;
+                                    const bool hit = sc >= tq && row < n_db32;
+                                    const unsigned long long m = __ballot(hit);
+                                    if (m) {
+                                        const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                        if (hit && pos < stage_cap) {
+                                            const unsigned o = pos * 16u, k_lo = key0 - e, k_hi = rb_ordered_bits(sc), qq = (unsigned)(q0 + 16 * t) + r16;
+                                            asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(k_lo), "s"(my_stage) : "memory");
+                                            asm volatile("global_store_dword %0, %1, %2 offset:4" ::"v"(o), "v"(k_hi), "s"(my_stage) : "memory");
+                                            asm volatile("global_store_dword %0, %1, %2 offset:8" ::"v"(o), "v"(qq), "s"(my_stage) : "memory");
+                                        }
+                                        wcount += (unsigned)__popcll(m);
                                     }
-                                    wcount += (unsigned)__popcll(m);
                                 }
+                                acc[f][t] = (rb_f32x4_t){0.f, 0.f, 0.f, 0.f};
                             }
-                            acc[f][t] = (rb_f32x4_t){0.f, 0.f, 0.f, 0.f};
                         }
+                    } else {
+                        // The block's candidate epilogue: 2 x NQT groups of 4 x 64 scores per wave.  While it runs the wave issues no
+                        // loads; the D steps already in flight keep the memory pipe busy for ~4 us, so the epilogue must stay well
+                        // below that (round 4: ~6 us per block — one LDS threshold read, a canonicalising max chain and a vector
+                        // branch per group, each waited for in turn: 0.12-0.15 ms of the 0.37 ms pass).  Now: the lane's NQT thresholds
+                        // are read from LDS once per epilogue (the fragment registers of the step are dead here), a group is four v_cmp straight into scalar masks (no max, no LDS, nothing to
+                        // wait for but the compares) reduced and tested on the SCALAR unit, which also skips empty rows of a hit
+                        // group; the bound test against n_db is a scalar mask that differs from all-ones in the last block only.
+                        // Same records in the same order as before (groups in (f, t, e) order, lanes ascending).
+                        const unsigned n_db32 = (unsigned)n_db;
+                        if constexpr (EPI == 2) {
+                            if (wl > (unsigned)(RCAP - 64)) flush_records();   // the one flush site inside the scan: rarely taken
+                        }
+                        float tqr[NQT];
+    #pragma unroll
+                        for (int t = 0; t < NQT; ++t) tqr[t] = sthr[16 * t + r16];
+                        unsigned long long vm[NF][4];
+    #pragma unroll
+                        for (int f = 0; f < NF; ++f)
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) vm[f][e] = ~0ull;
+                        if (blk == last_blk) {
+    #pragma unroll
+                            for (int f = 0; f < NF; ++f)
+    #pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    vm[f][e] = __ballot((unsigned)(blk * BR) + (unsigned)((wave * NF + f) * 16) + 4u * g + e < n_db32);
+                        }
+                        rb_static_for<NF>([&](auto F_) {
+                            constexpr int f = decltype(F_)::value;
+                            const unsigned row0 = (unsigned)(blk * BR) + (unsigned)((wave * NF + f) * 16);
+                            const unsigned key0 = 0xFFFFFFFFu - (uint32_t)row_base - row0 - 4u * g;
+                            rb_static_for<NQT>([&](auto T_) {
+                                constexpr int t = decltype(T_)::value;
+                                const float tq = tqr[t];
+                                const unsigned long long m0 = __ballot(acc[f][t][0] >= tq) & vm[f][0];
+                                const unsigned long long m1 = __ballot(acc[f][t][1] >= tq) & vm[f][1];
+                                const unsigned long long m2 = __ballot(acc[f][t][2] >= tq) & vm[f][2];
+                                const unsigned long long m3 = __ballot(acc[f][t][3] >= tq) & vm[f][3];
+                                if ((m0 | m1) | (m2 | m3)) {
+                                    const unsigned long long ms[4] = {m0, m1, m2, m3};
+    #pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const unsigned long long m = ms[e];
+                                        if (m) {
+                                            const float sc = acc[f][t][e];
+                                            const bool hit = sc >= tq && row0 + 4 * g + e < n_db32;
+                                            if constexpr (EPI == 2) {
+                                                // records wait in the wave's LDS buffer (see flush_records): no global store, hence no
+                                                // vmcnt entry, between the row loads of this block and the counted waits of the next
+                                                const unsigned pos = wl + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                                if (hit) {
+                                                    const unsigned k_lo = key0 - e, k_hi = rb_ordered_bits(sc), qq = (unsigned)(q0 + 16 * t) + r16;
+                                                    if (pos < (unsigned)RCAP) {
+                                                        const unsigned a = rec_lds + pos * 16u;
+                                                        asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(a), "v"(k_lo), "v"(k_hi) : "memory");
+                                                        asm volatile("ds_write_b32 %0, %1 offset:8" ::"v"(a), "v"(qq) : "memory");
+                                                    } else if (wcount + pos < stage_cap) {
+                                                        // a burst beyond the buffer (each epilogue starts with >= 64 free records): straight to
+                                                        // the record's place in the staging slot, as the other forms do
+                                                        const unsigned o = (wcount + pos) * 16u;
+                                                        asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(k_lo), "s"(my_stage) : "memory");
+                                                        asm volatile("global_store_dword %0, %1, %2 offset:4" ::"v"(o), "v"(k_hi), "s"(my_stage) : "memory");
+                                                        asm volatile("global_store_dword %0, %1, %2 offset:8" ::"v"(o), "v"(qq), "s"(my_stage) : "memory");
+                                                    }
+                                                }
+                                                wl += (unsigned)__popcll(m);
+                                            } else {
+                                            const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                            if (hit && pos < stage_cap) {
+                                                const unsigned o = pos * 16u, k_lo = key0 - e, k_hi = rb_ordered_bits(sc), qq = (unsigned)(q0 + 16 * t) + r16;
+                                                asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(k_lo), "s"(my_stage) : "memory");
+                                                asm volatile("global_store_dword %0, %1, %2 offset:4" ::"v"(o), "v"(k_hi), "s"(my_stage) : "memory");
+                                                asm volatile("global_store_dword %0, %1, %2 offset:8" ::"v"(o), "v"(qq), "s"(my_stage) : "memory");
+                                            }
+                                            wcount += (unsigned)__popcll(m);
+                                            }
+                                        }
+                                    }
+                                }
+                                acc[f][t] = (rb_f32x4_t){0.f, 0.f, 0.f, 0.f};
+                            });
+                        });
                     }
                     c = 0;
                     blk += gridDim.x;
@@ -634,6 +757,7 @@ __global__ __launch_bounds__(512, 1) void sim_candidates_shadow2_kernel(const un
     for (int r = 0; r < D; ++r)
 #pragma unroll
         for (int f = 0; f < NF; ++f) asm volatile("s_waitcnt vmcnt(0)" ::"v"(nx[r][f][0]), "v"(nx[r][f][1]) : "memory");
+    if constexpr (EPI == 2) flush_records();
     if (lane == 0) stage_cnt[wave_slot] = wcount;
 }
 
@@ -709,11 +833,24 @@ __global__ void pack_queries_kernel(const float* __restrict__ q, int n_q, int d,
 // fp32 row, so the approximate scores are bit-identical to the fp32-database scan.  One wave per row; the wave also leaves
 // max |row|^2 (fp32, lane-strided partial sums + a fixed xor tree: deterministic) for the completeness proof.
 __global__ __launch_bounds__(256) void dense_shadow_kernel(const float* __restrict__ db, int64_t n_db, int d, uint4* __restrict__ out,
-                                                           unsigned* __restrict__ max_norm2_bits) {
+                                                           unsigned* __restrict__ max_norm2_bits, int tiled) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_db) return;
     const int units = d >> 3;  // 16-B output units per row
+    // tiled (d % 256 == 0, what sim_candidates_shadow2_kernel reads): rows in blocks of 256; inside a block the 64-deep k-steps are
+    // the OUTER index — [block][step][row in block][128 B = chunk 2 step | chunk 2 step + 1] — so a scan step of a block is one
+    // contiguous 32 KB and a wave's load instruction covers 1 KB of whole lines (row-major: 16 half lines 1 KB apart per instruction,
+    // and every step of every CU touched 256 DRAM pages).  Rows past n_db in the last block are zero.
+    auto unit_index = [&](int u) -> int64_t {
+        if (!tiled) return row * units + u;
+        const int c = u >> 2, g = u & 3;
+        return (row >> 8) * (int64_t)(256 * units) + (int64_t)(c >> 1) * (256 * 8) + (row & 255) * 8 + (c & 1) * 4 + g;
+    };
+    if (row >= n_db) {
+        if (tiled && row < ((n_db + 255) >> 8 << 8))
+            for (int u = lane; u < units; u += 64) out[unit_index(u)] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     const float* src = db + row * d;
     float ss = 0.f;
     for (int u = lane; u < units; u += 64) {
@@ -721,7 +858,7 @@ __global__ __launch_bounds__(256) void dense_shadow_kernel(const float* __restri
         const float4 a = *reinterpret_cast<const float4*>(src + 32 * c + 4 * g), b = *reinterpret_cast<const float4*>(src + 32 * c + 16 + 4 * g);
         ss = fmaf(a.x, a.x, ss); ss = fmaf(a.y, a.y, ss); ss = fmaf(a.z, a.z, ss); ss = fmaf(a.w, a.w, ss);
         ss = fmaf(b.x, b.x, ss); ss = fmaf(b.y, b.y, ss); ss = fmaf(b.z, b.z, ss); ss = fmaf(b.w, b.w, ss);
-        out[row * units + u] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+        out[unit_index(u)] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -801,6 +938,7 @@ SWAT_API int64_t swat_dense_workspace_bytes(int n_q) {
 
 // Candidate pass, deep form (d % 128 == 0, n_q <= 4096): as swat_sim_candidates_bf16 with the queries given as the packed
 // image and a workspace of swat_dense_workspace_bytes(n_q) bytes for the per-wave staging of the candidate records.
+static int g_dense_epi = -1;   // swat_dense_set_epilogue / SWAT_DENSE_EPI (tuning): candidate epilogue of the shadow scan, 0 = round 4's, 1 = scalar masks, 2 = + records buffered in LDS
 static int dense_candidates_packed(const void* packed, int n_q, const float* db, bool shadow, int64_t n_db, int d, const float* thr_dev,
                                    int64_t row_base, void* cand_keys, int cap, void* cand_cnt, float* max_norm2,
                                    void* workspace, int64_t workspace_bytes, swat_stream_t s) {
@@ -820,26 +958,20 @@ static int dense_candidates_packed(const void* packed, int n_q, const float* db,
     hipStream_t st = (hipStream_t)s;
     const int n_tiles = dense_tiles(n_q);
     static const int abl = getenv("SWAT_DENSE_ABL") ? atoi(getenv("SWAT_DENSE_ABL")) : 0;  // tuning: timing ablations, wrong results
-    static const int nf = getenv("SWAT_DENSE_NF") ? atoi(getenv("SWAT_DENSE_NF")) : 2;  // tuning: 16-row fragments per wave of the shadow scan
-    static const int kd = getenv("SWAT_DENSE_KD") ? atoi(getenv("SWAT_DENSE_KD")) : 2;  // tuning: 32-k chunks per step of the shadow scan
     static const int waves = getenv("SWAT_DENSE_WAVES") ? atoi(getenv("SWAT_DENSE_WAVES")) : 12;  // tuning: 4 = 64-row blocks, 3 workgroups per CU
+    if (g_dense_epi < 0) g_dense_epi = getenv("SWAT_DENSE_EPI") ? atoi(getenv("SWAT_DENSE_EPI")) : 2;
+    const int epi = g_dense_epi;
+    static const int qa = getenv("SWAT_DENSE_QA") ? atoi(getenv("SWAT_DENSE_QA")) : 2;   // tuning: query chunks 2 (default) or 3 steps ahead
 #define SWAT_CAND_DEEP(NQT_, ABL_)                                                                                       \
-    if (shadow && d % 256 == 0 && kd == 2 && nf == 2 && (ABL_) == 0) {                                                   \
+    if (shadow && d % 256 == 0) {   /* (the tiled shadow image has one reader) */                                        \
         const int64_t nblocks = (n_db + 255) / 256;                                                                      \
         const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);                                                 \
-        auto kern = sim_candidates_shadow2_kernel<NQT_>;                                                                 \
-        const int lds = 4 * 2 * 16 * NQT_ * 64;                                                                          \
+        auto kern = epi == 2 ? (qa == 3 ? sim_candidates_shadow2_kernel<NQT_, 2, 3> : sim_candidates_shadow2_kernel<NQT_, 2, 2>) \
+                             : (qa == 3 ? sim_candidates_shadow2_kernel<NQT_, 0, 3> : sim_candidates_shadow2_kernel<NQT_, 0, 2>); \
+        const int lds = 4 * 2 * 16 * NQT_ * 64 + (epi == 2 ? 8 * SHADOW2_RCAP * 16 : 0);                                 \
         SWAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));               \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const unsigned short*)packed, n_tiles, n_q, q0,        \
                            (const unsigned short*)db, n_db, d, thr_dev, row_base, stage, stage_cap, stage_cnt);          \
-    } else if (shadow && d % 256 == 0 && kd == 2) {                                                                      \
-        const int64_t nblocks = (n_db + 191) / 192;                                                                      \
-        const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);                                                 \
-        auto kern = sim_candidates_bf16_deep_kernel<NQT_, 4, 12, ABL_, true, 2>;                                         \
-        const int lds = 4 * 2 * 16 * NQT_ * 64;                                                                          \
-        SWAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));               \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, st, (const unsigned short*)packed, n_tiles, n_q, q0, db,    \
-                           n_db, d, thr_dev, row_base, stage, stage_cap, stage_cnt, (unsigned*)max_norm2);               \
     } else if (shadow) {                                                                                                 \
         const int64_t nblocks = (n_db + 191) / 192;                                                                      \
         const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);                                                 \
@@ -885,6 +1017,12 @@ static int dense_candidates_packed(const void* packed, int n_q, const float* db,
     return check_launch("swat_sim_candidates_packed");
 }
 
+SWAT_API int swat_dense_set_epilogue(int form) {
+    SWAT_REQUIRE(form == 0 || form == 2, "swat_dense_set_epilogue: 0 or 2");
+    g_dense_epi = form;
+    return 0;
+}
+
 SWAT_API int swat_sim_candidates_packed(const void* packed, int n_q, const float* db, int64_t n_db, int d, const float* thr_dev,
                                         int64_t row_base, void* cand_keys, int cap, void* cand_cnt, float* max_norm2,
                                         void* workspace, int64_t workspace_bytes, swat_stream_t s) {
@@ -897,15 +1035,18 @@ SWAT_API int swat_sim_candidates_packed(const void* packed, int n_q, const float
 // candidate lists bit for bit (same roundings), half the HBM bytes per row.
 SWAT_API int64_t swat_dense_shadow_bytes(int64_t n_db, int d) {
     if (n_db <= 0 || d <= 0 || d % 128 != 0) return 0;
+    if (d % 256 == 0) return ((n_db + 255) / 256 * 256) * d * 2;   // tiled image: whole blocks of 256 rows (dense_shadow_kernel)
     return n_db * d * 2;
 }
 
 SWAT_API int swat_dense_build_shadow(const float* db, int64_t n_db, int d, void* shadow, float* max_norm2, swat_stream_t s) {
     SWAT_REQUIRE(db && shadow && max_norm2, "swat_dense_build_shadow: null pointer");
     SWAT_REQUIRE(n_db > 0 && d > 0 && d % 128 == 0, "swat_dense_build_shadow: d=%d must be a multiple of 128", d);
-    SWAT_REQUIRE((n_db + 3) / 4 < (1ll << 31), "swat_dense_build_shadow: too many rows for one launch");
-    hipLaunchKernelGGL(dense_shadow_kernel, dim3((unsigned)((n_db + 3) / 4)), dim3(256), 0, (hipStream_t)s, db, n_db, d, (uint4*)shadow,
-                       (unsigned*)max_norm2);
+    const int tiled = d % 256 == 0 ? 1 : 0;
+    const int64_t rows = tiled ? (n_db + 255) / 256 * 256 : n_db;
+    SWAT_REQUIRE((rows + 3) / 4 < (1ll << 31), "swat_dense_build_shadow: too many rows for one launch");
+    hipLaunchKernelGGL(dense_shadow_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, db, n_db, d, (uint4*)shadow,
+                       (unsigned*)max_norm2, tiled);
     return check_launch("swat_dense_build_shadow");
 }
 

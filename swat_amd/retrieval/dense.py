@@ -156,12 +156,14 @@ def _prepared(db, queries, k, sample):
         nq, d = queries.shape
         b = _shape_buffers(nq, d, k, db.device)
         K2 = b["K2"]
-        thr, qn2 = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)), approx=True, want_qnorm=True)
+        # (the packing first: it needs nothing from the thresholds, and the GPU — idle at the start of a cold call — runs it while the
+        # host is still marshalling the threshold sample's product)
         if b["packed"]:
             qb = b["qb"]
             _lib.check(_lib.lib().swat_dense_pack_queries(_lib.ptr(queries), nq, d, _lib.ptr(qb), _lib.stream()), "swat_dense_pack_queries")
         else:
             qb = queries.to(torch.bfloat16).contiguous()
+        thr, qn2 = _thresholds(queries, db, k, sample, 2.5 * max(1.0, K2 / (2.0 * k)), approx=True, want_qnorm=True)
         clean = b["cnt_clean"]
         _cache.clear()
         _cache.update(b)

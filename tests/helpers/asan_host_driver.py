@@ -56,7 +56,7 @@ run("swat_attn_fwd_tiled", N, N, N, 1, 100, 64, 1, 0, N)
 run("swat_attn_fwd_tiled", P(), P(1), N, 2, 400, 128, 2, 0, N)
 run("swat_attn_bwd_tiled", P(), P(1), P(2), P(3), P(4), 2, 100, 128, 2, N, N)
 run("swat_attn_fwd_small", P(), P(1), 2, 65, 128, 2, N)
-assert h.swat_dense_shadow_bytes(1000, 512) == 1000 * 512 * 2 and h.swat_dense_shadow_bytes(1000, 100) == 0
+assert h.swat_dense_shadow_bytes(1000, 512) == 1024 * 512 * 2 and h.swat_dense_shadow_bytes(1000, 640) == 1000 * 640 * 2 and h.swat_dense_shadow_bytes(1000, 100) == 0
 run("swat_dense_build_shadow", N, 10, 512, P(), P(1), N)
 run("swat_dense_build_shadow", P(), 10, 100, P(1), P(2), N)
 run("swat_dense_build_shadow", P(), 1 << 20, 512, P(1), P(2), N)

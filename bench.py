@@ -70,11 +70,11 @@ def build_job(dev, world, bsz=32, n_cls=200, arch="ViT-B-32-quickgelu", total_it
 
 
 def run_steps(args, step, sched, images, labels, n):
-    from swat_amd.training import cutmix_draw
+    from swat_amd.training import cutmix_draw, to_device
     for _ in range(n):
         lam, perm, box = cutmix_draw(args, images.size())
         if perm is not None:
-            perm = perm.to(images.device, non_blocking=True)
+            perm = to_device(perm, images.device)
             step(images, labels, labels[perm], lam, perm=perm, box=box)
         else:
             step(images, labels, labels, 1.0)

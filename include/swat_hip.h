@@ -228,6 +228,14 @@ int swat_layernorm_bwd_partial(const float* dy, int64_t dy_stride, int nsplit, i
                                swat_stream_t stream);
 int swat_layernorm_bwd_finish(const void* workspace, int rows, int d, float* dgamma, float* dbeta, float* dcolsum,
                               swat_stream_t stream);
+/*     swat_layernorm_bwd_partial for LayerNorm rows that sit `period` rows apart in a contiguous d-wide output (dx_out fp32 and / or
+ *     dx_bf16, [rows * period, d]; LayerNorm row j -> output row j * period): the same launch also writes ZEROS to every output row
+ *     in between — the tower's top gradient, where only the class-token row of an image carries one (ref: `pooled = x[:, 0]` in
+ *     open_clip's VisionTransformer.forward behind model.encode_image, utils/training.py:1474).  Partial sums as
+ *     swat_layernorm_bwd_partial (reduce with swat_layernorm_bwd_finish(workspace, rows, d, ...)). */
+int swat_layernorm_bwd_partial_fill(const float* dy, int64_t dy_stride, const float* x, int64_t x_stride, const float* gamma,
+                                    const float* mean, const float* rstd, float* dx_out, void* dx_bf16, int period,
+                                    void* workspace, int rows, int d, swat_stream_t stream);
 
 /* A2d  attention softmax over score rows (fp32 S, ld = padded T): P = softmax(scale*S[:, :T]) bf16,
  *     pad columns zeroed; causal!=0 for the text tower.  Backward: dS = scale*P o (dP - rowsum(P o dP)). */
@@ -360,6 +368,15 @@ swat_stream_t swat_vit_aux_stream(int i); /* i = 0, 1: two more process-wide str
 int swat_vit_lane_order(swat_stream_t stream); /* `stream` waits for what the lane holds now; the lane is not joined */
 int swat_vit_lane_follow(swat_stream_t stream); /* the lane waits for what `stream` holds now (then work may be queued on swat_vit_lane_stream()) */
 int swat_vit_backward_join(swat_stream_t stream);
+/* swat_vit_backward_join that leaves the join OWED instead of making `stream` wait now: what the lane and the second internal stream
+ *     still hold after a one-GPU step (the blocks' weight gradients and their AdamW) is read again only by the blocks of the next
+ *     forward, so the next step's stem (CutMix / patch extraction, patch embedding, class row, ln_pre: stage-0 parameters, stepped on
+ *     `stream` itself) may run beside the optimizer's tail.  swat_vit_forward pays the debt behind its stem; swat_vit_backward,
+ *     swat_vit_backward_join and swat_vit_join_pending(stream) pay it at once.  A caller that reads parameters, moments or gradients
+ *     itself (checkpoint, torch ops on the arena) calls swat_vit_join_pending(its stream) first.
+ *     ref: one process, one stream in the reference (utils/training.py:1486-1489): nothing there to order. */
+int swat_vit_backward_join_later(swat_stream_t stream);
+int swat_vit_join_pending(swat_stream_t stream);
 /* Data-parallel form of the blocks' backward (gradient all-reduce overlapped with backward work; ref: the
  *     reference is one process, utils/training.py:1486-1488).  swat_vit_backward_set_buckets names buckets of transformer blocks from
  *     the top of the tower down (n <= 16; the last one takes what remains).  The NEXT swat_vit_backward call that runs the blocks as

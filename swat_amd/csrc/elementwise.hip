@@ -95,10 +95,26 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
                                                      const float* __restrict__ rstd, const float* dx_add,
                                                      int64_t dxa_stride, float* dx_out, int64_t dxo_stride,
                                                      unsigned short* __restrict__ dx_bf, int64_t dxb_stride,
-                                                     float* __restrict__ part, int rows, int d, int64_t split_stride) {
+                                                     float* __restrict__ part, int rows, int d, int64_t split_stride,
+                                                     int ln_blocks, int fill_period) {
     __shared__ float sh[LNB_WAVES][64 * 4 * VPL];  // [wave][d], reused for dgamma / dbeta / colsum(dx_bf16)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
+    if ((int)blockIdx.x >= ln_blocks) {
+        // fill role (swat_layernorm_bwd_partial_fill): the rows of dx_out / dx_bf BETWEEN the LayerNorm's rows — output row j of the
+        // LayerNorm is row j * fill_period of the (contiguous, d-wide) output, rows with j % fill_period != 0 are set to zero.  The
+        // class-token gradient of the tower's top: one launch instead of a zero fill and a LayerNorm backward.
+        const int64_t total = (int64_t)rows * fill_period;
+        const int fb = (int)blockIdx.x - ln_blocks, nfb = (int)gridDim.x - ln_blocks;
+        for (int64_t r = (int64_t)fb * LNB_WAVES + wave; r < total; r += (int64_t)nfb * LNB_WAVES) {
+            if (r % fill_period == 0) continue;
+            for (int c = lane; c < nv; c += 64) {
+                if (dx_out) reinterpret_cast<float4*>(dx_out + r * d)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dx_bf) reinterpret_cast<ushort4*>(dx_bf + r * d)[c] = make_ushort4(0, 0, 0, 0);
+            }
+        }
+        return;
+    }
     float4 dg[VPL], db[VPL], dcs[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
         db[i] = dg[i];
         dcs[i] = dg[i];
     }
-    for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
+    for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += ln_blocks * LNB_WAVES) {
         const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * dy_stride);
         const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * x_stride);
         const float mu = mean[row], rs = rstd[row];
@@ -577,9 +593,9 @@ SWAT_API int64_t swat_layernorm_bwd_workspace_bytes(int rows, int d) {
 }
 
 #define LNB_LAUNCH(NS, V)                                                                                                    \
-    hipLaunchKernelGGL((ln_bwd_kernel<NS, V>), dim3(nblk), dim3(64 * lnb_waves(d)), 0, (hipStream_t)s, dy, dy_stride, x, x_stride,  \
+    hipLaunchKernelGGL((ln_bwd_kernel<NS, V>), dim3(nblk + fill_blocks), dim3(64 * lnb_waves(d)), 0, (hipStream_t)s, dy, dy_stride, x, x_stride,  \
                        gamma, mean, rstd, dx_add, dxa_stride, dx_out, dxo_stride, (unsigned short*)dx_bf16, dxb_stride,      \
-                       (float*)workspace, rows, d, split_stride)
+                       (float*)workspace, rows, d, split_stride, nblk, fill_period)
 #define LNB_SPLITS(V)                       \
     switch (nsplit) {                       \
         case 1: LNB_LAUNCH(1, V); break;    \
@@ -603,6 +619,7 @@ SWAT_API int swat_layernorm_bwd(const float* dy, int64_t dy_stride, const float*
     const int nblk = lnb_blocks(rows, d);
     const int nsplit = 1;
     const int64_t split_stride = 0;
+    const int fill_blocks = 0, fill_period = 1;
     LNB_DISPATCH();
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 31) / 32, 3), dim3(1024), 0, (hipStream_t)s, (const float*)workspace,
                        nblk, d, dgamma, dbeta, dcolsum);
@@ -630,8 +647,29 @@ SWAT_API int swat_layernorm_bwd_partial(const float* dy, int64_t dy_stride, int 
     SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && nsplit >= 1 && nsplit <= 4, "swat_layernorm_bwd_partial: bad arguments");
     if (rows <= 0) return 0;
     const int nblk = lnb_blocks(rows, d);
+    const int fill_blocks = 0, fill_period = 1;
     LNB_DISPATCH();
     return check_launch("swat_layernorm_bwd_partial");
+}
+
+// swat_layernorm_bwd_partial for LayerNorm rows that sit `period` rows apart in a contiguous d-wide output (dx_out and / or dx_bf16:
+// [rows * period, d]; LayerNorm row j -> output row j * period): the same launch ALSO writes zeros to every output row in between.
+// The tower's top gradient — only the class-token row of every image carries one (ref: `pooled = x[:, 0]` of open_clip's
+// VisionTransformer.forward; utils/training.py:1486 backward) — in one launch instead of a zero fill and a LayerNorm backward.
+SWAT_API int swat_layernorm_bwd_partial_fill(const float* dy, int64_t dy_stride, const float* x, int64_t x_stride, const float* gamma,
+                                             const float* mean, const float* rstd, float* dx_out, void* dx_bf16, int period,
+                                             void* workspace, int rows, int d, swat_stream_t s) {
+    SWAT_REQUIRE(d % 4 == 0 && d <= 256 * LN_MAXV && period >= 1 && (dx_out || dx_bf16), "swat_layernorm_bwd_partial_fill: bad arguments");
+    if (rows <= 0) return 0;
+    const int nblk = lnb_blocks(rows, d);
+    const int nsplit = 1;
+    const int64_t split_stride = 0;
+    const float* dx_add = nullptr;
+    const int64_t dxa_stride = 0, dxo_stride = (int64_t)period * d, dxb_stride = (int64_t)period * d;
+    const int fill_period = period;
+    const int fill_blocks = period > 1 ? (512 - nblk > 1 ? 512 - nblk : 1) : 0;
+    LNB_DISPATCH();
+    return check_launch("swat_layernorm_bwd_partial_fill");
 }
 
 namespace swat {

@@ -31,6 +31,71 @@ __global__ __launch_bounds__(256) void zero2_kernel(uint4* __restrict__ a, int64
     }
 }
 
+// The forward's tail in one launch (round 4: ln_fwd_kernel on the class-token rows, then a [B, d] x [d, E] product with 32 rows — two
+// launches of 5 + 13 us on the chain between the persistent forward and the loss): workgroup (j, b) normalises the class-token row of
+// image b (two-pass statistics, as ln_fwd_kernel) and computes 64 columns of feats[b] = ln_post(x[b, 0]) @ proj.  Thread (e4, part):
+// columns 64 j + 4 e4 .. + 3, rows c = part, part + 16, ... of proj as ONE fp32 fma chain in ascending c; the 16 parts are added in
+// part order.  Workgroup j = 0 also stores u = ln_post(x[b, 0]) and its statistics for the backward.
+// ref: `pooled = ln_post(x)[:, 0]; pooled @ proj` of open_clip's VisionTransformer.forward behind model.encode_image (utils/training.py:1474)
+__global__ __launch_bounds__(256) void cls_ln_proj_kernel(const float* __restrict__ x, int64_t x_stride, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ proj,
+                                                          float* __restrict__ u_out, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          float* __restrict__ feats, int d, int E, float eps) {
+    extern __shared__ float clp_sh[];   // [d] the normalised row | [16][64] partial sums
+    float* su = clp_sh;
+    float* sp = clp_sh + d;
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, j = blockIdx.x;
+    const float* xr = x + (int64_t)b * x_stride;
+    float s = 0.f;
+    for (int c = tid; c < d; c += 256) {
+        const float v = xr[c];
+        su[c] = v;
+        s += v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mu = ((red[0] + red[1]) + (red[2] + red[3])) / (float)d;
+    float q = 0.f;
+    for (int c = tid; c < d; c += 256) {
+        const float t = su[c] - mu;
+        q += t * t;
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float rs = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)d + eps);
+    for (int c = tid; c < d; c += 256) {
+        const float o = (su[c] - mu) * rs * gamma[c] + beta[c];
+        su[c] = o;
+        if (j == 0) u_out[(int64_t)b * d + c] = o;
+    }
+    if (j == 0 && tid == 0) {
+        mean_out[b] = mu;
+        rstd_out[b] = rs;
+    }
+    __syncthreads();
+    const int e4 = tid & 15, part = tid >> 4;
+    const float* pc = proj + 64 * j + 4 * e4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int c = part; c < d; c += 16) {
+        const float4 w = *reinterpret_cast<const float4*>(pc + (int64_t)c * E);
+        const float uv = su[c];
+        acc.x = fmaf(uv, w.x, acc.x); acc.y = fmaf(uv, w.y, acc.y); acc.z = fmaf(uv, w.z, acc.z); acc.w = fmaf(uv, w.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(sp + part * 64 + 4 * e4) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float v = sp[tid];
+#pragma unroll
+        for (int p = 1; p < 16; ++p) v += sp[p * 64 + tid];
+        feats[(int64_t)b * E + 64 * j + tid] = v;
+    }
+}
+
 struct VitDims {
     int B, img, patch, d, L, H, mlp, E, act, save;
     int g, T, M, Kp, ldk, dh, ldp;
@@ -366,6 +431,9 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
     // A2b: ln_pre -> residual stream xs[0]
     TRY(swat_layernorm_fwd(w.xpre, d, params + O.lnpre_w, params + O.lnpre_b, nullptr, w.xs, w.mean_pre, w.rstd_pre, M, d, eps, s));
 
+    // (the previous step's weight gradients / AdamW of the BLOCKS may still run on the lane and the second stream: the stem above read
+    // stage-0 parameters only; everything below reads the blocks')
+    TRY(swat_vit_join_pending(stream));
     int pending = 1;  // split-K planes of the previous block's c_proj still to be summed into xs[l]
     // ViT-B/32 regime: all blocks in ONE persistent launch (csrc/vit_mega.hip); same buffers, so the backward is unchanged
     const int mega = vit_mega_forward(D.B, T, d, D.H, D.mlp, D.L, D.act, D.save, M, D.Mp, params, sh, O.layer, w.xs, w.x1, w.h1, w.h2, w.a,
@@ -423,6 +491,11 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
     }
     // A2g: ln_post on the class token only, then the bias-free projection (fp32)
     float* xl = w.xs + (D.save ? (int64_t)D.L : (int64_t)(D.L & 1)) * M * d;
+    if (pending == 1 && D.E % 64 == 0 && d % 16 == 0) {
+        hipLaunchKernelGGL(cls_ln_proj_kernel, dim3(D.E / 64, D.B), dim3(256), (size_t)(d + 16 * 64) * sizeof(float), s, xl, (int64_t)T * d,
+                           params + O.lnpost_w, params + O.lnpost_b, params + O.proj, w.u, w.mean_post, w.rstd_post, feats, d, D.E, eps);
+        return check_launch("cls_ln_proj_kernel");
+    }
     TRY(swat_layernorm_fwd_split(pending > 1 ? w.xsplit : xl, (int64_t)T * d, pending, (int64_t)M * d, xl, params + O.lnpost_w, params + O.lnpost_b,
                                  nullptr, w.u, w.mean_post, w.rstd_post, D.B, d, eps, s));
     TRY(swat_sgemm_small(w.u, params + O.proj, feats, D.B, D.E, d, d, 1, D.E, 1, D.E, 1.0f, 0, s));
@@ -443,6 +516,10 @@ struct SideLane {
     hipEvent_t blk[2] = {nullptr, nullptr};       // one-launch form: end of the lane work of the last block with this parity
     bool open = false;           // lane work issued and not joined yet
     hipEvent_t aux_done = nullptr;  // end of what the backward queued on aux[0] (the piped AdamW of the blocks): joined with the lane
+    // swat_vit_backward_join_later: the join is owed — whoever next reads what the lane / aux[0] wrote (the next forward's BLOCKS; any
+    // library entry that takes the arena) waits for these two events on its own stream first (swat_vit_join_pending)
+    bool pending = false;
+    hipEvent_t pend_lane = nullptr, pend_aux = nullptr;
     hipEvent_t next() {
         if (ev.size() < 1024) {
             hipEvent_t e;
@@ -476,7 +553,29 @@ struct PendingProduct {
 };
 static PendingProduct g_pend_dproj;
 static bool g_defer_top = false;   // swat_vit_backward_defer_top: the caller's promise that the blocks' call comes next (one call)
-static int flush_pending_dproj(hipStream_t s) {
+// ... and the reduction of the ln_post backward's partial sums of the same call (w.lnws is not written again before the stem's
+// LayerNorm backward, which runs after the blocks)
+struct PendingLnPost {
+    bool on = false;
+    const void* ws = nullptr;
+    int rows = 0, d = 0;
+    float *dgamma = nullptr, *dbeta = nullptr, *dcolsum = nullptr;
+};
+static PendingLnPost g_pend_lnpost;
+// (lane: the weight-gradient stream of a call that runs the blocks as the persistent launch.  The column sums — the last block's
+// d c_proj.bias — belong to that block's arena range, whose AdamW follows the LANE's events, not the main stream: they are reduced
+// there; d ln_post.weight / bias and d proj belong to stage L+1, whose AdamW the caller queues on `s` behind this)
+static int flush_pending_dproj(hipStream_t s, hipStream_t lane = nullptr) {
+    if (g_pend_lnpost.on) {
+        const PendingLnPost q = g_pend_lnpost;
+        g_pend_lnpost.on = false;
+        if (lane && lane != s) {
+            TRY(swat_layernorm_bwd_finish(q.ws, q.rows, q.d, nullptr, nullptr, q.dcolsum, lane));
+            TRY(swat_layernorm_bwd_finish(q.ws, q.rows, q.d, q.dgamma, q.dbeta, nullptr, s));
+        } else {
+            TRY(swat_layernorm_bwd_finish(q.ws, q.rows, q.d, q.dgamma, q.dbeta, q.dcolsum, s));
+        }
+    }
     if (!g_pend_dproj.on) return 0;
     const PendingProduct p = g_pend_dproj;
     g_pend_dproj.on = false;
@@ -530,8 +629,42 @@ SWAT_API int swat_vit_lane_follow(swat_stream_t stream) {
     return 0;
 }
 
+// The owed join of swat_vit_backward_join_later, paid on `stream` (no-op when nothing is owed).
+SWAT_API int swat_vit_join_pending(swat_stream_t stream) {
+    if (!g_side.pending) return 0;
+    g_side.pending = false;
+    if (g_side.pend_lane) SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, g_side.pend_lane, 0));
+    if (g_side.pend_aux) SWAT_HIP(hipStreamWaitEvent((hipStream_t)stream, g_side.pend_aux, 0));
+    g_side.pend_lane = g_side.pend_aux = nullptr;
+    return 0;
+}
+
+// swat_vit_backward_join without making `stream` wait now: what the lane and the second stream still hold (the blocks' weight
+// gradients and their AdamW) is only read again by the blocks of the NEXT forward, so the next step's stem — CutMix / patch
+// extraction, patch-embedding product, class row, ln_pre: ~80 us that touch stage-0 parameters only, stepped on the main stream —
+// may run beside the optimizer's tail.  swat_vit_forward pays the join behind its stem, swat_vit_backward / swat_transformer_forward
+// / swat_vit_join_pending at their start.  A caller that reads the arena itself (checkpoint, validation through torch ops, logging)
+// calls swat_vit_join_pending(its stream) first.
+SWAT_API int swat_vit_backward_join_later(swat_stream_t stream) {
+    TRY(flush_pending_dproj((hipStream_t)stream));
+    TRY(swat_vit_join_pending(stream));   // (an older debt first: its events are about to be replaced)
+    if (!g_side.open) return 0;
+    hipEvent_t e = g_side.next();
+    SWAT_REQUIRE(e, "cannot create an event");
+    SWAT_HIP(hipEventRecord(e, g_side.st));
+    g_side.pend_lane = e;
+    g_side.pend_aux = g_side.aux_done;
+    g_side.aux_done = nullptr;
+    g_side.pending = true;
+    g_side.open = false;
+    g_side.doneA = g_side.doneB = nullptr;
+    g_side.blk[0] = g_side.blk[1] = nullptr;
+    return 0;
+}
+
 SWAT_API int swat_vit_backward_join(swat_stream_t stream) {
     TRY(flush_pending_dproj((hipStream_t)stream));
+    TRY(swat_vit_join_pending(stream));
     if (!g_side.open) return 0;
     hipEvent_t e = g_side.next();
     SWAT_REQUIRE(e, "cannot create an event");
@@ -646,6 +779,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
     const unsigned short* sh = (const unsigned short*)shadow_bf16;
     const int M = D.M, d = D.d, T = D.T, np = D.B * D.g * D.g, mlp = D.mlp;
 
+    TRY(swat_vit_join_pending(stream));
     const bool fork = g_overlap != 0;
     if (fork) SWAT_REQUIRE(g_side.ensure() == 0, "swat_vit_backward: cannot create the weight-gradient stream");
     hipStream_t ws = fork ? g_side.st : s;  // weight-gradient lane
@@ -713,14 +847,18 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             wait_lane(doneA);
             wait_lane(blk[0]);
             wait_lane(blk[1]);
-            // (one launch for both zero fills: two hipMemsetAsync are two ~6 us launches on the critical path)
-            hipLaunchKernelGGL(zero2_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<uint4*>(w.dx), (int64_t)M * d * 4 / 16,
-                               reinterpret_cast<uint4*>(dxb_head), (int64_t)M * d * 2 / 16);
-            TRY(check_launch("zero2_kernel"));
+            // ONE launch: LayerNorm backward of the class-token rows into dx / its bf16 copy, zeros in every other row (round 4: a zero
+            // fill, the LayerNorm's row pass and its reduction — three launches on the chain between the two persistent kernels).  The
+            // reduction of its partial sums (d ln_post.weight / bias, the last block's d c_proj.bias) feeds only the optimizer: with d
+            // proj it waits for the call that runs the blocks and is issued behind the persistent backward.
             const float* xl = w.xs + (int64_t)D.L * M * d;
-            TRY(swat_layernorm_bwd(w.du, d, xl, (int64_t)T * d, params + O.lnpost_w, w.mean_post, w.rstd_post, nullptr, 0, w.dx,
-                                   (int64_t)T * d, dxb_head, (int64_t)T * d, grads + O.lnpost_w, grads + O.lnpost_b,
-                                   grads + (O.layer + 12 * (D.L - 1))[PRB], w.lnws, D.B, d, s));
+            TRY(swat_layernorm_bwd_partial_fill(w.du, d, xl, (int64_t)T * d, params + O.lnpost_w, w.mean_post, w.rstd_post, w.dx, dxb_head, T,
+                                                w.lnws, D.B, d, s));
+            if (defer) {
+                g_pend_lnpost = PendingLnPost{true, w.lnws, D.B, d, grads + O.lnpost_w, grads + O.lnpost_b, grads + (O.layer + 12 * (D.L - 1))[PRB]};
+            } else {
+                TRY(swat_layernorm_bwd_finish(w.lnws, D.B, d, grads + O.lnpost_w, grads + O.lnpost_b, grads + (O.layer + 12 * (D.L - 1))[PRB], s));
+            }
         } else if (stage >= 1 && mega && stage < D.L) {
             continue;   // ran inside the persistent launch of stage L
         } else if (stage == D.L && mega && [&]() -> bool {
@@ -734,7 +872,7 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                    }()) {
             // lane: per block the four weight gradients as one launch; the 2 L LayerNorm reductions as one launch behind them
             to_lane();
-            TRY(flush_pending_dproj(s));   // (behind the persistent backward, beside the lane)
+            TRY(flush_pending_dproj(s, ws));   // (behind the persistent backward, beside the lane)
             const int nblk = ((D.B + 1) / 2) * 16;
             const int64_t lnp = vit_mega_backward_lnp_bytes(D.B, d) / 4;
             std::vector<const float*> parts;

@@ -92,6 +92,7 @@ class FusedTrainStep:
         # N > 1: the blocks' backward as ONE persistent launch with the buckets' all-reduce + AdamW trailing the weight gradients
         # (csrc/vit.hip: swat_vit_backward_set_buckets); SWAT_DP_PERSISTENT=0 keeps the stage-by-stage backward of rounds 2-4
         self.dp_persistent = os.environ.get("SWAT_DP_PERSISTENT", "1") != "0"
+        self.lazy_join = os.environ.get("SWAT_LAZY_JOIN", "1") != "0"
         if self.trail:
             # process-wide streams owned by the library (created once, together with the weight-gradient lane)
             self._comm_stream = torch.cuda.ExternalStream(_lib.lib().swat_vit_aux_stream(0), device=dev)  # all-reduces
@@ -459,7 +460,14 @@ class FusedTrainStep:
                         lo, hi = self._stage_slices[s]
                         finish(sl["stages"][s], lo, hi - lo)
         finally:
-            lib.swat_vit_backward_join(main.cuda_stream)
+            # one GPU: the join with the lane / second stream (the blocks' weight gradients and AdamW) is OWED, not paid here — the next
+            # step's stem reads stage-0 parameters only (stepped on the main stream above) and runs beside the optimizer's tail;
+            # swat_vit_forward pays the join behind its stem (include/swat_hip.h: swat_vit_backward_join_later).  Whoever reads the
+            # arena with torch ops before the next step calls join() (pop_loss_sum does)
+            if self.lazy_join and not self.reduce:
+                lib.swat_vit_backward_join_later(main.cuda_stream)
+            else:
+                lib.swat_vit_backward_join(main.cuda_stream)
             lib.swat_vit_set_overlap(1)
         if self.reduce:
             main.wait_stream(side)
@@ -501,7 +509,13 @@ class FusedTrainStep:
         assert opt.step_count == count_now, (opt.step_count, count_now)
         torch.cuda.synchronize()
 
+    def join(self):
+        """The current stream waits for everything the last step left on the library's side streams (the blocks' weight gradients and
+        AdamW of a one-GPU step: see _trailing_backward).  Call before reading weights, moments or gradients with torch ops."""
+        _lib.check(_lib.lib().swat_vit_join_pending(torch.cuda.current_stream().cuda_stream), "swat_vit_join_pending")
+
     def pop_loss_sum(self):
+        self.join()
         v = self.loss_accum.item()
         # the persistent forward's hand-offs are bounded spins: a give-up is recorded, not hung on.  This is a synchronisation
         # point: nothing is in flight, so a failure that the per-call poll has not seen yet is visible now

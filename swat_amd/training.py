@@ -61,12 +61,57 @@ def rand_bbox(size, lam):
     return bbx1, bby1, bbx2, bby2
 
 
+class _PinnedRing:
+    """Pinned host buffers for the per-iteration permutation.  `torch.randperm(B).cuda()` (ref :1462) copies from PAGEABLE memory:
+    hipMemcpyAsync then stages the copy and returns only when the stream has reached it — the host, which otherwise runs a step or
+    two ahead of the GPU, stood still once per CutMix iteration and every step began with an idle GPU (tools/step_timeline.py: the
+    copy sits at the very end of the previous step's stream).  Drawn into a pinned buffer (same generator, same values) the copy is
+    asynchronous.  64 slots; a slot's next draw waits for the event behind its last upload (to_device)."""
+
+    def __init__(self, slots=64):
+        self.slots, self.i, self.buf, self.ev = slots, 0, {}, {}
+
+    def take(self, n):
+        if not torch.cuda.is_available():
+            return None
+        self.i = (self.i + 1) % self.slots
+        key = (self.i, n)
+        if key not in self.buf:
+            self.buf[key] = torch.empty(n, dtype=torch.int64).pin_memory()
+        ev = self.ev.pop(key, None)
+        if ev is not None:
+            ev.synchronize()
+        self.last = key
+        return self.buf[key]
+
+    def uploaded(self, t):
+        for key, b in self.buf.items():
+            if b.data_ptr() == t.data_ptr():
+                ev = torch.cuda.Event()
+                ev.record()
+                self.ev[key] = ev
+                return
+
+
+_perm_ring = _PinnedRing()
+
+
+def to_device(perm, device):
+    """The permutation of cutmix_draw on the device, without stalling the host (see _PinnedRing)."""
+    out = perm.to(device, non_blocking=True)
+    if perm.is_pinned():
+        _perm_ring.uploaded(perm)
+    return out
+
+
 def cutmix_draw(args, size):
-    """The host-side draws of one train_cutmix iteration (ref :1458-1472) -> (lam, rand_index|None, box|None)."""
+    """The host-side draws of one train_cutmix iteration (ref :1458-1472) -> (lam, rand_index|None, box|None).  rand_index is a
+    pinned host tensor when a GPU is present (upload it with to_device)."""
     r = np.random.rand(1)
     if args.cutmix_beta > 0 and r < args.mix_prob:
         lam = np.random.beta(args.cutmix_beta, args.cutmix_beta)
-        rand_index = torch.randperm(size[0])
+        pin = _perm_ring.take(size[0])
+        rand_index = torch.randperm(size[0], out=pin) if pin is not None else torch.randperm(size[0])
         bbx1, bby1, bbx2, bby2 = rand_bbox(size, lam)
         lam = 1 - ((bbx2 - bbx1) * (bby2 - bby1) / (size[-1] * size[-2]))
         return float(lam), rand_index, (int(bbx1), int(bby1), int(bbx2), int(bby2))
@@ -125,7 +170,7 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
             else:
                 lam, rand_index, box = 1.0, None, None
             if rand_index is not None:
-                rand_index = rand_index.to(args.device)
+                rand_index = to_device(rand_index, args.device)
             if split_batch:
                 loc, ya, yb, perm_l, b = dp.shard_batch(images, labels, rand_index, rank, nranks)
                 step(loc, ya, yb, lam, perm=perm_l, box=box, batch=b)

@@ -632,6 +632,7 @@ def decode_secondary(dev, bsz=32, h=375, w=500, steps=20, with_cpu=True):
                                   "train transform", "host_threads": threads},
            "ms_per_pass": round(dt * 1e3, 3), "dtype": "u8/int16/int32", "decode_only_img_per_s": round(bsz / dt_dec, 1),
            "equals_pillow_decode": same}
+    rec["loader"] = loader_throughput(dev, files, bsz, w, h)
     if with_cpu:
         host_tf = T.build_transform(224, "train")
         t0 = time.perf_counter()
@@ -651,6 +652,60 @@ def decode_secondary(dev, bsz=32, h=375, w=500, steps=20, with_cpu=True):
                                          "reference's loader workers (utils/dataloader.py:107-135 runs 8 of them)",
                                "decode_only_img_per_s": round(1.0 / t_dec, 1)}
     return rec
+
+
+def loader_throughput(dev, files, bsz, w, h, n_files=4096, epochs=3, workers=8):
+    """Files ON DISK -> normalised fp32 training batches, through the CLI's default loaders (swat_amd.dataloader.get_dataloader:
+    DataLoader worker processes that only read the files, host-thread entropy decode, GPU inverse DCT / transform) at the training batch
+    shape — the rate the input pipeline sustains with real file I/O, next to the reference's pipeline (--host_transform: the same
+    DataLoader with Pillow decode + host transform in the workers; ref utils/dataloader.py:107-135) on the same files.  First epoch =
+    worker start-up, not timed."""
+    import shutil
+    import tempfile
+    from types import SimpleNamespace
+    from swat_amd import dataloader as dl, jpeg, transforms as T
+    root = tempfile.mkdtemp(prefix="swat_loader_")
+    try:
+        os.makedirs(os.path.join(root, "img"))
+        lines = []
+        for i in range(n_files):
+            with open(os.path.join(root, "img", f"{i}.jpg"), "wb") as f:
+                f.write(files[i % len(files)])
+            lines.append(f"img/{i}.jpg {i % 200} {i % 2}\n")
+        with open(os.path.join(root, "split.txt"), "w") as f:
+            f.write("".join(lines))
+        split = [["split.txt"], [root]]
+        small = [["split.txt"], [root]]
+        out = {"files": n_files, "file_bytes": len(files[0]), "batch": bsz, "loader_workers": workers, "epochs_timed": epochs - 1}
+        for name, host in (("gpu_pipeline_img_per_s", False), ("host_pipeline_img_per_s", True)):
+            if host:   # (the reference's pipeline runs at a few hundred images per second: a sixth of the files is sample enough)
+                with open(os.path.join(root, "split_host.txt"), "w") as f:
+                    f.write("".join(lines[:n_files // 6]))
+                split = [["split_host.txt"], [root]]
+            args = SimpleNamespace(dataset_root=root, bsz=bsz, num_workers=workers, device=dev, host_transform=host)
+            n0 = dict(jpeg.stats)
+            train_loader, _, _ = dl.get_dataloader(args, split, small, small, None, T.build_transform(224, "val"))
+            n_img, dt = 0, 0.0
+            for ep in range(epochs if not host else 2):
+                t0 = None
+                for batch in train_loader:
+                    x = batch[0].to(dev, non_blocking=True)
+                    if t0 is None:   # an epoch's clock starts with its first batch: the worker processes' start-up is not the pipeline's rate
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                    elif ep >= 1:
+                        n_img += x.shape[0]
+                torch.cuda.synchronize()
+                if ep >= 1:
+                    dt += time.perf_counter() - t0
+            out[name] = round(n_img / dt, 1)
+            if not host:
+                out["decoded_on_gpu_path"] = jpeg.stats["device"] - n0["device"]
+                out["decoded_by_pillow"] = jpeg.stats["host_other_format"] - n0["host_other_format"]
+            del train_loader
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def self_launch(n, argv):

@@ -155,6 +155,16 @@ class DeviceTransformLoader:
             yield (self.tf(imgs, geometry=geo), *rest)
 
 
+def input_pipeline(args):
+    """'gpu_decode' (default: workers read files, decode + transform on host threads / the GPU), 'gpu_transform' (--host_decode:
+    workers decode with Pillow, the GPU transforms) or 'host' (--host_transform: the reference's pipeline, utils/dataloader.py:107-135)."""
+    if getattr(args, 'host_transform', False):
+        return 'host'
+    if getattr(args, 'host_decode', False) or (getattr(args, 'gpu_transform', False) and not getattr(args, 'gpu_decode', False)):
+        return 'gpu_transform'
+    return 'gpu_decode'
+
+
 def load_dataset(dataset_root, split, preprocess, tokenized_text_prompts):
     return MyDataset(dataset_root, split, preprocess, tokenized_text_prompts)
 
@@ -177,8 +187,9 @@ def get_dataloader(args, train_split, val_split, test_split, tokenized_text_prom
         # global batch split over the ranks: each rank's loader yields its own rows (+ CutMix partners) only
         from .dp import RankBatchSampler
         train_kw = dict(batch_sampler=RankBatchSampler(len(tr), args.bsz, args.rank, args.world))
-    gpu_decode = getattr(args, 'gpu_decode', False)
-    if (getattr(args, 'gpu_transform', False) or gpu_decode) and not getattr(args, 'synthetic', 0):
+    pipe = input_pipeline(args)
+    gpu_decode = pipe == 'gpu_decode'
+    if pipe != 'host' and not getattr(args, 'synthetic', 0):
         dev = getattr(args, 'device', 'cuda')
         for ds, mode in ((tr, 'train'), (va, 'val'), (te, 'val')):
             if gpu_decode:   # workers read files; decode + transform on the GPU (same draws, same order: the geometry needs only (w, h))

@@ -70,14 +70,18 @@ def build_parser():
     p.add_argument('--epochs', type=int, default=0)
     p.add_argument('--stop_epochs', type=int, default=200)
     p.add_argument('--num_workers', type=int, default=8)
-    p.add_argument('--gpu_transform', action='store_true',
-                   help='loader workers only decode; crop / bicubic resize / flip / normalise run on the GPU per batch (bit-exact)')
+    # input pipeline (ref utils/dataloader.py:107-135: 8 PIL workers decode and transform every image).  Default for
+    # image-folder data: the workers only READ the files; baseline JPEGs are entropy-decoded on host threads and inverse-DCT-ed /
+    # upsampled / colour-converted / cropped / resized / flipped / normalised on the GPU, bytes identical to Pillow's (other formats
+    # are decoded by Pillow per file and counted in the epoch log).  --host_decode: workers decode with Pillow, the GPU transforms.
+    # --host_transform: the reference's pipeline unchanged (Pillow decode + host transform in the workers).
+    p.add_argument('--host_transform', action='store_true', help='the reference\'s input pipeline: loader workers decode and transform with Pillow')
+    p.add_argument('--host_decode', action='store_true', help='loader workers decode with Pillow; crop / bicubic resize / flip / normalise on the GPU')
+    p.add_argument('--gpu_transform', action='store_true', help='(accepted for older command lines) same as --host_decode')
     p.add_argument('--dp_full_load', action='store_true',
                    help='data-parallel global-batch mode: every rank loads the WHOLE --bsz batch and slices its rows (the round-3 behaviour); '
                         'default: a rank-aware sampler loads only the rank\'s rows and their CutMix partners')
-    p.add_argument('--gpu_decode', action='store_true',
-                   help='implies --gpu_transform; loader workers only READ the image files: baseline JPEGs are entropy-decoded on host threads and '
-                        'dequantised / inverse-DCT-ed / upsampled / colour-converted on the GPU (bytes identical to Pillow), other files fall back to Pillow')
+    p.add_argument('--gpu_decode', action='store_true', help='(accepted for older command lines) the default pipeline')
     p.add_argument('--start_validation', type=int, default=0)
     p.add_argument('--lr_classifier', type=float, default=1e-4)
     p.add_argument('--lr_backbone', type=float, default=1e-6)

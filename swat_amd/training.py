@@ -220,8 +220,11 @@ def _train_loop(args, logger, loss_logger, model, classifier_head, train_loader,
         train_loss_avg = train_loss_sum / len(train_loader)
         loss_logger.write(f'{epoch},{num_iter},{round(train_loss_avg, 6)},{round(val_loss, 6)},{round(val_acc, 6)},{round(test_acc, 6)}\n')
         loss_logger.flush()
+        from . import jpeg as _jpeg   # (the default input pipeline decodes on host threads + the GPU: say what went where)
+        dec = (f", decoded on the GPU path: {_jpeg.stats['device']}, by Pillow (other formats): {_jpeg.stats['host_other_format']}"
+               if _jpeg.stats['device'] or _jpeg.stats['host_other_format'] else "")
         logger.info(f"Epoch {int(epoch)}, Iter {num_iter}, Trn Loss: {round(train_loss_avg, 6)}, Val Loss: {round(val_loss, 6)}, "
-                    f"Val Acc: {round(val_acc, 3)}, Test Acc: {round(test_acc, 3)}")
+                    f"Val Acc: {round(val_acc, 3)}, Test Acc: {round(test_acc, 3)}{dec}")
         if logger.handlers:
             logger.handlers[0].flush()
 
@@ -307,8 +310,11 @@ def train_probing(args, logger, loss_logger, model, classifier_head, tokenized_t
         train_loss_avg = train_loss_sum / len(train_loader)
         loss_logger.write(f'{epoch},{num_iter},{round(train_loss_avg, 6)},{round(val_loss, 6)},{round(val_acc, 6)},{round(test_acc, 6)}\n')
         loss_logger.flush()
+        from . import jpeg as _jpeg   # (the default input pipeline decodes on host threads + the GPU: say what went where)
+        dec = (f", decoded on the GPU path: {_jpeg.stats['device']}, by Pillow (other formats): {_jpeg.stats['host_other_format']}"
+               if _jpeg.stats['device'] or _jpeg.stats['host_other_format'] else "")
         logger.info(f"Epoch {int(epoch)}, Iter {num_iter}, Trn Loss: {round(train_loss_avg, 6)}, Val Loss: {round(val_loss, 6)}, "
-                    f"Val Acc: {round(val_acc, 3)}, Test Acc: {round(test_acc, 3)}")
+                    f"Val Acc: {round(val_acc, 3)}, Test Acc: {round(test_acc, 3)}{dec}")
         if args.save_ckpt and (num_iter % args.save_freq == 0 or epoch == args.epochs):
             save_model_ckpt(args, best_records, model, classifier_head, optimizer, scheduler, logit_scale, val_acc, epoch, num_iter)
     logger.info('Probing done.')

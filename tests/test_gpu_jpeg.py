@@ -99,11 +99,11 @@ def test_loader_with_gpu_decode_matches_host_loader(tmp_path):
         lines.append(f"{name} {i % 3} {i % 2}\n")
     (tmp_path / "split.txt").write_text("".join(lines))
     split = [["split.txt"], [str(tmp_path)]]
-    args = SimpleNamespace(dataset_root=str(tmp_path), bsz=4, num_workers=0, device="cuda:0", gpu_transform=False, gpu_decode=False)
+    args = SimpleNamespace(dataset_root=str(tmp_path), bsz=4, num_workers=0, device="cuda:0", host_transform=True)
     val_tf = T.build_transform(224, "val")
     torch.manual_seed(3)
     want = [list(l) for l in dl.get_dataloader(args, split, split, split, None, val_tf)]
-    args.gpu_decode = True
+    args.host_transform = False   # the default pipeline: workers read files, decode + transform on host threads / the GPU
     torch.manual_seed(3)
     loaders = dl.get_dataloader(args, split, split, split, None, val_tf)
     assert all(isinstance(l, dl.DeviceTransformLoader) and l.decode for l in loaders)

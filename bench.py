@@ -632,7 +632,8 @@ def decode_secondary(dev, bsz=32, h=375, w=500, steps=20, with_cpu=True):
                                   "train transform", "host_threads": threads},
            "ms_per_pass": round(dt * 1e3, 3), "dtype": "u8/int16/int32", "decode_only_img_per_s": round(bsz / dt_dec, 1),
            "equals_pillow_decode": same}
-    rec["loader"] = loader_throughput(dev, files, bsz, w, h)
+    rec["loader"] = loader_throughput(dev, files, bsz, w, h)                      # --num_workers 8: the CLI's (and the reference's) default
+    rec["loader"]["gpu_pipeline_img_per_s_16_workers"] = loader_throughput(dev, files, bsz, w, h, workers=16, host_leg=False)["gpu_pipeline_img_per_s"]
     if with_cpu:
         host_tf = T.build_transform(224, "train")
         t0 = time.perf_counter()
@@ -654,7 +655,7 @@ def decode_secondary(dev, bsz=32, h=375, w=500, steps=20, with_cpu=True):
     return rec
 
 
-def loader_throughput(dev, files, bsz, w, h, n_files=4096, epochs=3, workers=8):
+def loader_throughput(dev, files, bsz, w, h, n_files=4096, epochs=3, workers=8, host_leg=True):
     """Files ON DISK -> normalised fp32 training batches, through the CLI's default loaders (swat_amd.dataloader.get_dataloader:
     DataLoader worker processes that only read the files, host-thread entropy decode, GPU inverse DCT / transform) at the training batch
     shape — the rate the input pipeline sustains with real file I/O, next to the reference's pipeline (--host_transform: the same
@@ -677,7 +678,7 @@ def loader_throughput(dev, files, bsz, w, h, n_files=4096, epochs=3, workers=8):
         split = [["split.txt"], [root]]
         small = [["split.txt"], [root]]
         out = {"files": n_files, "file_bytes": len(files[0]), "batch": bsz, "loader_workers": workers, "epochs_timed": epochs - 1}
-        for name, host in (("gpu_pipeline_img_per_s", False), ("host_pipeline_img_per_s", True)):
+        for name, host in (("gpu_pipeline_img_per_s", False), ("host_pipeline_img_per_s", True))[:2 if host_leg else 1]:
             if host:   # (the reference's pipeline runs at a few hundred images per second: a sixth of the files is sample enough)
                 with open(os.path.join(root, "split_host.txt"), "w") as f:
                     f.write("".join(lines[:n_files // 6]))

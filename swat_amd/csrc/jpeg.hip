@@ -456,6 +456,14 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegDesc* __restr
 
 // ---- per-process staging (pinned host + device), grown on demand -------------------------------------------------------------------
 struct JpegArena {
+    // the pinned staging buffer is DOUBLE: the entropy decode of batch i + 1 fills one half while the upload of batch i (queued on the
+    // stream, possibly behind a training step's kernels) still reads the other — with one buffer the host stood still until the
+    // GPU had reached that copy, and the loader could not run ahead of the step
+    void* hosts[2] = {nullptr, nullptr};
+    size_t hosts_bytes[2] = {0, 0};
+    hipEvent_t copies[2] = {nullptr, nullptr};
+    bool pendings[2] = {false, false};
+    int turn = 0;
     void* host = nullptr;
     void* dev = nullptr;
     void* planes = nullptr;
@@ -621,11 +629,15 @@ SWAT_API int swat_jpeg_decode_batch(const void* const* files, const int64_t* nby
     SWAT_HIP(hipGetDevice(&dev_i));
     SWAT_REQUIRE(dev_i >= 0 && dev_i < 16, "swat_jpeg_decode_batch: device %d out of range", dev_i);
     JpegArena& A = g_jpeg_dev[dev_i];
-    if (A.pending) {   // the previous batch's copy still reads the pinned buffer
+    const int hb = A.turn ^= 1;   // this call's half of the pinned staging
+    A.host = A.hosts[hb]; A.host_bytes = A.hosts_bytes[hb]; A.copied = A.copies[hb]; A.pending = A.pendings[hb];
+    if (A.pending) {   // the copy two calls ago still reads this half
         SWAT_HIP(hipEventSynchronize(A.copied));
         A.pending = false;
     }
-    SWAT_REQUIRE(grow(&A.host, &A.host_bytes, up_bytes, true) == 0 && grow(&A.dev, &A.dev_bytes, up_bytes, false) == 0 &&
+    const int grc = grow(&A.host, &A.host_bytes, up_bytes, true);
+    A.hosts[hb] = A.host; A.hosts_bytes[hb] = A.host_bytes; A.pendings[hb] = false;   // (whatever grow left: never a stale pointer)
+    SWAT_REQUIRE(grc == 0 && grow(&A.dev, &A.dev_bytes, up_bytes, false) == 0 &&
                      grow(&A.planes, &A.plane_bytes, plane_total + 64, false) == 0,
                  "swat_jpeg_decode_batch: cannot allocate %zu staging bytes", up_bytes);
     if (!A.copied) SWAT_HIP(hipEventCreateWithFlags(&A.copied, hipEventDisableTiming));
@@ -650,6 +662,7 @@ SWAT_API int swat_jpeg_decode_batch(const void* const* files, const int64_t* nby
     SWAT_HIP(hipMemcpyAsync(A.dev, A.host, up_bytes, hipMemcpyHostToDevice, s));
     SWAT_HIP(hipEventRecord(A.copied, s));
     A.pending = true;
+    A.hosts[hb] = A.host; A.hosts_bytes[hb] = A.host_bytes; A.copies[hb] = A.copied; A.pendings[hb] = true;
     const JpegDesc* ddesc = (const JpegDesc*)A.dev;
     const int16_t* dcoef = (const int16_t*)((char*)A.dev + desc_bytes);
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((max_blocks + 127) / 128), (unsigned)(3 * n)), dim3(128), 0, s, ddesc, dcoef,

@@ -166,10 +166,22 @@ class DeviceBatchTransform:
                 desc[b] = (w, h, x0, y0, in_w, in_h, out_w, out_h, off_x, off_y, flip, 0)
                 row_start[b + 1] = row_start[b] + in_h
                 ks = max(ks, _axis_ksize(in_w, out_w), _axis_ksize(in_h, out_h))
-            meta = torch.from_numpy(np.concatenate([offsets, row_start, desc.reshape(-1).view(np.int64)]))
+            meta = np.concatenate([offsets, row_start, desc.reshape(-1).view(np.int64)])
             lib, ptr = self._lib.lib(), self._lib.ptr
+            # (the descriptor upload comes from a pinned ring: a pageable source makes the copy synchronous with the stream — the host
+            # would stand still once per batch until the GPU has reached it)
+            if not hasattr(self, '_meta_pin'):
+                self._meta_pin, self._meta_ev, self._meta_i = [None] * 4, [None] * 4, 0
+            k = self._meta_i = (self._meta_i + 1) % 4
+            if self._meta_pin[k] is None or self._meta_pin[k].numel() < meta.size:
+                self._meta_pin[k] = torch.empty(max(4096, 2 * meta.size), dtype=torch.int64).pin_memory()
+            elif self._meta_ev[k] is not None:
+                self._meta_ev[k].synchronize()
+            self._meta_pin[k][:meta.size].copy_(torch.from_numpy(meta))
             with torch.cuda.stream(s):
-                m = meta.to(dev)   # (small: 8 (2 B + 1) + 48 B bytes)
+                m = self._meta_pin[k][:meta.size].to(dev, non_blocking=True)   # (small: 8 (2 B + 1) + 48 B bytes)
+                self._meta_ev[k] = torch.cuda.Event()
+                self._meta_ev[k].record(s)
                 need = lib.swat_preprocess_workspace_bytes(B, n, ks, int(row_start[-1]))
                 if self._ws is None or self._ws.numel() < need:
                     self._ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)

@@ -44,6 +44,14 @@ def vit_gflop_per_img(d, L, T, patch_cols, embed, mlp_ratio=4):
     return round(3 * fwd / 1e9 - 2 * (T - 1) * patch_cols * d / 1e9, 3)
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (the PMC summaries bench.py cites are collected per round by
+    tools/collect_profiles.sh and committed)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")))
+    return c[-1] if c else None
+
+
 class _Lg:
     handlers = []
 
@@ -109,10 +117,10 @@ def gemm_roofline(args, step, sched, images, labels, n_steps, bsz, overlap=1):
     per_kind = {names[i]: {"launches_per_step": cnt[i] / n_steps, "avg_us": (1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0,
                            "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0} for i in range(16) if cnt[i]}
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r04_gemm_pmc.json")
-    if os.path.exists(tpath):  # PMC passes cannot run inside this process: the committed rocprofv3 --pmc result of this command
+    tpath = _latest_profile("gemm_pmc.json")
+    if tpath:  # PMC passes cannot run inside this process: the committed rocprofv3 --pmc result of this command
         traffic = round(json.load(open(tpath))["hbm_bytes_per_gemm_launch"])
-        traffic_src = "profiles/r04_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes, mean bytes per timed launch)"
+        traffic_src = f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes, mean bytes per timed launch)"
     return {"bound": "mfma", "kernel": "vit_fwd_mega_kernel + vit_bwd_mega_kernel (all blocks' forward / data-gradient chain, one launch each) + gemm_xl_kernel "
                                        "(weight gradients) + gemm_pc_kernel / gemm_ring_kernel (stem, head)" if mega and mega_b else
                                        "vit_fwd_mega_kernel (all forward blocks, one launch) + gemm_pc_kernel / gemm_dma_kernel / gemm_ring2_kernel / "
@@ -317,10 +325,8 @@ def retrieval_secondary(dev, rank=0, world=1, d=512, steps=5, with_cpu=True):
 def _pmc_traffic(kernel, d=512, contains=None):
     """HBM bytes per launch of a retrieval kernel from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh;
     counters cannot be collected inside this process).  None when the profile is absent or was taken at another d."""
-    p = os.path.join(ROOT, "profiles", "r04_retrieval_pmc.json")
-    if not os.path.exists(p):
-        p = os.path.join(ROOT, "profiles", "r02_retrieval_pmc.json")
-    if not os.path.exists(p) or d != 512:
+    p = _latest_profile("retrieval_pmc.json")
+    if not p or d != 512:
         return None
     recs = [v for n, v in json.load(open(p)).items() if n.startswith(kernel) and isinstance(v, dict) and (contains is None or contains in n)]
     return round(max(r["hbm_bytes_per_launch"] for r in recs)) if recs else None  # the shard scan is the largest launch of its kernel

@@ -10,13 +10,15 @@ ROOT=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-secondary"
 O=$ROOT/gpurun_out
-rm -rf $O/${TAG}_prof_stats $O/${TAG}_prof_stats0 $O/${TAG}_pmc_sq $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write
+rm -rf $O/${TAG}_prof_stats $O/${TAG}_prof_stats0 $O/${TAG}_pmc_sq $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_tcc
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_stats -- $BENCH --steps 20 --warmup 5 > $O/${TAG}_prof_stats.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_stats0 -- $BENCH --steps 20 --warmup 5 --overlap 0 > $O/${TAG}_prof_stats0.json 2> /dev/null
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT \
     --output-format csv -d $O/${TAG}_pmc_sq -- $BENCH --steps 4 --warmup 2 --overlap 0 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- $BENCH --steps 4 --warmup 2 --overlap 0 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- $BENCH --steps 4 --warmup 2 --overlap 0 > /dev/null 2>&1
+# L2 (TCC) hits / misses of the same kernels in a pass of their own (round-4 verdict: where does the persistent kernels' fetch come from)
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/${TAG}_pmc_tcc -- $BENCH --steps 4 --warmup 2 --overlap 0 > /dev/null 2>&1
 python3 - <<PY
 import csv, glob, json, collections
 O, TAG = "$O", "$TAG"
@@ -28,7 +30,7 @@ def load(d):
                 k = r["Kernel_Name"].split("(")[0].replace("void swat::", "")
                 res[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return res
-sq, fe, wr = load("pmc_sq"), load("pmc_fetch"), load("pmc_write")
+sq, fe, wr, tc = load("pmc_sq"), load("pmc_fetch"), load("pmc_write"), load("pmc_tcc")
 out = {"source": "rocprofv3 --pmc (three separate passes: 8 SQ counters; FETCH_SIZE; WRITE_SIZE) over 'bench.py --steps 4 --warmup 2 --overlap 0 "
                  "--no-cpu-baseline --no-secondary' (kernels run alone, one stream); means per launch of every GEMM instantiation and of the persistent forward (vit_fwd_mega_kernel: all twelve blocks in one launch)",
        "reading": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32 (the counter sums "
@@ -51,6 +53,10 @@ for k in sorted(sq):
         v = fe[k]["FETCH_SIZE"]; e["hbm_fetch_bytes"] = 2 * 1024 * sum(v) / len(v); tot_f += 2 * 1024 * sum(v); n_f += len(v)
     if k in wr:
         v = wr[k]["WRITE_SIZE"]; e["hbm_write_bytes"] = 1024 * sum(v) / len(v); tot_w += 1024 * sum(v); n_w += len(v)
+    if k in tc and "TCC_HIT_sum" in tc[k] and "TCC_MISS_sum" in tc[k]:
+        h, m = tc[k]["TCC_HIT_sum"], tc[k]["TCC_MISS_sum"]
+        e["l2_hits"] = sum(h) / len(h); e["l2_misses"] = sum(m) / len(m)
+        e["l2_hit_rate"] = sum(h) / max(1.0, sum(h) + sum(m))
     out["kernels"][k] = e
 if n_f and n_w:
     out["hbm_bytes_per_gemm_launch"] = tot_f / n_f + tot_w / n_w

@@ -96,6 +96,34 @@ __global__ __launch_bounds__(256) void cls_ln_proj_kernel(const float* __restric
     }
 }
 
+// d u = d feats @ proj^T for the B class rows (the first launch of the backward's chain; round 4: a k-ordered small product that stages
+// 82 KB per workgroup and runs a 512-deep dependent chain per output, 12 us).  Workgroup (j, b): columns 64 j .. + 63 of row b, a WAVE
+// per column: the lanes split the E features (V float4 each, all of a wave's 16 columns loaded up front), one fma chain per lane and a
+// fixed xor tree across the lanes — deterministic.  E = 256 V.
+template <int V>
+__global__ __launch_bounds__(256) void du_rows_kernel(const float* __restrict__ df, const float* __restrict__ proj, float* __restrict__ du, int d, int E) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, c0 = blockIdx.x * 64 + wave * 16;
+    float4 f[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) f[v] = reinterpret_cast<const float4*>(df + (int64_t)b * E)[lane + 64 * v];
+    float4 w[16][V];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int v = 0; v < V; ++v) w[i][v] = reinterpret_cast<const float4*>(proj + (int64_t)(c0 + i < d ? c0 + i : d - 1) * E)[lane + 64 * v];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            a = fmaf(f[v].x, w[i][v].x, a); a = fmaf(f[v].y, w[i][v].y, a); a = fmaf(f[v].z, w[i][v].z, a); a = fmaf(f[v].w, w[i][v].w, a);
+        }
+        a = wave_sum(a);
+        if (lane == 0 && c0 + i < d) du[(int64_t)b * d + c0 + i] = a;
+    }
+}
+
 struct VitDims {
     int B, img, patch, d, L, H, mlp, E, act, save;
     int g, T, M, Kp, ldk, dh, ldp;
@@ -843,7 +871,13 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             } else {
                 TRY(swat_sgemm_small(w.u, dfeats, grads + O.proj, d, D.E, D.B, 1, d, D.E, 1, D.E, 1.0f, 0, s));
             }
-            TRY(swat_sgemm_small(dfeats, params + O.proj, w.du, D.B, d, D.E, D.E, 1, 1, D.E, d, 1.0f, 0, s));
+            if (D.E == 512 || D.E == 768) {
+                if (D.E == 512) hipLaunchKernelGGL(du_rows_kernel<2>, dim3((d + 63) / 64, D.B), dim3(256), 0, s, dfeats, params + O.proj, w.du, d, D.E);
+                else hipLaunchKernelGGL(du_rows_kernel<3>, dim3((d + 63) / 64, D.B), dim3(256), 0, s, dfeats, params + O.proj, w.du, d, D.E);
+                TRY(check_launch("du_rows_kernel"));
+            } else {
+                TRY(swat_sgemm_small(dfeats, params + O.proj, w.du, D.B, d, D.E, D.E, 1, 1, D.E, d, 1.0f, 0, s));
+            }
             wait_lane(doneA);
             wait_lane(blk[0]);
             wait_lane(blk[1]);

@@ -528,7 +528,10 @@ def retrieval_dense_secondary(dev, rank=0, world=1, steps=5, with_cpu=True):
                                             "warm_pass_frac": round(survey_bytes / 1e9 / dt / HBM_PEAK_GBS, 4),
                                             "note": "SURVEY 8(d) prices a pass at 4 d bytes per row (the fp32 matrix) whatever the route reads; with "
                                                     "the bf16 scan image this is a rate in fp32-row equivalents, not the HBM efficiency of a kernel"},
-                        "mfma": {"achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}}}
+                        "mfma": {"achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                                 "note": "at 200 queries the scan is co-limited: per 64-deep step a CU issues 416 MFMAs (1 664 cycles per SIMD) and reads "
+                                         "208 KB of query fragments from LDS (1 625 cycles), each as long as the step's HBM stream; measured 0.24 ms for one "
+                                         "query tile + 0.0095 ms per further tile (csrc/retrieval_bf16.hip header, round-5 A/B runs)"}}}
     if dt_f32 is not None:
         rec["fp32_scan"] = {"ms_per_pass": round(dt_f32 * 1e3, 3), "queries_per_s": round(nq / dt_f32, 1),
                             "pass_frac": round((n * d * 4 + rescore_bytes) / 1e9 / dt_f32 / HBM_PEAK_GBS, 4),

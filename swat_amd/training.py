@@ -81,7 +81,6 @@ class _PinnedRing:
         ev = self.ev.pop(key, None)
         if ev is not None:
             ev.synchronize()
-        self.last = key
         return self.buf[key]
 
     def uploaded(self, t):

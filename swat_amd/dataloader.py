@@ -6,6 +6,7 @@ ref: MyDataset dataset_utils.py:130-180 (list files `relpath label source`), Ten
 """
 import os
 
+import numpy as np
 import torch
 from torch.utils.data import DataLoader, Dataset
 
@@ -129,10 +130,14 @@ def _file_collate(samples):
     # shared memory, a list of numpy arrays would be pickled through its pipe — 3 MB per 32-image batch, which bounded the loader
     # at ~6 k img/s against the 22 k img/s the decode behind it sustains (bench.py: loader leg)
     blob = torch.cat([s[0][0] for s in samples])
-    lens = torch.tensor([s[0][0].numel() for s in samples], dtype=torch.int64)
+    lens = [int(s[0][0].numel()) for s in samples]
     geo = [tuple(int(v) for v in s[0][1]) for s in samples]
     sizes = [(int(s[0][2][0]), int(s[0][2][1])) if int(s[0][2][2]) else None for s in samples]
-    return (blob, lens, geo, sizes), *default_collate([tuple(s[1:]) for s in samples])
+    # ... and the blob is the ONLY tensor that crosses: every tensor of a batch costs the main process a file-descriptor hand-over
+    # from the worker (~0.5 ms each, serial in the main process, whatever the number of workers); labels / prompt tokens / sources go
+    # as numpy arrays inside the pickle and become the tensors default_collate would have made on the other side (_file_uncollate)
+    rest = tuple(t.numpy() if isinstance(t, torch.Tensor) else t for t in default_collate([tuple(s[1:]) for s in samples]))
+    return (blob, lens, geo, sizes), rest
 
 
 class DeviceTransformLoader:
@@ -146,6 +151,9 @@ class DeviceTransformLoader:
         self.loader = DataLoader(dataset, collate_fn=_file_collate if decode else _raw_collate, **loader_kw)
         self.dataset, self.batch_size, self.batch_sampler = dataset, self.loader.batch_size, self.loader.batch_sampler
         self.tf = DeviceBatchTransform(n_px, mode, device)
+        # host threads of the entropy decode (one file per thread at a time): a thread per image of a 32-image batch where the host has
+        # the cores beside the loader's worker processes (the library's own default is one per two files)
+        self.threads = max(1, min(32, (os.cpu_count() or 8) - int(loader_kw.get('num_workers', 0) or 0)))
 
     def __len__(self):
         return len(self.loader)
@@ -165,12 +173,16 @@ class DeviceTransformLoader:
         def produce():
             try:
                 with torch.cuda.device(dev):
-                    for (blob, lens, geo, sizes), *rest in self.loader:
+                    for (blob, lens, geo, sizes), rest in self.loader:
                         if stop.is_set():
                             return
-                        a, ends = blob.numpy(), lens.cumsum(0).tolist()
-                        files = [a[e - n:e] for e, n in zip(ends, lens.tolist())]
-                        out = self.tf.from_jpeg(files, geometry=geo, sizes=sizes, stream=side)
+                        rest = [torch.from_numpy(t) if isinstance(t, np.ndarray) else t for t in rest]
+                        a, e = blob.numpy(), 0
+                        files = []
+                        for n in lens:
+                            files.append(a[e:e + n])
+                            e += n
+                        out = self.tf.from_jpeg(files, geometry=geo, sizes=sizes, stream=side, threads=self.threads)
                         ev = torch.cuda.Event()
                         ev.record(side)
                         q.put((out, ev, rest))

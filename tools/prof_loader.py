@@ -35,8 +35,9 @@ for ep in range(2):
         except StopIteration:
             break
         t1 = time.perf_counter()
-        a, ends = blob.numpy(), lens.cumsum(0).tolist()
-        files = [a[e - k:e] for e, k in zip(ends, lens.tolist())]
+        a, e, files = blob.numpy(), 0, []
+        for k in lens:
+            files.append(a[e:e + k]); e += k
         t2 = time.perf_counter()
         pixels, offsets, shapes = jpeg.decode_batch(files, dev, sizes=sizes, threads=0)
         t3 = time.perf_counter()

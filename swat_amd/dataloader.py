@@ -66,15 +66,18 @@ class MinedDataset(Dataset):
         self.n_total = len(self.fnames)
         self.fnames = self.fnames[rank::world]
         self.caption_map, self.transform, self.loader = caption_map, transform, loader
+        self.captions_only = False
 
     def __len__(self):
         return len(self.fnames)
 
     def __getitem__(self, i):
         f = self.fnames[i]
-        img = self.loader(str(f))
         label = int(f.parent.name)
         img_id = f.name.split('.')[0]
+        if self.captions_only:   # the caption pass of the extraction needs no pixels (the reference decodes them anyway, :113-125)
+            return 0, label, str(f), self.caption_map[str(label)][img_id] if self.caption_map is not None else ''
+        img = self.loader(str(f))
         if self.transform is not None:
             img = self.transform(img)
         if self.caption_map is not None:

@@ -62,7 +62,8 @@ def extract_mined_feats_batch(model, dataloader, tokenizer, save_dir=None, batch
     -> {'caption_features' [N,E], 'labels' [N], 'filepath' list[N], 'image_features' [N,E]} (CPU tensors), loader order."""
     model.eval()
     cap_feats, labels_lst, paths = [], [], []
-    for imgs, labels, file_path, captions in dataloader:            # pass 1: captions
+    # pass 1: captions.  `caption_loader` (pre_extract_mined_fea): the same files in the same order without reading a pixel
+    for imgs, labels, file_path, captions in getattr(dataloader, 'caption_loader', dataloader):
         tok = tokenizer(list(captions)).to(device)
         cap_feats.append(l2_normalize(model.encode_text(tok)))
         labels_lst.append(labels.long())
@@ -137,7 +138,23 @@ def pre_extract_mined_fea(args, dataset_name, dataset_root, caption_path, model_
         fnames = box[0]
     dataset = MinedDataset(dataset_root=dataset_root, transform=preprocess, caption_map=caption_map, rank=rank, world=world,
                            fnames=fnames)
-    loader = DataLoader(dataset, batch_size=args.bsz, shuffle=False, num_workers=args.num_workers, drop_last=False, pin_memory=True)
+    dev_tf = getattr(preprocess, 'swat_transform', None)
+    if dev_tf is not None and not getattr(args, 'host_transform', False) and torch.cuda.is_available():
+        # the default input pipeline (swat_amd/dataloader.py): workers only READ the files; baseline JPEGs are entropy-decoded on host
+        # threads and decoded / resized / cropped / normalised on the GPU, bytes identical to what `preprocess` computes with Pillow —
+        # the decode in 16 PIL workers is where the reference's extraction spends its time; the caption pass
+        # reads no image at all
+        import copy
+        from ..dataloader import DeviceTransformLoader
+        from ..transforms import ReadOnly
+        dataset.loader, dataset.transform = ReadOnly.load, ReadOnly(dev_tf[0], dev_tf[1])
+        loader = DeviceTransformLoader(dataset, dev_tf[0], dev_tf[1], torch.device('cuda', torch.cuda.current_device()), decode=True,
+                                       batch_size=args.bsz, shuffle=False, num_workers=args.num_workers, drop_last=False)
+        cap_ds = copy.copy(dataset)
+        cap_ds.captions_only = True
+        loader.caption_loader = DataLoader(cap_ds, batch_size=args.bsz, shuffle=False, num_workers=0, drop_last=False)
+    else:
+        loader = DataLoader(dataset, batch_size=args.bsz, shuffle=False, num_workers=args.num_workers, drop_last=False, pin_memory=True)
     part = extract_mined_feats_batch(model, loader, tokenizer, save_dir=f'{args.root}/{dataset_name}/temp')
     if world > 1:
         part = gather_rank_parts(part, dataset.n_total, rank, world)
@@ -162,6 +179,7 @@ def main(argv=None):
     parser.add_argument('--bsz', type=int, default=1024, help='Batch size.')
     parser.add_argument('--num_workers', type=int, default=16, help='Number of workers for dataloader.')
     parser.add_argument('--dist_backend', type=str, default='nccl', choices=['nccl', 'gloo'])
+    parser.add_argument('--host_transform', action='store_true', help="the reference's input pipeline: loader workers decode and transform with Pillow")
     args = parser.parse_args(argv)
     from .. import dp
     dp.init_from_env(args, split_batch=False)  # before anything touches the GPU; --bsz is per rank here (nothing is split)

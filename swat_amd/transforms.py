@@ -59,7 +59,9 @@ def build_transform(n_px, mode='train'):
         left, top = int(round((nw - n_px) / 2.0)), int(round((nh - n_px) / 2.0))
         return _to_tensor_normalize(img.crop((left, top, left + n_px, top + n_px)))
 
-    return train if mode == 'train' else val
+    fn = train if mode == 'train' else val
+    fn.swat_transform = (n_px, mode)   # (lets a loader swap this host transform for its device form: DeviceTransformLoader)
+    return fn
 
 
 def _axis_ksize(in_size, out_size):

@@ -674,7 +674,17 @@ def test_extract_mined_features_matches_oracle_and_round_trips_mined_pth(tmp_pat
     model.to("cuda")
     preprocess = build_transform(64, "val")
     args = types.SimpleNamespace(root=str(tmp_path / "retrieved"), bsz=4, num_workers=0)
+    from swat_amd import jpeg
+    n_dev0 = jpeg.stats["device"]
     got = ex.pre_extract_mined_fea(args, "toy", str(root), str(cap_path), "tinycfg", model, preprocess, tokenizer)
+    # the default input pipeline: the workers read files, the 15 baseline JPEGs are decoded and transformed on host threads + the GPU —
+    # and the dict is the one the reference-shaped pipeline (Pillow decode + host transform in the workers) produces, bit for bit
+    assert jpeg.stats["device"] - n_dev0 == 15
+    args.host_transform = True
+    host = ex.pre_extract_mined_fea(args, "toy", str(root), str(cap_path), "tinycfg", model, preprocess, tokenizer)
+    assert jpeg.stats["device"] - n_dev0 == 15
+    assert host["filepath"] == got["filepath"] and all(torch.equal(host[k], got[k]) for k in ("caption_features", "labels", "image_features"))
+    args.host_transform = False
     fn = tmp_path / "retrieved" / "toy" / "toy_tinycfg_mined.pth"
     disk = torch.load(fn, weights_only=False)
     assert set(disk) == {"caption_features", "labels", "filepath", "image_features"}

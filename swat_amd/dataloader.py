@@ -175,11 +175,15 @@ class DeviceTransformLoader:
         q = queue.Queue(maxsize=2)
         side = self._side = getattr(self, '_side', None) or torch.cuda.Stream(device=dev)
         stop = threading.Event()
+        # the DataLoader's iterator is created HERE, in the consumer's thread, at the moment the reference's loop creates its own: it
+        # draws the worker base seed and the shuffle seed from torch's GLOBAL generator — drawn from the producer
+        # thread they would race with the loop's own draws (the CutMix permutation)
+        it = iter(self.loader)
 
         def produce():
             try:
                 with torch.cuda.device(dev):
-                    for (blob, lens, geo, sizes), rest in self.loader:
+                    for (blob, lens, geo, sizes), rest in it:
                         if stop.is_set():
                             return
                         rest = [torch.from_numpy(t) if isinstance(t, np.ndarray) else t for t in rest]
@@ -220,8 +224,19 @@ class DeviceTransformLoader:
             t.join()
 
     def __iter__(self):
-        if self.decode:
+        if self.decode and self.loader.num_workers > 0:
             yield from self._decoded_batches()
+            return
+        if self.decode:
+            # no worker processes: the dataset code (file read, geometry draws from torch's global generator) runs in whichever thread
+            # pulls the batches — it must be the caller's, in the caller's order
+            for (blob, lens, geo, sizes), rest in self.loader:
+                a, e, files = blob.numpy(), 0, []
+                for n in lens:
+                    files.append(a[e:e + n])
+                    e += n
+                yield (self.tf.from_jpeg(files, geometry=geo, sizes=sizes, threads=self.threads),
+                       *(torch.from_numpy(t) if isinstance(t, np.ndarray) else t for t in rest))
             return
         for (blob, shapes, geo), rest in self.loader:
             a, e, imgs = blob.numpy(), 0, []
@@ -283,6 +298,22 @@ def get_dataloader(args, train_split, val_split, test_split, tokenized_text_prom
     return train_loader, val_loader, test_loader
 
 
+def image_loader(args, ds, mode, n_px=224, **loader_kw):
+    """A loader over an image-folder dataset `ds` (MyDataset / MinedDataset built with the host transform of `mode`) in the input
+    pipeline the arguments select (input_pipeline): the default hands the files to DeviceTransformLoader (workers read, host-thread
+    entropy decode, GPU decode + transform — bytes identical to the host transform, same random draws in the same order),
+    --host_decode keeps the Pillow decode in the workers, --host_transform is the reference's DataLoader unchanged."""
+    pipe = input_pipeline(args)
+    if pipe == 'host' or isinstance(ds, SyntheticImages) or not torch.cuda.is_available():
+        return DataLoader(ds, **loader_kw)
+    if pipe == 'gpu_decode':
+        ds.loader, ds.transform = ReadOnly.load, ReadOnly(n_px, mode)
+    else:
+        ds.transform = DecodeOnly(n_px, mode)
+    loader_kw.pop('pin_memory', None)
+    return DeviceTransformLoader(ds, n_px, mode, getattr(args, 'device', 'cuda'), decode=pipe == 'gpu_decode', **loader_kw)
+
+
 def _dataset_for(args, split, preprocess, tokenized_text_prompts, seed):
     if getattr(args, 'synthetic', 0):
         return SyntheticImages(max(64, args.synthetic // 4), args.num_classes, seed=seed)
@@ -292,7 +323,7 @@ def _dataset_for(args, split, preprocess, tokenized_text_prompts, seed):
 def extract_dataloader(args, model, split, fea_path, preprocess, tokenized_text_prompts, bsz=128, seed=2):
     """ref :11-31 — encode the split once with `model`, cache to fea_path, serve the features (bsz 128, no shuffle)."""
     ds = _dataset_for(args, split, preprocess, tokenized_text_prompts, seed)
-    feats = extract_test_feats(model, DataLoader(ds, batch_size=128, shuffle=False, num_workers=args.num_workers))
+    feats = extract_test_feats(model, image_loader(args, ds, 'val', batch_size=128, shuffle=False, num_workers=args.num_workers))
     os.makedirs(os.path.dirname(fea_path) or '.', exist_ok=True)
     torch.save(feats, fea_path)
     return DataLoader(TensorDataset(data=feats), batch_size=bsz, shuffle=False, drop_last=False, num_workers=0)
@@ -306,8 +337,8 @@ def extract_train_dataloader(args, model, split, fea_path, preprocess, tokenized
         ds = load_dataset(args.dataset_root, split, build_transform(224, 'train'), tokenized_text_prompts)
     # like the reference: shuffled batches of bsz with the tail batch dropped BEFORE the features are cached (the stage-2
     # probing set is len // bsz * bsz samples, and the shuffle draws from the global torch RNG at this point)
-    feats = extract_test_feats(model, DataLoader(ds, batch_size=bsz, pin_memory=True, shuffle=True, num_workers=args.num_workers,
-                                                 drop_last=True))
+    feats = extract_test_feats(model, image_loader(args, ds, 'train', batch_size=bsz, pin_memory=True, shuffle=True,
+                                                   num_workers=args.num_workers, drop_last=True))
     os.makedirs(os.path.dirname(fea_path) or '.', exist_ok=True)
     torch.save(feats, fea_path)
     return DataLoader(TensorDataset(data=feats), batch_size=bsz, shuffle=True, drop_last=True, num_workers=0)

@@ -115,3 +115,27 @@ def test_loader_with_gpu_decode_matches_host_loader(tmp_path):
             assert all(torch.equal(a, b) for a, b in zip(bg[1:], bw[1:]))
     args.num_workers = 2
     assert all(torch.equal(a[0].cpu(), b[0]) for a, b in zip(dl.get_dataloader(args, split, split, split, None, val_tf)[1], want[1]))
+    # the training loop's host RNG order with worker processes and the decode running one batch AHEAD on a producer
+    # thread: per epoch the loader's iterator draws its seeds from torch's global generator when the loop creates it, per iteration
+    # the loop draws the CutMix scalars and permutation — shuffled batches, pixels and draws must be those of the reference-shaped
+    # loader, two epochs from the same seeds (a DataLoader iterator created on the producer thread would race with the loop's draws)
+    import types
+    from swat_amd import training
+    cm = types.SimpleNamespace(cutmix_beta=1.0, mix_prob=0.5)
+
+    def run(host):
+        args.host_transform = host
+        torch.manual_seed(9)
+        np.random.seed(9)
+        tl = dl.get_dataloader(args, split, split, split, None, val_tf)[0]
+        out = []
+        for epoch in range(2):
+            for x, y, tok, src in tl:
+                lam, perm, box = training.cutmix_draw(cm, x.shape)
+                out.append((x.cpu(), y.clone(), lam, None if perm is None else perm.clone(), box))
+        return out
+    a, b = run(True), run(False)
+    assert len(a) == len(b) == 2 * (12 // 4)
+    for (xa, ya, la, pa, ba), (xb, yb, lb, pb, bb) in zip(a, b):
+        assert torch.equal(xa, xb) and torch.equal(ya, yb) and la == lb and ba == bb and (pa is None) == (pb is None)
+        assert pa is None or torch.equal(pa, pb)

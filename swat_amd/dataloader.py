@@ -306,6 +306,7 @@ def image_loader(args, ds, mode, n_px=224, **loader_kw):
     pipe = input_pipeline(args)
     if pipe == 'host' or isinstance(ds, SyntheticImages) or not torch.cuda.is_available():
         return DataLoader(ds, **loader_kw)
+    n_px, mode = getattr(getattr(ds, 'transform', None), 'swat_transform', (n_px, mode))   # (the host transform says what it computes)
     if pipe == 'gpu_decode':
         ds.loader, ds.transform = ReadOnly.load, ReadOnly(n_px, mode)
     else:

@@ -139,3 +139,34 @@ def test_loader_with_gpu_decode_matches_host_loader(tmp_path):
     for (xa, ya, la, pa, ba), (xb, yb, lb, pb, bb) in zip(a, b):
         assert torch.equal(xa, xb) and torch.equal(ya, yb) and la == lb and ba == bb and (pa is None) == (pb is None)
         assert pa is None or torch.equal(pa, pb)
+
+
+def test_stage_two_feature_extraction_takes_the_default_pipeline_and_equals_the_host_pipeline(tmp_path):
+    """extract_dataloader / extract_train_dataloader (ref utils/dataloader.py:11-31,278-296: the cached features stage 2 probes on): with
+    the default input pipeline the features are those of the reference-shaped loaders (Pillow in the workers), bit for bit (the training form's RNG order
+    is covered by test_loader_with_gpu_decode_matches_host_loader)."""
+    from types import SimpleNamespace
+    from swat_amd import dataloader as dl, jpeg, transforms as T
+    from swat_amd.clip_model import CLIP
+    rng = np.random.default_rng(4)
+    os.makedirs(tmp_path / "img")
+    lines = []
+    for i in range(10):
+        h, w = int(rng.integers(70, 160)), int(rng.integers(70, 160))
+        Image.fromarray(synth(rng, h, w)).save(tmp_path / f"img/{i}.jpg", "JPEG", quality=88, subsampling=int(rng.integers(0, 3)))
+        lines.append(f"img/{i}.jpg {i % 3} 1\n")
+    (tmp_path / "split.txt").write_text("".join(lines))
+    split = [["split.txt"], [str(tmp_path)]]
+    torch.manual_seed(1)
+    model = CLIP(vision_cfg=(64, 16, 128, 2, 2, 64, "quick_gelu"), text_cfg=(8, 64, 64, 1, 1)).to("cuda:0").eval()
+    pre = T.build_transform(64, "val")
+
+    def run(host):
+        args = SimpleNamespace(dataset_root=str(tmp_path), num_workers=2, device="cuda:0", host_transform=host)
+        torch.manual_seed(5)
+        n0 = jpeg.stats["device"]
+        val = dl.extract_dataloader(args, model, split, str(tmp_path / f"val{int(host)}.pth"), pre, None)
+        return torch.load(tmp_path / f"val{int(host)}.pth", weights_only=False), jpeg.stats["device"] - n0, len(val)
+    (fh, nh, lh), (fg, ng, lg) = run(True), run(False)
+    assert nh == 0 and ng == 10 and lh == lg
+    assert torch.equal(fh["image_features"], fg["image_features"]) and torch.equal(fh["labels"], fg["labels"])

@@ -129,7 +129,8 @@ int swat_sim_candidates_packed(const void* packed, int n_q, const float* db, int
 /*     The same pass over a bf16 SHADOW of the shard, built once per index (the reference keeps the fp32 matrix of mined.pth in
  *     memory for every class query, retrieval/sample_retrieval.py:1387-1415; this is its scan-side image): rows rounded to bf16
  *     once and stored in the scan's order — for d % 256 == 0 tiled: blocks of 256 rows, inside a block one 64-deep k-step of
- *     all its rows is contiguous (32 KB), rows padded with zeros to whole blocks; swat_dense_shadow_bytes(n_db, d) = 2 d x
+ *     all its rows is contiguous (32 KB, in the order the scan's lanes load it: 1 KiB per 16-row fragment and 32-deep half),
+ *     rows padded with zeros to whole blocks; swat_dense_shadow_bytes(n_db, d) = 2 d x
  *     n_db rounded up to 256 (d % 256 == 0) or 2 n_db d (other multiples of 128); 0: d not supported.
  *     swat_dense_build_shadow also leaves max |row|^2 of the fp32 rows in *max_norm2 (zero it first).  The candidate lists are
  *     those of swat_sim_candidates_packed bit for bit (same roundings, same order of accumulation) from half the HBM bytes;

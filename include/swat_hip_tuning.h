@@ -71,11 +71,19 @@ int swat_vit_mega_backward_launches(void);
 int swat_vit_backward_blocks_fused(const int32_t* dims);
 int swat_vit_mega_backward_trace(void* device_buffer);
 
-/* Candidate epilogue of the dense top-k's shadow scan (csrc/retrieval_bf16.hip, A/B runs): 0 = round 4's (LDS threshold + max chain +
- *     vector branch per group, records stored to the staging slot at once), 2 = thresholds read once per block, four compares per
- *     group into scalar masks, records kept in a per-wave LDS buffer until the scan is over (default; env SWAT_DENSE_EPI).  Same
- *     record set; measured equal within 2 % (the scan is bound by the matrix pipe and the LDS read port, see the kernel's header). */
+/* Candidate epilogue of the dense top-k's shadow scan (csrc/retrieval_bf16.hip, A/B runs).  Both forms read the lane's thresholds once
+ *     per block and keep the records in a per-wave LDS buffer until the scan is over; they differ in how a hit becomes a record:
+ *     2 = a group of 4 x 64 scores is four compares into scalar masks, a group with a hit runs vector code under exec masks per row;
+ *     3 = a group is one max + compare, a group with a hit parks its hit lanes (four scores + a tag) in LDS and one rolled loop
+ *     after the groups converts them (default; env SWAT_DENSE_EPI).  Same set of records; the order inside a group differs. */
 int swat_dense_set_epilogue(int form);
+/*     where a step of that scan issues its row loads: 1 = one between every few MFMAs of the step (default), 0 = all at the step's
+ *     start (measured 2 % slower; env SWAT_DENSE_SPREAD).  Same records. */
+int swat_dense_set_spread(int on);
+/*     with env SWAT_DENSE_PROF=1 the scan runs its cycle-accounting build; this copies the last launch's per-wave sums of shader
+ *     cycles to host_out[256 workgroups][8 waves][5] = {counted wait, barrier, MFMA phase, candidate epilogue, whole kernel}
+ *     (device synchronised first).  tools/prof_dense_waves.py. */
+int swat_dense_debug_profile(unsigned long long* host_out);
 
 /* swat_adamw's launch shape: 0 = wide (up to 4096 blocks, the fastest alone), n > 0 = n blocks of 256 threads handling four
  *     16-byte quads per array and trip (n = 256: one block per CU, 4 of its 32 wave slots) so that GEMM workgroups on another

@@ -347,8 +347,9 @@ def test_dense_cache_is_keyed_on_tensor_identity_not_on_addresses():
 
 def test_packed_query_image_layout():
     """swat_dense_pack_queries: per (32-deep chunk, 16-query tile) a 1 KiB block whose 16-B unit L holds query 16T + L/4,
-    k-slot s = (L % 4) ^ ((L / 16) % 4) = k 32c + 4s .. +3 and 32c + 16 + 4s .. +3 (the order in which the scan reads a
-    database row), rounded to bf16 (RNE); rows >= n_q and the 13 slack tiles are zero."""
+    k-slot s = (L % 4) ^ (3 * ((L / 32) % 2)) = k 32c + 4s .. +3 and 32c + 16 + 4s .. +3 (the order in which the scan reads a
+    database row), rounded to bf16 (RNE); rows >= n_q and the 13 slack tiles are zero.  The swizzle makes the scan's fragment read
+    (lane r16 + 16 g -> unit 4 r16 + (g ^ slot swizzle)) conflict-free in each of the four lane groups ds_read_b128 is served in."""
     from swat_amd import _lib
     dev = _dev()
     nq, d = 37, 256
@@ -362,7 +363,11 @@ def test_packed_query_image_layout():
     qb = torch.zeros(tiles * 16, d)
     qb[:nq] = q.to(torch.bfloat16).float().cpu()
     L = torch.arange(64)
-    slot = (L % 4) ^ ((L // 16) % 4)
+    slot = (L % 4) ^ (3 * ((L // 32) % 2))
+    for group in ([0, 1, 2, 3, 12, 13, 14, 15] + list(range(20, 28)), list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31]):
+        for base in (0, 32):   # MI355X_MICROARCH.md: the groups of ds_read_b128; a 16-B unit U covers banks 4 (U % 16) .. + 3
+            units = [4 * (ln % 16) + ((ln // 16) ^ (3 * (((ln % 16) >> 3) & 1))) for ln in (x + base for x in group)]
+            assert len({u % 16 for u in units}) == 16
     for c in range(d // 32):
         for T in (0, 1, 2, 3, tiles - 1):
             want = torch.stack([torch.cat([qb[16 * T + int(L[i]) // 4, 32 * c + 4 * int(slot[i]):32 * c + 4 * int(slot[i]) + 4],

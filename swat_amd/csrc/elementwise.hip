@@ -449,9 +449,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float bc1 = bc[0], sbc2 = sqrtf(bc[1]);
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     typedef float nt4 __attribute__((ext_vector_type(4)));
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += U * stride) {
-        // every byte is touched once per step: nontemporal accesses keep the stream out of the way of the GEMMs' L2 lines
-        nt4 pn[U], gn[U], mn[U], vn[U];
+    // every byte is touched once per step: nontemporal accesses keep the stream out of the way of the GEMMs' L2 lines
+    auto load = [&](nt4 (&pn)[U], nt4 (&gn)[U], nt4 (&mn)[U], nt4 (&vn)[U], int64_t i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
@@ -462,6 +461,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                 vn[u] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(v) + i);
             }
         }
+    };
+    auto update = [&](const nt4 (&pn)[U], const nt4 (&gn)[U], const nt4 (&mn)[U], const nt4 (&vn)[U], int64_t i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
@@ -469,25 +470,56 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             const int64_t e = i << 2;
             float pa[4] = {pn[u][0], pn[u][1], pn[u][2], pn[u][3]}, ma[4] = {mn[u][0], mn[u][1], mn[u][2], mn[u][3]};
             float va[4] = {vn[u][0], vn[u][1], vn[u][2], vn[u][3]};
+            // the learning-rate group of an element: the groups are a handful of long contiguous segments, so all but a few quads of
+            // the arena lie inside one — the group of the quad's first and last element decide (one lookup per quad; the per-element
+            // lookup, a vector load and three 64-bit compares per element, only for a quad that straddles a boundary)
+            int sg0 = 0, sg3 = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                sg0 += (q < segs.n && e >= segs.begin[q]) ? 1 : 0;
+                sg3 += (q < segs.n && e + 3 >= segs.begin[q]) ? 1 : 0;
+            }
+            const float lr0 = lrs[sg0];
+            float decay[4], stepsz[4];   // 1 - lr wd and lr / bc1 of the four elements: computed once for a quad inside one group
+            {
+#pragma clang fp contract(off)   // every AdamW form of the library rounds each operation: their results are identical by construction
+                const float d0 = 1.0f - lr0 * wd, s0 = lr0 / bc1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { decay[k] = d0; stepsz[k] = s0; }
+                if (sg0 != sg3) {
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        int sg = 0;
+#pragma unroll
+                        for (int q = 1; q < 4; ++q) sg += (q < segs.n && e + k >= segs.begin[q]) ? 1 : 0;
+                        const float lr = lrs[sg];
+                        decay[k] = 1.0f - lr * wd;
+                        stepsz[k] = lr / bc1;
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-#pragma clang fp contract(off)   // every AdamW form of the library rounds each operation: their results are identical by construction
-                int sg = 0;
-#pragma unroll
-                for (int q = 1; q < 4; ++q) sg += (q < segs.n && e + k >= segs.begin[q]) ? 1 : 0;
-                const float lr = lrs[sg];
+#pragma clang fp contract(off)
                 const float gg = gn[u][k] * grad_scale;
-                pa[k] *= 1.0f - lr * wd;
+                pa[k] *= decay[k];
                 ma[k] = beta1 * ma[k] + (1.0f - beta1) * gg;
                 va[k] = beta2 * va[k] + (1.0f - beta2) * gg * gg;
                 const float denom = sqrtf(va[k]) / sbc2 + eps;
-                pa[k] -= (lr / bc1) * (ma[k] / denom);
+                pa[k] -= stepsz[k] * (ma[k] / denom);
             }
             __builtin_nontemporal_store((nt4){pa[0], pa[1], pa[2], pa[3]}, reinterpret_cast<nt4*>(p) + i);
             __builtin_nontemporal_store((nt4){ma[0], ma[1], ma[2], ma[3]}, reinterpret_cast<nt4*>(m) + i);
             __builtin_nontemporal_store((nt4){va[0], va[1], va[2], va[3]}, reinterpret_cast<nt4*>(v) + i);
             if (shadow) reinterpret_cast<ushort4*>(shadow)[i] = make_ushort4(f2bf(pa[0]), f2bf(pa[1]), f2bf(pa[2]), f2bf(pa[3]));
         }
+    };
+    // (tried for the thin form, U = 4: a trip's loads issued before the previous trip is updated and stored — two register sets, two
+    //  trips of reads in flight: 594 us against 560 for the 88 M-parameter arena alone; the plain loop stays)
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += U * stride) {
+        nt4 pn[U], gn[U], mn[U], vn[U];
+        load(pn, gn, mn, vn, i0);
+        update(pn, gn, mn, vn, i0);
     }
 }
 

@@ -379,6 +379,37 @@ __global__ __launch_bounds__(HR_THREADS) void head_rows_kernel(const float* __re
     __syncthreads();
     // ---- z[c] = sum_e fn[e] W[c][e]: a wave per class, lanes split the features by float4 (E % 4 == 0)
     const int e4n = E >> 2;
+    if (e4n <= 128) {
+        // E <= 512 (every CLIP head of the reference): a lane holds at most two float4 of a class row — the rows of SEVEN classes are
+        // loaded before the first is used, so a wave waits for memory twice for its ~13 classes instead of once per class (each wait
+        // is ~1 us of L2 latency: the class loop was 13 of the kernel's 24 us).  Same products in the same order per class.
+        constexpr int ZU = 7;
+        const bool two = lane + 64 < e4n, one = lane < e4n;
+        const float4 f0 = one ? reinterpret_cast<const float4*>(fn)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 f1 = two ? reinterpret_cast<const float4*>(fn)[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = wave; c0 < C; c0 += HR_WAVES * ZU) {
+            float4 w0[ZU], w1[ZU];
+#pragma unroll
+            for (int u = 0; u < ZU; ++u) {
+                const int c = c0 + HR_WAVES * u;
+                const float4* wr = reinterpret_cast<const float4*>(W + (int64_t)(c < C ? c : c0) * E);
+                w0[u] = one ? wr[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+                w1[u] = two ? wr[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < ZU; ++u) {
+                const int c = c0 + HR_WAVES * u;
+                float a = 0.f;
+                if (one) { a = fmaf(f0.x, w0[u].x, a); a = fmaf(f0.y, w0[u].y, a); a = fmaf(f0.z, w0[u].z, a); a = fmaf(f0.w, w0[u].w, a); }
+                if (two) { a = fmaf(f1.x, w1[u].x, a); a = fmaf(f1.y, w1[u].y, a); a = fmaf(f1.z, w1[u].z, a); a = fmaf(f1.w, w1[u].w, a); }
+                a = wave_sum(a);
+                if (lane == 0 && c < C) {
+                    zs[c] = a;
+                    z_out[(int64_t)b * C + c] = a;
+                }
+            }
+        }
+    } else {
     for (int c = wave; c < C; c += HR_WAVES) {
         const float4* wr = reinterpret_cast<const float4*>(W + (int64_t)c * E);
         float a = 0.f;
@@ -392,6 +423,7 @@ __global__ __launch_bounds__(HR_THREADS) void head_rows_kernel(const float* __re
             zs[c] = a;
             z_out[(int64_t)b * C + c] = a;
         }
+    }
     }
     __syncthreads();
     // ---- mixed cross entropy on the scaled logits (the arithmetic of ce_mixed_kernel, sums over 16 waves)

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void cls_ln_proj_kernel(const float* __restric
     const int e4 = tid & 15, part = tid >> 4;
     const float* pc = proj + 64 * j + 4 * e4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
+#pragma unroll 8   // (unroll 16: 28 us instead of 10.6)
     for (int c = part; c < d; c += 16) {
         const float4 w = *reinterpret_cast<const float4*>(pc + (int64_t)c * E);
         const float uv = su[c];

@@ -849,6 +849,13 @@ def main():
         out["cpu_baseline"] = None
     del step, model, head, images
     torch.cuda.empty_cache()
+    # the input-pipeline leg (loader worker processes + host decode threads) runs BEFORE the CPU-baseline legs: measured in one process,
+    # files on disk -> batches drops from 12-13 k to 8.3-8.7 k img/s once cpu_baseline() (torch on every host core for ~20 s) has run —
+    # with one torch thread in the loaders' process too (tools/micro/loader_ctx.py) — and a training run has no such leg in front of
+    # its loaders.  Its record keeps its place in the list.
+    dec = None
+    if world == 1 and not a.no_secondary:
+        dec = decode_secondary(dev, with_cpu=not a.no_cpu_baseline)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.bsz)
     if not a.no_secondary:
@@ -858,7 +865,7 @@ def main():
         if world == 1:
             sec.append(retrieval_secondary(dev, d=768, with_cpu=False))  # ViT-L/14 embedding width
             sec.append(preprocess_secondary(dev))
-            sec.append(decode_secondary(dev, with_cpu=with_cpu))
+            sec.append(dec)
             sec += [finetune_secondary_subprocess(arch) for arch in ("ViT-B-16", "ViT-L-14")]
         if rank == 0:
             out["secondary"] = sec

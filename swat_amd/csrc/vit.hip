@@ -430,6 +430,8 @@ SWAT_API int64_t swat_vit_workspace_bytes(const int32_t* dims) {
     return carve(D, nullptr).total;
 }
 
+static int join_pending_lane(hipStream_t s);   // the lane half of an owed join (defined with swat_vit_join_pending)
+
 SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const float* params, const void* shadow_bf16,
                               const float* images, const int64_t* perm, int x1, int x2, int y1, int y2, void* workspace,
                               float* feats, swat_stream_t stream) {
@@ -451,6 +453,14 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
         convw = w.convw;
     }
     {
+        // A join owed to the previous step (swat_vit_backward_join_later): the patch-embedding product waits for the LANE's tail — beside
+        // a block's weight-gradient launch both take twice their time (round-5 timeline: 106 us instead of 21 for this product, 96
+        // instead of 47 for the weight gradients it met, and the lane's chain is what bounds the optimizer phase) — and runs beside
+        // the last blocks' AdamW instead, which is HBM-bound.  The second stream's tail is joined behind the stem as before.
+        // Measured (alternating builds): 2.715 / 2.730 against 2.728 / 2.740 ms per step; in the trace the patch extraction in front
+        // of this wait starts behind the lane's tail as well (the runtime submits the two together).
+        static const int stem_late = getenv("SWAT_STEM_AFTER_LANE") ? atoi(getenv("SWAT_STEM_AFTER_LANE")) : 1;
+        if (stem_late) TRY(join_pending_lane(s));
         GemmArgs a = G(w.patches, convw, w.xpre, np, d, D.Kp, D.ldk, D.ldk, d, 1);
         a.rpg = D.g * D.g; a.gstride = T; a.roff = 1; a.rowbias = params + O.pos;
         TRY(gemm_dispatch(L_NT, a, 1, s));
@@ -654,6 +664,14 @@ SWAT_API int swat_vit_lane_follow(swat_stream_t stream) {
     SWAT_HIP(hipEventRecord(e, (hipStream_t)stream));
     SWAT_HIP(hipStreamWaitEvent(g_side.st, e, 0));
     g_side.open = true;  // the caller joins (swat_vit_backward_join) before it reads what it queued on the lane
+    return 0;
+}
+
+static int join_pending_lane(hipStream_t s) {
+    if (g_side.pending && g_side.pend_lane) {
+        SWAT_HIP(hipStreamWaitEvent(s, g_side.pend_lane, 0));
+        g_side.pend_lane = nullptr;
+    }
     return 0;
 }
 

@@ -473,6 +473,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void sim_candidates
 //     0.322): a third of the 26 groups of a block hold one.  Turning a hit into a record with vector code per row (EPI 2) or with a
 //     scalar walk over the hit bits cost the same; parking the hit lanes and converting them in one rolled loop (EPI 3) is 4 %
 //     faster (0.301 against 0.314 ms scan + regroup, same process).
+//   * tried on top of EPI 3 and dropped: the block's first step taking a constant-zero C operand instead of 104 zeroed registers, with
+//     a first epilogue round free of the `done` mask — slower (0.312 against 0.301 ms scan + regroup; 0.275 against 0.265 with no
+//     hits at all: the second copy of the step's MFMA loop costs more than the moves it saves).
 //   * falsified earlier in the round: the epilogue's compare form (0.329 vs 0.334 ms), record stores sharing vmcnt with the row loads
 //     (0.331), DRAM locality (tiled shadow, 0.329 vs 0.336; fragment-ordered so that a load instruction reads 1 KiB contiguous: no
 //     change), the depth of the row stream (0.339 vs 0.341), wave priorities (s_setprio for the second wave of a SIMD: 0.354 vs

@@ -24,7 +24,8 @@ class GradWire:
     * collective `all_reduce` (default) or `rs_ag`: reduce_scatter_tensor + all_gather_into_tensor — on 8 fully connected
       GPUs every rank then exchanges 1/8 of the range with each of its 7 peers over all 7 xGMI links at once instead of
       pushing the whole range round a ring (SWAT_DP_COLLECTIVE=rs_ag);
-    * wire format `fp32` (default) or `bf16` (SWAT_DP_WIRE=bf16): the range is rounded to bf16 (swat_cast_bf16), SUMMED in
+    * wire format `fp32` (this class's default; the CLI's --dp_wire auto picks fp32 for the batch-splitting mode and bf16 for --dp_weak,
+      bench.py --gpus N picks bf16: swat_amd/dp.py) or `bf16` (SWAT_DP_WIRE=bf16): the range is rounded to bf16 (swat_cast_bf16), SUMMED in
       bf16 by the collective and widened back into the fp32 gradient buffer the optimizer reads — half the bytes per link.
       Tolerance: every addend rounded to 8 significant bits and every partial sum rounded again, i.e.
       |error| <= (1 + log2(world)) * 2^-8 * sum_r |g_r| per element (tests/test_distributed_cpu.py holds it to that);

@@ -101,6 +101,10 @@ def build_parser():
     p.add_argument('--dp_weak', action='store_true',
                    help='data-parallel runs: every rank loads its own --bsz rows (global batch = world x bsz) instead of '
                         'splitting the --bsz batch')
+    p.add_argument('--dp_wire', type=str, default='auto', choices=['auto', 'fp32', 'bf16'],
+                   help="data-parallel runs: what a gradient bucket crosses the xGMI links as (swat_amd.ddp.GradWire).  auto = fp32 when "
+                        "the --bsz batch is split over the ranks (that mode reproduces the one-GPU trajectory), bf16 with --dp_weak "
+                        "(throughput: 88 M fp32 gradients are 352 MB per step and GPU, more than the links move in a ViT-B/32 step)")
     p.add_argument('--synthetic', type=int, default=0, help='train on N seeded synthetic images (no dataset needed)')
     p.add_argument('--num_classes', type=int, default=200, help='classes of the synthetic dataset')
     p.add_argument('--config', type=str, default='config.yml')

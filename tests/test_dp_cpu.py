@@ -130,6 +130,27 @@ def test_extraction_does_not_split_the_batch_over_ranks(monkeypatch):
     assert a.world == 3
 
 
+def test_gradient_wire_follows_the_data_parallel_mode(monkeypatch):
+    """--dp_wire auto: the mode that splits --bsz over the ranks reproduces the one-GPU trajectory and keeps fp32 gradients on the links;
+    --dp_weak (throughput) sends bf16; the flag and an exported SWAT_DP_WIRE override it (swat_amd/dp.py, ddp.GradWire)."""
+    from swat_amd import dp
+    from swat_amd.parser import parse_args
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(dist, "init_process_group", lambda *a, **k: None)
+    for kw, want in ((dict(), "fp32"), (dict(dp_weak=True), "bf16"), (dict(dp_weak=True, dp_wire="fp32"), "fp32"), (dict(dp_wire="bf16"), "bf16")):
+        monkeypatch.delenv("SWAT_DP_WIRE", raising=False)
+        dp.init_from_env(types.SimpleNamespace(dist_backend="gloo", bsz=32, dp_wire=kw.get("dp_wire", "auto"), dp_weak=kw.get("dp_weak", False)))
+        assert os.environ["SWAT_DP_WIRE"] == want, (kw, os.environ["SWAT_DP_WIRE"])
+    monkeypatch.setenv("SWAT_DP_WIRE", "fp32")
+    dp.init_from_env(types.SimpleNamespace(dist_backend="gloo", bsz=32, dp_wire="auto", dp_weak=True))
+    assert os.environ["SWAT_DP_WIRE"] == "fp32"   # an exported value wins
+    monkeypatch.delenv("SWAT_DP_WIRE", raising=False)
+    import sys
+    monkeypatch.setattr(sys, "argv", ["main.py"])
+    assert parse_args().dp_wire == "auto"
+
+
 def test_single_process_is_untouched():
     from swat_amd import dp
     args = types.SimpleNamespace()

@@ -554,6 +554,39 @@ def test_data_parallel_step_runs_the_persistent_backward_and_equals_the_one_gpu_
     assert total1 == total2 and total1 > 0
 
 
+def test_data_parallel_step_with_bf16_gradients_on_the_wire_over_rccl(monkeypatch):
+    """The --dp_weak / bench default (SWAT_DP_WIRE=bf16, ddp.GradWire): each bucket is cast to bf16, all-reduced by RCCL as bf16 and widened
+    back before its AdamW.  In a 1-rank RCCL group the collective is the identity, so the gradient the optimizer reads is the one-GPU
+    step's gradient rounded to bf16 — element by element — and the first step's loss is the same number."""
+    import torch.distributed as dist
+    from swat_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(17)
+    x, y = torch.randn(32, 3, 224, 224, generator=g).to(dev()), torch.randint(0, 200, (32,), generator=g).to(dev())
+    monkeypatch.setenv("SWAT_DP_WIRE", "bf16")
+
+    def run(make):
+        model, head, opt, sched, step = make(seed=5)
+        w0 = opt.arena.flat.clone()
+        step(x, y, y.flip(0), 0.6, perm=torch.arange(31, -1, -1, device=dev()), box=(30, 40, 150, 190))
+        loss = step.loss.clone()
+        step.pop_loss_sum()
+        assert L.swat_vit_mega_status() == 0
+        return step, loss.cpu(), opt.arena.grad.clone(), opt.arena.flat.clone() - w0
+
+    created = _one_rank_group()
+    try:
+        _, l1, g1, w1 = run(_b32_step)
+        step, l2, g2, w2 = run(_b32_dp_step)
+        assert step._wire().wire == "bf16" and step._dp_fused
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.equal(l1, l2)
+    assert torch.equal(g2, g1.to(torch.bfloat16).float()), (g2 - g1).abs().max().item()
+    assert (w2 - w1).norm() <= 0.2 * w1.norm()   # (w = the first AdamW step's move: only signs of rounding-level gradients may flip)
+
+
 @pytest.mark.parametrize("when", ["early", "last"])
 def test_data_parallel_give_up_voids_the_step_and_every_rank_replays(when):
     """A hand-off give-up at N > 1 (round-4 verdict: it used to raise).  The step's flag exchange (swat_vit_mega_void_flag ->

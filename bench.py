@@ -846,6 +846,8 @@ def main():
                "final_loss": round(loss, 4),
                # which step ran: persistent forward / backward launches per timed step on rank 0 (1.0 / 1.0 = the fast path, at any N)
                "persistent_launches_per_step": {"forward": pl[0] / a.steps, "backward": pl[1] / a.steps},
+               # N > 1 on RCCL: which backward the step chose from a timed collective (swat_amd/step.py:_decide_dp_path); None otherwise
+               "dp_path": getattr(step, "dp_calibration", None),
                "step_mfma_frac": round(GFLOP_PER_IMG_STEP * 1e9 * a.bsz / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
     # the instrumented replay runs on every rank (its steps contain the gradient all-reduces); rank 0 reports its own
     roof = gemm_roofline(args, step, sched, images, labels, min(a.steps, 10), a.bsz, a.overlap)

@@ -91,12 +91,56 @@ class FusedTrainStep:
         self._void_flag = None
         # N > 1: the blocks' backward as ONE persistent launch with the buckets' all-reduce + AdamW trailing the weight gradients
         # (csrc/vit.hip: swat_vit_backward_set_buckets); SWAT_DP_PERSISTENT=0 keeps the stage-by-stage backward of rounds 2-4
-        self.dp_persistent = os.environ.get("SWAT_DP_PERSISTENT", "1") != "0"
+        # (auto, the default: decided once, at the first data-parallel step, from a timed collective — _decide_dp_path)
+        self._dp_mode = os.environ.get("SWAT_DP_PERSISTENT", "auto")
+        self.dp_persistent = self._dp_mode != "0"
+        self.dp_calibration = None
         self.lazy_join = os.environ.get("SWAT_LAZY_JOIN", "1") != "0"
         if self.trail:
             # process-wide streams owned by the library (created once, together with the weight-gradient lane)
             self._comm_stream = torch.cuda.ExternalStream(_lib.lib().swat_vit_aux_stream(0), device=dev)  # all-reduces
             self._opt_stream = torch.cuda.ExternalStream(_lib.lib().swat_vit_aux_stream(1), device=dev)   # AdamW slices at N > 1
+
+    DP_COMM_BREAK_EVEN_MS = 1.35
+
+    def _decide_dp_path(self):
+        """SWAT_DP_PERSISTENT=auto, once per job, on every rank alike.  The persistent launches own every CU, so with them a bucket's
+        collective can only run in the optimizer phase (~0.8 ms at the benchmark's shape): step ~ 1.9 ms + max(0.8, t_comm).  The
+        stage-by-stage backward of rounds 2-4 is slower alone (3.4 ms) but its collectives run beside ordinary kernels through the whole
+        backward: step ~ max(3.4, 0.9 + t_comm).  The two cross at t_comm ~ 1.35 ms — the gradient's time on the links, which is 4.6 /
+        2.3 / 1.15 ms for fp32 and half that for bf16 on 2 / 4 / 8 GPUs by the link count alone.  So: time a
+        32 MB collective of the wire's dtype on the communication backend, scale it to the arena, take the slowest rank's figure, and
+        keep the persistent form when it is below the break-even.  Only on RCCL with more than one rank: the one-GPU tests' gloo
+        groups (host round trips) and 1-rank groups keep the persistent form, as does any failure of the measurement."""
+        self._dp_mode = "decided"
+        try:
+            force = os.environ.get("SWAT_DP_CALIBRATE_FORCE") == "1"   # tests: run the measurement in a 1-rank RCCL group
+            if not (dist.is_initialized() and dist.get_backend() == "nccl" and (dist.get_world_size() > 1 or force)):
+                return
+            wire = self._wire()
+            dt = torch.bfloat16 if wire.wire == "bf16" else torch.float32
+            n = min(self.arena.numel, (32 << 20) // (2 if dt == torch.bfloat16 else 4))
+            buf = torch.zeros(n, dtype=dt, device=self.arena.flat.device)
+            for _ in range(2):
+                dist.all_reduce(buf)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(4):
+                dist.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 4 * (self.arena.numel / n)
+            t = torch.tensor([ms], dtype=torch.float32, device=buf.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+            self.dp_persistent = ms <= self.DP_COMM_BREAK_EVEN_MS
+            self.dp_calibration = {"gradient_ms_on_the_links": round(ms, 3), "break_even_ms": self.DP_COMM_BREAK_EVEN_MS,
+                                   "path": "persistent backward, buckets trailing" if self.dp_persistent else "stage-by-stage backward, collectives beside it"}
+        except Exception as ex:  # noqa: a failed measurement must not stop a training job
+            import warnings
+            warnings.warn(f"swat_amd: could not time the gradient collective ({ex}); keeping the persistent data-parallel step")
+            self.dp_persistent = True
 
     def _wire(self):
         w = getattr(self, "_grad_wire", None)
@@ -145,6 +189,8 @@ class FusedTrainStep:
         blocks_fused = bool(self.train_visual and self.trail and _lib.lib().swat_vit_backward_blocks_fused(self.visual._last_ws[1]))
         self._late_loss = blocks_fused and not self.reduce
         # N > 1: the same one persistent launch for the blocks, its buckets reduced behind the weight gradients (_reduce_persistent)
+        if self.reduce and self._dp_mode == "auto":
+            self._decide_dp_path()
         self._dp_fused = blocks_fused and self.reduce and self.dp_persistent
         # N > 1: a step can be voided by ANOTHER rank's give-up, known only after the step's flag exchange: the running loss sum is
         # fed behind that exchange (swat_loss_accumulate), not by the loss kernel

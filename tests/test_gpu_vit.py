@@ -554,6 +554,40 @@ def test_data_parallel_step_runs_the_persistent_backward_and_equals_the_one_gpu_
     assert total1 == total2 and total1 > 0
 
 
+def test_data_parallel_stage_by_stage_backward_at_the_benchmark_shape_tracks_the_one_gpu_step(monkeypatch):
+    """The other data-parallel form the step may choose when the links are slow (step.py:_decide_dp_path; SWAT_DP_PERSISTENT=0 forces it):
+    persistent forward, then the backward stage by stage with each stage's slice reduced beside the next stage's kernels.  Same
+    arithmetic per tensor up to the order of a few sums: loss equal, gradients within 4e-3 of the one-GPU step's in the norm, and no
+    persistent backward launch."""
+    import torch.distributed as dist
+    from swat_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(19)
+    x, y = torch.randn(32, 3, 224, 224, generator=g).to(dev()), torch.randint(0, 200, (32,), generator=g).to(dev())
+
+    def run(make):
+        model, head, opt, sched, step = make(seed=6)
+        nb0 = L.swat_vit_mega_backward_launches()
+        step(x, y, y.flip(0), 0.6, perm=torch.arange(31, -1, -1, device=dev()), box=(30, 40, 150, 190))
+        loss = step.loss.clone()
+        step.pop_loss_sum()
+        assert L.swat_vit_mega_status() == 0
+        return step, loss.cpu(), opt.arena.grad.clone(), L.swat_vit_mega_backward_launches() - nb0
+
+    created = _one_rank_group()
+    try:
+        _, l1, g1, n1 = run(_b32_step)
+        monkeypatch.setenv("SWAT_DP_PERSISTENT", "0")
+        step, l2, g2, n2 = run(_b32_dp_step)
+        assert step.reduce and not step._dp_fused
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert n1 == 1 and n2 == 0
+    assert abs(l1.item() - l2.item()) < 1e-5 * abs(l1.item())
+    assert ((g2 - g1).norm() / g1.norm()).item() < 4e-3
+
+
 def test_data_parallel_step_with_bf16_gradients_on_the_wire_over_rccl(monkeypatch):
     """The --dp_weak / bench default (SWAT_DP_WIRE=bf16, ddp.GradWire): each bucket is cast to bf16, all-reduced by RCCL as bf16 and widened
     back before its AdamW.  In a 1-rank RCCL group the collective is the identity, so the gradient the optimizer reads is the one-GPU
@@ -564,6 +598,7 @@ def test_data_parallel_step_with_bf16_gradients_on_the_wire_over_rccl(monkeypatc
     g = torch.Generator().manual_seed(17)
     x, y = torch.randn(32, 3, 224, 224, generator=g).to(dev()), torch.randint(0, 200, (32,), generator=g).to(dev())
     monkeypatch.setenv("SWAT_DP_WIRE", "bf16")
+    monkeypatch.setenv("SWAT_DP_CALIBRATE_FORCE", "1")   # ... and the step times a collective to choose its backward (step.py:_decide_dp_path)
 
     def run(make):
         model, head, opt, sched, step = make(seed=5)
@@ -579,6 +614,8 @@ def test_data_parallel_step_with_bf16_gradients_on_the_wire_over_rccl(monkeypatc
         _, l1, g1, w1 = run(_b32_step)
         step, l2, g2, w2 = run(_b32_dp_step)
         assert step._wire().wire == "bf16" and step._dp_fused
+        cal = step.dp_calibration   # a 1-rank collective costs next to nothing: the persistent form stays
+        assert cal and cal["path"].startswith("persistent") and 0 <= cal["gradient_ms_on_the_links"] < cal["break_even_ms"]
     finally:
         if created:
             dist.destroy_process_group()

@@ -785,11 +785,12 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # weak scaling (every rank its own 32 images) is the CLI's --dp_weak mode, whose gradient buckets cross the links as bf16
-        # (swat_amd/dp.py: 352 MB of fp32 gradients per step and GPU are 4.6 ms on the ONE xGMI link between two GPUs, 1.2 ms over the
-        # seven of an 8-GPU node, against a 2.7 ms step whose persistent launches leave the collectives only the optimizer phase);
-        # SWAT_DP_WIRE=fp32 measures the other form.  The JSON line says which one ran (config.gradient_wire).
-        os.environ.setdefault("SWAT_DP_WIRE", "bf16")
+        # The headline keeps fp32 gradients on the links (what the reference's optimizer sees; the one-GPU trajectory).  352 MB of
+        # fp32 gradients per step and GPU are 4.6 ms on the ONE xGMI link between two GPUs and 1.2 ms over the seven of an 8-GPU node,
+        # against a 2.7 ms step whose persistent launches leave the collectives only the optimizer phase: SWAT_DP_WIRE=bf16 (the
+        # CLI's --dp_weak default, swat_amd/dp.py) halves the bytes at bf16 summation error.  The JSON line says which one ran
+        # (config.gradient_wire).
+        os.environ.setdefault("SWAT_DP_WIRE", "fp32")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -841,7 +842,7 @@ def main():
                                       "200 classes, AdamW 3 LR groups, fp32 master + bf16 MFMA", "per_gpu_batch": a.bsz,
                           "global_batch": a.bsz * world, "image": "3x224x224 fp32 resident in HBM",
                           "parallelism": f"dp{world}" if world > 1 else "single",
-                          "gradient_wire": os.environ.get("SWAT_DP_WIRE", "fp32") if world > 1 else None,   # (bf16 unless exported: see main())
+                          "gradient_wire": os.environ.get("SWAT_DP_WIRE", "fp32") if world > 1 else None,   # (fp32 unless exported: see main())
                           "gradient_collective": os.environ.get("SWAT_DP_COLLECTIVE", "all_reduce") if world > 1 else None},
                "final_loss": round(loss, 4),
                # which step ran: persistent forward / backward launches per timed step on rank 0 (1.0 / 1.0 = the fast path, at any N)

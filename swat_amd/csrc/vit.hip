@@ -449,6 +449,8 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
     TRY(swat_patchify_cutmix(images, perm, w.patches, D.B, D.img, D.img, D.patch, D.ldk, x1, x2, y1, y2, s));
     const unsigned short* convw = sh + O.conv1;
     if (D.Kp % 8) {
+        // reads the fp32 MASTER conv1 weights (patch 14: Kp = 588): an owed join's lane half comes first whatever stepped stage 0
+        TRY(join_pending_lane(s));
         hipLaunchKernelGGL(pad_cast_rows_kernel, dim3(256), dim3(256), 0, s, params + O.conv1, w.convw, d, D.Kp, D.ldk);
         convw = w.convw;
     }
@@ -460,6 +462,8 @@ SWAT_API int swat_vit_forward(const int32_t* dims, const int64_t* offs, const fl
         // Measured (alternating builds): 2.715 / 2.730 against 2.728 / 2.740 ms per step; in the trace the patch extraction in front
         // of this wait starts behind the lane's tail as well (the runtime submits the two together).
         static const int stem_late = getenv("SWAT_STEM_AFTER_LANE") ? atoi(getenv("SWAT_STEM_AFTER_LANE")) : 1;
+        // (SWAT_STEM_AFTER_LANE=0 is a measurement switch for the FUSED step only, where stage 0 is stepped on the main stream;
+        // swat_amd/step.py owes the join in no other case)
         if (stem_late) TRY(join_pending_lane(s));
         GemmArgs a = G(w.patches, convw, w.xpre, np, d, D.Kp, D.ldk, D.ldk, d, 1);
         a.rpg = D.g * D.g; a.gstride = T; a.roff = 1; a.rowbias = params + O.pos;

@@ -46,11 +46,17 @@ def init_from_env(args, split_batch=True):
     if ngpu:
         torch.cuda.set_device(index)
     args.rank, args.world, args.local_rank = rank, world, local
-    # what crosses the links (ddp.GradWire reads SWAT_DP_WIRE; an exported value wins over the flag)
+    # what crosses the links (ddp.GradWire reads SWAT_DP_WIRE): an explicit --dp_wire fp32 | bf16 wins; with `auto` an exported
+    # SWAT_DP_WIRE wins over the mode's default
     wire = getattr(args, 'dp_wire', 'auto')
     if wire == 'auto':
-        wire = 'bf16' if getattr(args, 'dp_weak', False) else 'fp32'
-    os.environ.setdefault('SWAT_DP_WIRE', wire)
+        os.environ.setdefault('SWAT_DP_WIRE', 'bf16' if getattr(args, 'dp_weak', False) else 'fp32')
+    else:
+        env = os.environ.get('SWAT_DP_WIRE')
+        if env and env != wire and rank == 0:
+            import warnings
+            warnings.warn(f"--dp_wire {wire} overrides the exported SWAT_DP_WIRE={env}")
+        os.environ['SWAT_DP_WIRE'] = wire
     if split_batch and not getattr(args, 'dp_weak', False) and getattr(args, 'bsz', world) % world:
         raise ValueError(f"--bsz {args.bsz} is split over {world} ranks: it must be a multiple of the world size "
                          "(or use --dp_weak for --bsz rows per rank)")

@@ -510,7 +510,9 @@ class FusedTrainStep:
             # step's stem reads stage-0 parameters only (stepped on the main stream above) and runs beside the optimizer's tail;
             # swat_vit_forward pays the join behind its stem (include/swat_hip.h: swat_vit_backward_join_later).  Whoever reads the
             # arena with torch ops before the next step calls join() (pop_loss_sum does)
-            if self.lazy_join and not self.reduce:
+            # Only the FUSED step (blocks as the persistent launch) steps the head, the logit scale and stage 0 on the main stream; the
+            # op-by-op branch runs every AdamW on the lane, so the next stem (conv1 / cls / pos / ln_pre) would race with it: it joins
+            if self.lazy_join and not self.reduce and self._late_loss:
                 lib.swat_vit_backward_join_later(main.cuda_stream)
             else:
                 lib.swat_vit_backward_join(main.cuda_stream)

@@ -6,6 +6,8 @@ import socket
 import sys
 import types
 
+import pytest
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -144,7 +146,11 @@ def test_gradient_wire_follows_the_data_parallel_mode(monkeypatch):
         assert os.environ["SWAT_DP_WIRE"] == want, (kw, os.environ["SWAT_DP_WIRE"])
     monkeypatch.setenv("SWAT_DP_WIRE", "fp32")
     dp.init_from_env(types.SimpleNamespace(dist_backend="gloo", bsz=32, dp_wire="auto", dp_weak=True))
-    assert os.environ["SWAT_DP_WIRE"] == "fp32"   # an exported value wins
+    assert os.environ["SWAT_DP_WIRE"] == "fp32"   # an exported value wins over `auto` ...
+    monkeypatch.setenv("SWAT_DP_WIRE", "bf16")
+    with pytest.warns(UserWarning, match="overrides the exported"):
+        dp.init_from_env(types.SimpleNamespace(dist_backend="gloo", bsz=32, dp_wire="fp32", dp_weak=True))
+    assert os.environ["SWAT_DP_WIRE"] == "fp32"   # ... but not over an explicit --dp_wire
     monkeypatch.delenv("SWAT_DP_WIRE", raising=False)
     import sys
     monkeypatch.setattr(sys, "argv", ["main.py"])

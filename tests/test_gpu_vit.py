@@ -471,6 +471,44 @@ def test_persistent_forward_equals_the_op_by_op_forward_and_ignores_history(B):
         assert r < GRAD_TOL, f"{n}: {r}"
 
 
+@pytest.mark.parametrize("cfg", [TINY_GELU, TINY])
+def test_owed_join_leaves_the_trajectory_bit_identical(cfg, monkeypatch):
+    """the join with the weight-gradient lane may be OWED to the next forward only when the step that owes it
+    stepped stage 0 on the main stream (the fused ViT-B/32 step).  Every other shape — here patch 14, whose stem first re-packs the fp32
+    conv1 MASTER weights (588 columns) — must see the lane's AdamW before its stem: SWAT_LAZY_JOIN=1 and =0 give the same bits."""
+    from swat_amd import optimizers
+    from swat_amd.clip_model import CLIP
+    from swat_amd.models import MyLinear
+    from swat_amd.step import FusedTrainStep
+
+    def run(lazy):
+        monkeypatch.setenv("SWAT_LAZY_JOIN", lazy)
+        torch.manual_seed(0)
+        model = CLIP(vision_cfg=cfg, text_cfg=(8, 64, 64, 1, 1)).to(dev())
+        W = torch.randn(10, cfg[5])
+        head = MyLinear(weights=W / W.norm(dim=-1, keepdim=True)).to(dev())
+        args = _args(lr_backbone=1e-3)   # (large enough for every step to move conv1 / cls / pos / ln_pre in bf16)
+        params, ls = optimizers.set_params(args, model, head, _Lg())
+        opt, sched, _ = optimizers.set_optimizer(args, params, [None] * 100)
+        step = FusedTrainStep(model, head, ls, opt, world_size=1)
+        assert step.lazy_join == (lazy == "1")
+        g = torch.Generator().manual_seed(5)
+        losses = []
+        for it in range(6):
+            x = torch.randn(48, 3, cfg[0], cfg[0], generator=g).to(dev())
+            y = torch.randint(0, 10, (48,), generator=g).to(dev())
+            losses.append(step(x, y, y, 1.0).detach().clone())
+            sched.step()
+        step.join()
+        torch.cuda.synchronize()
+        return torch.stack([l.detach().reshape(()) for l in losses]).cpu(), step.arena.flat.detach().cpu().clone()
+
+    l1, w1 = run("1")
+    l0, w0 = run("0")
+    assert torch.equal(l1, l0)
+    assert torch.equal(w1, w0)
+
+
 def _b32_step(seed=0, C=200):
     from swat_amd import optimizers
     from swat_amd.clip_model import CLIP

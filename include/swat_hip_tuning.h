@@ -43,6 +43,15 @@ int swat_gemm_set_wgrad_big(int mode);
  *     38 <= T <= 56): 1 = on when the shapes qualify and the batch fills whole rounds of 16 two-image panels (B = 27-32, 59-64;
  *     default), 2 = on for every batch of a qualifying shape (tests), 0 = always op by op.  Same buffers, same rounding points. */
 int swat_vit_set_mega(int mode);
+/* Roles of the persistent launches' waves (SWAT_VIT_MEGA_ROLES presets it): 2 (default) = the four loader waves move operand bytes
+ *     only for the whole launch and carry up to 192 KB of the NEXT product's weight stages in their registers across the epilogue,
+ *     hand-off and LayerNorm in between (the four consumer waves do everything else); 1 = the kernels of rounds 3-5, where every
+ *     wave takes part in every phase.  Outputs are bit-identical. */
+int swat_vit_set_mega_roles(int mode);
+/* XCDs the 16 members of a team are spread over under round-robin workgroup placement (SWAT_VIT_MEGA_XSPLIT presets it): 1 = an XCD
+ *     hosts two whole teams (rounds 3-5); 2 / 4 / 8 = it hosts the same 8 / 4 / 2 members of 4 / 8 / 16 teams, i.e. sees a half / a
+ *     quarter / an eighth of every weight matrix.  Default 4.  Placement is for speed only: outputs do not depend on it. */
+int swat_vit_set_mega_xsplit(int xcds);
 /* Synchronises the device, returns and clears the status word of the persistent forwards since the last call: 0 = every team
  *     hand-off completed; otherwise bit 30 is set and the low bits name the hand-off a workgroup gave up on (0.5 s). */
 int swat_vit_mega_status(void);

@@ -5,7 +5,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libswat_hip.so")
+# (SWAT_HIP_LIB: an alternate build of the same ABI, for A/B measurements — tools/micro/_ab/ — without touching the in-tree library)
+LIB_PATH = os.environ.get("SWAT_HIP_LIB") or os.path.join(_HERE, "lib", "libswat_hip.so")
 _lib = None
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float

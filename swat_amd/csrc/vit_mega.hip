@@ -53,6 +53,7 @@ struct MegaFwd {
     int B, T, d, H, mlp, L, act, save, M, Mp;
     int P;          // images per panel
     int npanels, nteams;
+    int xsplit;     // XCDs a team is spread over (mg_place)
     float eps;
     // parameters: fp32 master + bf16 shadow at the same element offsets; layer l adds l * layer_stride
     const float* params;
@@ -114,46 +115,49 @@ __device__ __forceinline__ void mg_barrier() {
 // `early(lw)` runs on the four loader waves between the two workgroup barriers — while lane 0 waits for the team they already
 // stream the first stages of the NEXT phase's weight slice into the LDS ring (weights depend on no hand-off).  The second
 // barrier is a raw s_barrier: __syncthreads() would drain those LDS-DMAs (vmcnt(0)).
+// lane 0 of the workgroup: arrive at the team's counter and wait (bounded) until every member has
+template <class Params>
+__device__ __forceinline__ void team_arrive(const Params& p, int team, int member, unsigned target, unsigned long long* tr) {
+    if (tr) tr[1] = mg_clock();                   // stores drained, workgroup together
+    unsigned* c = p.ctr + team * 32;
+    const bool skip = p.fail_sync && target == (unsigned)p.fail_sync * MG_TEAM && team == 0 && member == 1;
+    target += p.ctr_base;
+    if (!skip) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = mg_clock();
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        // a hand-off that has already been given up on anywhere (this launch or an earlier one the host has not seen yet):
+        // the launch's values are void, do not wait 0.5 s at each of its 72 hand-offs
+        if ((++spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (mg_clock() - t0 > p.spin_ticks) {  // a member never arrived (not resident / faulted): give up, flag it
+            __hip_atomic_store(p.status, 0x80000000u | (target - p.ctr_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned expect = 0;
+            __hip_atomic_compare_exchange_strong(p.host_flag, &expect, p.launch_no, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    if (tr) tr[2] = mg_clock();                   // every member has arrived
+    // The acquire drops lines this CU's L1 (and the L2's non-local lines) may hold from BEFORE they were rewritten.  With
+    // save = 1 every handed-off buffer is per layer: each line is written once in a launch and no workgroup loads it before
+    // the hand-off that publishes it (the launch itself starts with invalidated caches), so there is nothing stale to
+    // drop and the ~1 us invalidate is skipped.  save = 0 re-uses the buffers layer after layer: the acquire stays.
+    if (!p.save) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (tr) tr[3] = mg_clock();                   // acquire complete
+}
+
 template <class Params, class Early>
 __device__ __forceinline__ void team_sync(const Params& p, int team, int member, unsigned target, Early&& early, unsigned long long* tr = nullptr) {
     if (tr && threadIdx.x == 0) tr[0] = mg_clock();   // stores issued
     mg_drain();          // every storing wave
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) {
-        if (tr) tr[1] = mg_clock();                   // stores drained, workgroup together
-        unsigned* c = p.ctr + team * 32;
-        const bool skip = p.fail_sync && target == (unsigned)p.fail_sync * MG_TEAM && team == 0 && member == 1;
-        target += p.ctr_base;
-        if (!skip) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = mg_clock();
-        unsigned spins = 0;
-        while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            // a hand-off that has already been given up on anywhere (this launch or an earlier one the host has not seen yet):
-            // the launch's values are void, do not wait 0.5 s at each of its 72 hand-offs
-            if ((++spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            if (mg_clock() - t0 > p.spin_ticks) {  // a member never arrived (not resident / faulted): give up, flag it
-                __hip_atomic_store(p.status, 0x80000000u | (target - p.ctr_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned expect = 0;
-                __hip_atomic_compare_exchange_strong(p.host_flag, &expect, p.launch_no, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-        if (tr) tr[2] = mg_clock();                   // every member has arrived
-        // The acquire drops lines this CU's L1 (and the L2's non-local lines) may hold from BEFORE they were rewritten.  With
-        // save = 1 every handed-off buffer is per layer: each line is written once in a launch and no workgroup loads it before
-        // the hand-off that publishes it (the launch itself starts with invalidated caches), so there is nothing stale to
-        // drop and the ~1 us invalidate is skipped.  save = 0 re-uses the buffers layer after layer: the acquire stays.
-        if (!p.save) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (tr) tr[3] = mg_clock();                   // acquire complete
-    } else if (wave >= MG_NC) {
-        early(wave - MG_NC);
-    }
+    if (threadIdx.x == 0) team_arrive(p, team, member, target, tr);
+    else if (wave >= MG_NC) early(wave - MG_NC);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     mg_barrier();
 }
@@ -246,6 +250,117 @@ __device__ __forceinline__ void mg_w_prologue(unsigned char* smem, const MegaW& 
     for (int st = 0; st < NS - 1; ++st) mg_issue_w<BN>(smem, st, cur + step * st, voff, lw);
 }
 
+// ---- the consumer waves' half of a GEMM phase: fragments from the ring, MFMA, one raw s_barrier per k-step; then (behind the
+// barrier that tells the loaders the ring is free) the fp32 tile to LDS at smem as [112][BN + 4].  The caller's workgroup barrier
+// follows.
+template <int BN, int CN, int NS, bool WKC>
+__device__ __forceinline__ void mg_gemm_consume(unsigned char* smem, int nk, int wave, int lane) {
+    constexpr int NC = MG_NC;
+    constexpr int FM = MG_FM, WN = BN / CN, FN = WN / 16;
+    using PC = MgPieces<BN>;
+    constexpr int A_BYTES = PC::A_BYTES, STAGE = PC::STAGE;
+    (void)NC;
+    const bool active = wave < CN;   // BN = 48: three column fragments, the fourth consumer wave only keeps the barriers
+    const int wn0 = (active ? wave : 0) * WN;
+    const int r16 = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
+    constexpr int NB = WKC ? 1 : 2;   // LDS read instructions per B fragment (k-strided: two transposed 8-B reads)
+    unsigned ra[2], rb[2][WKC ? 1 : FN][NB];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        ra[ks] = lds0 + kc_off(r16, 4 * ks + g);
+        if constexpr (WKC) rb[ks][0][0] = lds0 + A_BYTES + kc_off(wn0 + r16, 4 * ks + g);
+        else {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int k = 32 * ks + 8 * g + (r16 >> 2);
+                rb[ks][j][0] = lds0 + A_BYTES + stp_off<BN>(k, wn0 + 16 * j) + 8 * (r16 & 3);
+                rb[ks][j][NB - 1] = lds0 + A_BYTES + stp_off<BN>(k + 4, wn0 + 16 * j) + 8 * (r16 & 3);
+            }
+        }
+    }
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        bf16x8_t fa[FM], fb[2][FN];
+        constexpr int RB = FM / 2;
+        auto read_a = [&](auto I, unsigned so, int ks) {
+            constexpr int i = decltype(I)::value;
+            fa[i] = mg_lds_b128<2048 * i>(ra[ks] + so);
+        };
+        auto read_b = [&](auto J, unsigned so, int ks, bf16x8_t (&bfr)[FN]) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (WKC) bfr[j] = mg_lds_b128<2048 * j>(rb[ks][0][0] + so);
+            else bfr[j] = mg_lds_tr(rb[ks][j][0] + so, rb[ks][j][NB - 1] + so);
+        };
+        constexpr int NRI = FM + FN * NB;
+        auto half = [&](auto WITH_READS, bf16x8_t (&bcur)[FN], bf16x8_t (&bnext)[FN], unsigned sn, int nks) {
+            mg_static_for<FM>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                // reads issued behind row i-1 of THIS half (with reads): a_{i-1} + the B fragments that ride behind row i-1
+                if constexpr (i == 0) {
+                    mg_wait_lgkm<(FM - RB)>();
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) mg_pin(bcur[j]);
+                } else if constexpr (decltype(WITH_READS)::value) {
+                    mg_wait_lgkm<NRI - 1>();
+                } else {
+                    constexpr int later_b = i + 1 < RB ? FN - (i + 1) * FN / RB : 0;
+                    mg_wait_lgkm<(FM - 1 - i) + later_b * NB>();
+                }
+                mg_pin(fa[i]);
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], fa[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (decltype(WITH_READS)::value) {
+                    read_a(I, sn, nks);
+                    if constexpr (i < RB) {
+                        constexpr int j0 = i * FN / RB, j1 = (i + 1) * FN / RB;
+                        mg_static_for<j1 - j0>([&](auto Jd) {
+                            read_b(std::integral_constant<int, j0 + decltype(Jd)::value>{}, sn, nks, bnext);
+                        });
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        };
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        mg_barrier();  // barrier 0: stages 0 and 1 have landed
+        mg_static_for<FM>([&](auto I) { read_a(I, 0u, 0); });
+        mg_static_for<FN>([&](auto J) { read_b(J, 0u, 0, fb[0]); });
+        mg_wait_lgkm<0>();
+        unsigned so = 0;
+        for (int t = 0; t + 1 < nk; ++t) {
+            const unsigned sn = so + STAGE == NS * STAGE ? 0u : so + STAGE;
+            half(T1{}, fb[0], fb[1], so, 1);
+            half(T1{}, fb[1], fb[0], sn, 0);
+            mg_barrier();
+            so = sn;
+        }
+        half(T1{}, fb[0], fb[1], so, 1);
+        half(T0{}, fb[1], fb[0], 0u, 0);
+    } else {
+        for (int t = 0; t < nk; ++t) mg_barrier();
+    }
+    // accumulators -> LDS fp32 tile, behind a barrier: every consumer has finished reading the ring
+    // (the loaders are past their last stage barrier: this extra barrier is matched below)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (active) {
+        float* cl = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<f32x4_t*>(cl + (16 * i + r16) * (BN + 4) + wn0 + 16 * j + 4 * g) = acc[i][j];
+    }
+}
+
 // ---- one GEMM phase: C[112, BN] = A[rows, K] (row-major, lda) x W^T, W rows given by w.row(n), both operands
 // k-contiguous.  Structure and LDS image of gemm_pc_kernel<L_NT> (one tile, FM = 7 row fragments for every consumer
 // wave, CN consumer waves side by side in n); the W pieces of the first NS-1 stages were issued by mg_w_prologue before the
@@ -306,106 +421,7 @@ __device__ __forceinline__ void mg_gemm_nt(unsigned char* smem, const unsigned s
             mg_barrier();
         }
     } else {
-        // ================================ consumer waves ================================
-        const bool active = wave < CN;   // BN = 48: three column fragments, the fourth consumer wave only keeps the barriers
-        const int wn0 = (active ? wave : 0) * WN;
-        const int r16 = lane & 15, g = lane >> 4;
-        const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
-        constexpr int NB = WKC ? 1 : 2;   // LDS read instructions per B fragment (k-strided: two transposed 8-B reads)
-        unsigned ra[2], rb[2][WKC ? 1 : FN][NB];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            ra[ks] = lds0 + kc_off(r16, 4 * ks + g);
-            if constexpr (WKC) rb[ks][0][0] = lds0 + A_BYTES + kc_off(wn0 + r16, 4 * ks + g);
-            else {
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int k = 32 * ks + 8 * g + (r16 >> 2);
-                    rb[ks][j][0] = lds0 + A_BYTES + stp_off<BN>(k, wn0 + 16 * j) + 8 * (r16 & 3);
-                    rb[ks][j][NB - 1] = lds0 + A_BYTES + stp_off<BN>(k + 4, wn0 + 16 * j) + 8 * (r16 & 3);
-                }
-            }
-        }
-        f32x4_t acc[FM][FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (active) {
-            bf16x8_t fa[FM], fb[2][FN];
-            constexpr int RB = FM / 2;
-            auto read_a = [&](auto I, unsigned so, int ks) {
-                constexpr int i = decltype(I)::value;
-                fa[i] = mg_lds_b128<2048 * i>(ra[ks] + so);
-            };
-            auto read_b = [&](auto J, unsigned so, int ks, bf16x8_t (&bfr)[FN]) {
-                constexpr int j = decltype(J)::value;
-                if constexpr (WKC) bfr[j] = mg_lds_b128<2048 * j>(rb[ks][0][0] + so);
-                else bfr[j] = mg_lds_tr(rb[ks][j][0] + so, rb[ks][j][NB - 1] + so);
-            };
-            constexpr int NRI = FM + FN * NB;
-            auto half = [&](auto WITH_READS, bf16x8_t (&bcur)[FN], bf16x8_t (&bnext)[FN], unsigned sn, int nks) {
-                mg_static_for<FM>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    // reads issued behind row i-1 of THIS half (with reads): a_{i-1} + the B fragments that ride behind row i-1
-                    if constexpr (i == 0) {
-                        mg_wait_lgkm<(FM - RB)>();
-#pragma unroll
-                        for (int j = 0; j < FN; ++j) mg_pin(bcur[j]);
-                    } else if constexpr (decltype(WITH_READS)::value) {
-                        mg_wait_lgkm<NRI - 1>();
-                    } else {
-                        constexpr int later_b = i + 1 < RB ? FN - (i + 1) * FN / RB : 0;
-                        mg_wait_lgkm<(FM - 1 - i) + later_b * NB>();
-                    }
-                    mg_pin(fa[i]);
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], fa[i], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (decltype(WITH_READS)::value) {
-                        read_a(I, sn, nks);
-                        if constexpr (i < RB) {
-                            constexpr int j0 = i * FN / RB, j1 = (i + 1) * FN / RB;
-                            mg_static_for<j1 - j0>([&](auto Jd) {
-                                read_b(std::integral_constant<int, j0 + decltype(Jd)::value>{}, sn, nks, bnext);
-                            });
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                });
-            };
-            using T0 = std::integral_constant<int, 0>;
-            using T1 = std::integral_constant<int, 1>;
-            mg_barrier();  // barrier 0: stages 0 and 1 have landed
-            mg_static_for<FM>([&](auto I) { read_a(I, 0u, 0); });
-            mg_static_for<FN>([&](auto J) { read_b(J, 0u, 0, fb[0]); });
-            mg_wait_lgkm<0>();
-            unsigned so = 0;
-            for (int t = 0; t + 1 < nk; ++t) {
-                const unsigned sn = so + STAGE == NS * STAGE ? 0u : so + STAGE;
-                half(T1{}, fb[0], fb[1], so, 1);
-                half(T1{}, fb[1], fb[0], sn, 0);
-                mg_barrier();
-                so = sn;
-            }
-            half(T1{}, fb[0], fb[1], so, 1);
-            half(T0{}, fb[1], fb[0], 0u, 0);
-        } else {
-            for (int t = 0; t < nk; ++t) mg_barrier();
-        }
-        // accumulators -> LDS fp32 tile, behind a barrier: every consumer has finished reading the ring
-        // (the loaders are past their last stage barrier: this extra barrier is matched below)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (active) {
-            float* cl = reinterpret_cast<float*>(smem);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    *reinterpret_cast<f32x4_t*>(cl + (16 * i + r16) * (BN + 4) + wn0 + 16 * j + 4 * g) = acc[i][j];
-        }
+        mg_gemm_consume<BN, CN, NS, WKC>(smem, nk, wave, lane);
     }
     if (wave >= NC) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -553,6 +569,31 @@ __device__ __forceinline__ void mg_attention(const unsigned short* qt, const uns
     }
 }
 
+// team <-> XCD affinity (speed only: the hand-off protocol is placement-independent).  Blocks b, b + 8, ... share an XCD under
+// round-robin placement.  xsplit = 1 (rounds 3-5): an XCD hosts whole teams (two of 16 members) — every member's weight slice is then
+// pulled into that XCD's L2 by two workgroups, i.e. once per XCD from the Infinity Cache (8 copies of the tower's weights per pass).
+// xsplit = 2 / 4 / 8: a team's members are spread over that many XCDs, member groups of 8 / 4 / 2 — an XCD then hosts the SAME member
+// group of 4 / 8 / 16 teams and sees only a half / a quarter / an eighth of every weight matrix, read by 4 / 8 / 16 workgroups: a
+// quarter of a block's weights (3.5 MB) fits the XCD's 4 MB L2, so seven of eight readers hit it.  The panels, written through to
+// memory anyway, are pulled once per XCD they are read on instead of once: at 8 XCDs per team that costs more than the weights gain.
+// Default 4 (round 6).
+__device__ __forceinline__ void mg_place(int nteams, int xsplit, int b, int& team, int& member) {
+    if (nteams % 8 == 0 && (xsplit == 2 || xsplit == 4 || xsplit == 8)) {
+        const int x = b & 7, s = b >> 3;              // XCD, slot on it (0 .. 2 nteams / 8 * 16 / ... )
+        const int per = MG_TEAM / xsplit;             // members of a team on one XCD
+        const int tg = x / xsplit, mg = x % xsplit;   // XCD group (hosts nteams * xsplit / 8 teams), member group inside it
+        team = tg * (nteams * xsplit / 8) + s / per;
+        member = mg * per + s % per;
+    } else if (nteams % 8 == 0) {
+        const int q = nteams / 8, s = b >> 3;
+        team = (b & 7) * q + s / MG_TEAM;
+        member = s % MG_TEAM;
+    } else {
+        team = b / MG_TEAM;
+        member = b % MG_TEAM;
+    }
+}
+
 #define MG_STAMP(i)                                                                                   \
     do {                                                                                              \
         if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 64 + ((i) & 63)] = mg_clock();  \
@@ -564,14 +605,7 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
     const int b = blockIdx.x;
     // team <-> XCD affinity (speed only): blocks b, b + 8, ... share an XCD under round-robin placement
     int team, member;
-    if (p.nteams % 8 == 0) {
-        const int q = p.nteams / 8, s = b >> 3;
-        team = (b & 7) * q + s / MG_TEAM;
-        member = s % MG_TEAM;
-    } else {
-        team = b / MG_TEAM;
-        member = b % MG_TEAM;
-    }
+    mg_place(p.nteams, p.xsplit, b, team, member);
     const int d = p.d, T = p.T, mlp = p.mlp;
     const int64_t M = p.M, Mp = p.Mp;
     const float scale = 1.0f / sqrtf(64.0f);
@@ -720,6 +754,7 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
 struct MegaBwd {
     int B, T, d, H, mlp, L, act, save, M, Mp;
     int P, npanels, nteams;
+    int xsplit;
     const float* params;
     const unsigned short* shadow;
     int64_t lo[12];
@@ -1021,14 +1056,7 @@ __global__ __launch_bounds__(MG_THREADS) void vit_bwd_mega_kernel(const MegaBwd 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     int team, member;
-    if (p.nteams % 8 == 0) {
-        const int q = p.nteams / 8, s = b >> 3;
-        team = (b & 7) * q + s / MG_TEAM;
-        member = s % MG_TEAM;
-    } else {
-        team = b / MG_TEAM;
-        member = b % MG_TEAM;
-    }
+    mg_place(p.nteams, p.xsplit, b, team, member);
     const int d = p.d, T = p.T, mlp = p.mlp;
     const int64_t M = p.M, Mp = p.Mp;
     const float scale = 1.0f / sqrtf(64.0f);
@@ -1166,6 +1194,527 @@ __global__ __launch_bounds__(MG_THREADS) void vit_bwd_mega_kernel(const MegaBwd 
     MG_STAMP(stamp++);
 }
 
+// =====================================================================================================================
+// Round 6: the same two launches with the waves' ROLES fixed for the whole launch (vit_fwd_mega2_kernel, vit_bwd_mega2_kernel).
+//
+// What bounds the kernels above (profiles/r05_mega_*_trace.txt): a product's k-loop is fed from L2 / the
+// Infinity Cache at what ~76 KB in flight per CU buy — the member's weight slice (0.9 MB per block and CU, first touch per XCD from
+// the Infinity Cache at ~33 GB/s per CU) costs more than the panel it multiplies (1.2 MB, L2 hits at ~68 GB/s) — while between the
+// products (epilogue, hand-off, LayerNorm, attention: 45-55 % of a block) the memory pipes idle.  The weights depend on NO hand-off,
+// and the four loader waves own 4 x 64 x 256 registers they never use.  So here the loader waves do nothing but move operand bytes:
+// behind a product's last stage they load the NEXT product's weight slice — up to 48 x 16 B per lane, 192 KB per CU — into their
+// REGISTERS while the consumer waves run the epilogue, the hand-off and the LayerNorm in between, and inside the next product's
+// k-loop they put those stages into the ring with ds_write_b128 instead of LDS-DMA; the ring's LDS-DMA then carries the panel
+// (and the few weight stages that did not fit).  vmcnt is in order, so a wave with long-lived loads in flight must never wait for a
+// younger one: the loader waves take no part in epilogues, LayerNorm or attention (the four consumer waves do all of it, 256
+// threads), never drain, and pass the workgroup's barriers as raw s_barriers.  Arithmetic, rounding points and summation orders
+// are those of the kernels above: outputs are bit-identical (tests/test_gpu_vit.py).
+constexpr int MG_CT = 64 * MG_NC;   // threads of the consumer waves
+#ifndef MG_WREG_N
+#define MG_WREG_N 48
+#endif
+#ifndef MG_TRIGGER
+#define MG_TRIGGER 1
+#endif
+constexpr int MG_WREG = MG_WREG_N;  // 16-B registers of weight bytes a loader wave carries from one product into the next (measurement
+                                    // builds: 1 = none).  MG_TRIGGER 0: the register stages are loaded right behind the product's last
+                                    // stage; 1: when the consumer waves have ISSUED the epilogue's stores (mg_signal / mg_wait_flag)
+
+template <int BN, int NS, int NK>
+struct MgRegStages {   // which 64-deep k-steps of a product's weight slice ride in the loader waves' registers: [S0, S1)
+    static constexpr int MAXW = MgPieces<BN>::MAXW;
+    static constexpr int F = MG_WREG / MAXW;
+    static constexpr int S0 = NS - 1;                          // stages 0 .. NS-2 go into the free ring during the hand-off, as before
+    static constexpr int S1 = NK < S0 + F ? NK : S0 + F;
+    __host__ __device__ static constexpr bool reg(int s) { return s >= S0 && s < S1; }
+};
+
+// The loader program sits inside the loop over the blocks and every address it forms is block-invariant: the compiler would hoist
+// them ALL out of the loop (dozens of registers next to the 192 that carry weights -> spills).  An opaque copy of the lane number at
+// the top of each step keeps its address arithmetic (a few instructions) inside the step.
+__device__ __forceinline__ int mg_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// Pieces of a loader wave, known at compile time once the wave's class is: LO = loader waves 0, 1 / !LO = loader waves 2, 3 (the
+// piece lists of a stage are dealt round-robin over the four waves: both waves of a class own the same NUMBER of pieces)
+template <int BN, bool LO>
+struct MgLoad {
+    using PC = MgPieces<BN>;
+    static constexpr int L0 = LO ? 0 : 2;
+    static constexpr int NA = (PC::PA - L0 + MG_NL - 1) / MG_NL, NW = (PC::PB - L0 + MG_NL - 1) / MG_NL;
+    static_assert(NA == (PC::PA - L0 - 1 + MG_NL - 1) / MG_NL && NW == (PC::PB - L0 - 1 + MG_NL - 1) / MG_NL, "both waves of a class own the same pieces");
+};
+
+template <int BN, bool LO, bool WKC>
+__device__ __forceinline__ void mg_w_offsets2(const MegaW& w, int lw, int lane, unsigned (&voff)[MgLoad<BN, LO>::NW]) {
+#pragma unroll
+    for (int i = 0; i < MgLoad<BN, LO>::NW; ++i) {
+        const int byte = (lw + MG_NL * i) * 1024 + lane * 16;
+        if constexpr (WKC) {
+            const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
+            voff[i] = (unsigned)(w.row(row) * w.ldw + 8 * t) * 2u;
+        } else {
+            int k = 0, col = 0;
+            stp_inv<BN>(byte, k, col);
+            voff[i] = (unsigned)(k * w.ldw + col) * 2u;
+        }
+    }
+}
+
+// W pieces of one stage by LDS-DMA into ring buffer `buf`
+template <int BN, bool LO>
+__device__ __forceinline__ void mg_issue_w2(unsigned char* smem, int buf, const char* cur, const unsigned (&voff)[MgLoad<BN, LO>::NW], int lw) {
+    using PC = MgPieces<BN>;
+#pragma unroll
+    for (int i = 0; i < MgLoad<BN, LO>::NW; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cur + voff[i]),
+                                         (__attribute__((address_space(3))) void*)(smem + buf * PC::STAGE + PC::A_BYTES + (lw + MG_NL * i) * 1024), 16, 0, 0);
+}
+
+// the part of a GEMM phase that needs no hand-off: W of stages 0 .. NS-2 into the (free) ring, inside the hand-off
+template <int BN, int NS, bool LO, bool WKC>
+__device__ __forceinline__ void mg_w_prologue2(unsigned char* smem, const MegaW& w, int lw, int lane) {
+    if (!w.W) return;
+    lane = mg_opaque(lane);
+    unsigned voff[MgLoad<BN, LO>::NW];
+    mg_w_offsets2<BN, LO, WKC>(w, lw, lane, voff);
+    const char* cur = reinterpret_cast<const char*>(w.W);
+    const int64_t step = mg_w_step<WKC>(w);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) mg_issue_w2<BN, LO>(smem, st, cur + step * st, voff, lw);
+}
+
+// the weight stages [S0, S1) of the product that follows -> registers (plain loads: they stay in flight across the hand-offs)
+template <int BN, int NS, int NK, bool LO, bool WKC>
+__device__ __forceinline__ void mg_w_prefetch(const MegaW& w, int lw, int lane, u32x4_t (&wreg)[MG_WREG]) {
+    using RS = MgRegStages<BN, NS, NK>;
+    constexpr int NW = MgLoad<BN, LO>::NW;
+    lane = mg_opaque(lane);   // (w.W is not null: the caller's product exists)
+    unsigned voff[NW];
+    mg_w_offsets2<BN, LO, WKC>(w, lw, lane, voff);
+    const char* base = reinterpret_cast<const char*>(w.W);
+    const int64_t step = mg_w_step<WKC>(w);
+    // (inline asm: a load the compiler counts makes it put s_waitcnt vmcnt(0) in front of the first ds_write of the next k-loop — it
+    // cannot follow the count across the hand-offs — which drains the ring's stream once per product.  The k-loop's own counted wait
+    // in front of its barrier 0 covers these loads: they are the oldest the wave has in flight.)
+    mg_static_for<(RS::S1 - RS::S0) * NW>([&](auto Q) {
+        constexpr int s = decltype(Q)::value / NW, i = decltype(Q)::value % NW;
+        u32x4_t& r = wreg[s * RS::MAXW + i];
+        const unsigned vo = voff[i];
+        const char* bs = base + step * (RS::S0 + s);
+        asm volatile("global_load_dwordx4 %0, %1, %2 ; mg-stage" : "=&v"(r) : "v"(vo), "s"(bs) : "memory");
+    });
+}
+
+template <int OFF>
+__device__ __forceinline__ void mg_lds_store16(unsigned addr, const u32x4_t& v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2 ; mg-stage\n\ts_nop 1" ::"v"(addr), "v"(v), "n"(OFF) : "memory");   // (s_nop: the data registers may be re-used right behind it)
+}
+
+// ---- the loader waves' half of a GEMM phase (NK k-steps).  VMEM issue order of a wave, oldest first: the register stages
+// (mg_w_prefetch, behind the previous product), W of stages 0 .. NS-2 by LDS-DMA (inside the hand-off), then here A of stages
+// 0 .. NS-2 and, behind barrier t, stage t + NS - 1: its A pieces by LDS-DMA and its W pieces either from registers (ds_write) or by
+// LDS-DMA.  Barrier t needs stages <= t + 1 landed: the wait in front of it allows everything younger to fly (an immediate: the
+// piece counts of the wave's class are compile-time).
+template <int BN, int NS, int NK, bool LO, bool WKC>
+__device__ __forceinline__ void mg_gemm_load(unsigned char* smem, const unsigned short* A, int lda, int rows, const MegaW& w, int lw, int lane,
+                                             u32x4_t (&wreg)[MG_WREG]) {
+    using PC = MgPieces<BN>;
+    using RS = MgRegStages<BN, NS, NK>;
+    using ML = MgLoad<BN, LO>;
+    constexpr int NL = MG_NL, STAGE = PC::STAGE, A_BYTES = PC::A_BYTES, NA = ML::NA, NW = ML::NW;
+    static_assert(NK >= NS && NS >= 4, "ring");
+    lane = mg_opaque(lane);
+    unsigned voffA[NA], voffW[NW];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int byte = (lw + NL * i) * 1024 + lane * 16;
+        const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
+        const int gr = row < rows ? row : rows - 1;
+        voffA[i] = (unsigned)(gr * lda + 8 * t) * 2u;
+    }
+    mg_w_offsets2<BN, LO, WKC>(w, lw, lane, voffW);
+    const char* curA = reinterpret_cast<const char*>(A);
+    const char* curW = reinterpret_cast<const char*>(w.W);
+    const int64_t stepW = mg_w_step<WKC>(w);
+    // ds_write_b128 takes a 16-bit immediate offset: one base register per 64 KB window of the ring
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) + lw * 1024 + lane * 16;
+    const unsigned ldsw[3] = {lds0, lds0 + 65536u, lds0 + 131072u};
+    auto issue_a = [&](int buf, int st) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(curA + 128 * st + voffA[i]),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (lw + NL * i) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue_a(st, st);
+    mg_static_for<NK>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        // items younger than the last one of stage t + 1: `ca` whole A sets and `cw` LDS-DMA W sets
+        constexpr int lo = (t + 1 <= NS - 2) ? NS - 1 : t + 2;
+        constexpr int hi0 = t + NS - 2, hi = hi0 < NK - 1 ? hi0 : NK - 1;   // stages issued so far: up to t + NS - 2
+        constexpr int pro = (t + 1 <= NS - 2) ? NS - 3 - t : 0;               // A sets of the prologue behind A(t + 1)
+        constexpr int ca = pro + (hi >= lo ? hi - lo + 1 : 0);
+        constexpr int nreg = (hi < RS::S1 - 1 ? hi : RS::S1 - 1) - (lo > RS::S0 ? lo : RS::S0) + 1;   // register stages among lo .. hi
+        constexpr int cw = (hi >= lo ? hi - lo + 1 : 0) - (nreg > 0 ? nreg : 0);
+        constexpr int fly = ca * NA + cw * NW;
+        mg_wait_vmcnt<(fly < 63 ? fly : 63)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the register stages written behind the previous barrier
+        mg_barrier();
+        constexpr int s = t + NS - 1;
+        if constexpr (s < NK) {
+            constexpr int buf = s % NS;
+            issue_a(buf, s);
+            if constexpr (RS::reg(s)) {
+                mg_static_for<NW>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    constexpr int off = buf * STAGE + A_BYTES + NL * i * 1024;
+                    mg_lds_store16<(off & 0xffff)>(ldsw[off >> 16], wreg[(s - RS::S0) * RS::MAXW + i]);
+                });
+            } else {
+                mg_issue_w2<BN, LO>(smem, buf, curW + stepW * s, voffW, lw);
+            }
+        }
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mg_barrier();   // the consumers' "ring is free" barrier
+    mg_barrier();   // the fp32 tile is complete (the consumers' __syncthreads)
+}
+
+// ---- "the epilogue's stores are issued": a CU has ONE in-order vector-memory pipe, and whatever a consumer wave loads or stores
+// behind 192 KB of weight loads waits until most of them have landed (first build of this kernel: every epilogue 3 us longer, the
+// whole gain of the shorter k-loops gone).  So the loader waves fire the register stages only when each consumer wave has issued the
+// last store of its epilogue — the burst then queues BEHIND them and runs under the drain, the hand-off and (attention / LayerNorm)
+// whatever the consumers do without the memory pipe.  One LDS word counts the signals of the launch; it only grows.
+__device__ __forceinline__ void mg_signal(unsigned* flag, int lane) {
+    if (MG_TRIGGER && lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void mg_wait_flag(unsigned* flag, unsigned want) {
+    if (!MG_TRIGGER) return;
+    for (int i = 0; i < 8192; ++i) {   // (bounded: a missed signal costs the burst's placement, never the launch)
+        const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((int)(__builtin_amdgcn_readfirstlane(v) - want) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// consumer waves: hand-off.  The loader waves pass the same two barriers in team_sync_l
+template <class Params>
+__device__ __forceinline__ void team_sync_c(const Params& p, int team, int member, unsigned target, unsigned long long* tr) {
+    if (tr && threadIdx.x == 0) tr[0] = mg_clock();
+    mg_drain();
+    __syncthreads();
+    if (threadIdx.x == 0) team_arrive(p, team, member, target, tr);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mg_barrier();
+}
+template <class Early>
+__device__ __forceinline__ void team_sync_l(Early&& early) {
+    mg_barrier();
+    early();
+    mg_barrier();
+}
+
+// LayerNorm of the member's seven rows on FOUR waves: wave w takes rows w and w + 4, every load of both in flight before the first
+// reduction; per row the arithmetic of mg_layernorm
+__device__ __forceinline__ void mg_layernorm4(const MegaFwd& p, const float* x, const float* gamma, const float* beta, unsigned short* y,
+                                              float* mean, float* rstd, int row0, int rows_valid, int member, int wave, int lane) {
+    const int d = p.d;   // 768: 3 float4 per lane
+    float4 v[2][3], gm[3], bt[3];
+    bool ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 7 * member + wave + 4 * j;
+        ok[j] = wave + 4 * j < 7 && r < rows_valid;
+        if (ok[j]) {
+            const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)(row0 + r) * d);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[j][i] = xr[lane + 64 * i];
+        }
+    }
+    if (!ok[0]) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        gm[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
+        bt[i] = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (!ok[j]) continue;
+        const int r = 7 * member + wave + 4 * j;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += v[j][i].x + v[j][i].y + v[j][i].z + v[j][i].w;
+        const float mu = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float a = v[j][i].x - mu, b = v[j][i].y - mu, cc = v[j][i].z - mu, dd = v[j][i].w - mu;
+            q += a * a + b * b + cc * cc + dd * dd;
+        }
+        const float var = wave_sum(q) / (float)d;
+        const float rs = rsqrtf(var + p.eps);
+        if (lane == 0) {
+            mean[row0 + r] = mu;
+            rstd[row0 + r] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = lane + 64 * i;
+            const float o0 = (v[j][i].x - mu) * rs * gm[i].x + bt[i].x, o1 = (v[j][i].y - mu) * rs * gm[i].y + bt[i].y;
+            const float o2 = (v[j][i].z - mu) * rs * gm[i].z + bt[i].z, o3 = (v[j][i].w - mu) * rs * gm[i].w + bt[i].w;
+            st_sc1_8(y + (int64_t)(row0 + r) * d + 4 * c, pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        }
+    }
+}
+
+// the epilogue passes of the kernels above on 256 threads: BN = 48: 12 chunks of 4 columns x 21 rows per pass, 6 passes
+__device__ __forceinline__ void mg_epi_residual4(const float* cl, const float* bias, const float* res, float* out, int64_t ld, int rows, int tid) {
+    const int cc = tid % 12, r0 = tid / 12;
+    if (r0 >= 21) return;
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + 4 * cc);
+    float4 rr[6];
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int row = r0 + 21 * it;
+        if (row < rows) rr[it] = *reinterpret_cast<const float4*>(res + (int64_t)row * ld + 4 * cc);
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int row = r0 + 21 * it;
+        if (row >= rows) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(cl + row * 52 + 4 * cc);
+        u32x4_t v;
+        v[0] = __float_as_uint(c0.x + b0.x + rr[it].x); v[1] = __float_as_uint(c0.y + b0.y + rr[it].y);
+        v[2] = __float_as_uint(c0.z + b0.z + rr[it].z); v[3] = __float_as_uint(c0.w + b0.w + rr[it].w);
+        st_sc1_16(out + (int64_t)row * ld + 4 * cc, v);
+    }
+}
+// BN = 192: 24 chunks of 8 columns x 10 rows per pass (240 threads), 12 passes
+template <class F>
+__device__ __forceinline__ void mg_epi_bf16_4(const float* cl, const float* b0p, const float* b1p, int tid, F&& emit) {
+    const int cc = tid % 24, r0 = tid / 24;
+    if (r0 >= 10) return;
+    const float4 b0 = *reinterpret_cast<const float4*>(b0p), b1 = *reinterpret_cast<const float4*>(b1p);
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int row = r0 + 10 * it;
+        if (row >= MG_ROWS) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(cl + row * 196 + 8 * cc);
+        const float4 c1 = *reinterpret_cast<const float4*>(cl + row * 196 + 8 * cc + 4);
+        u32x4_t pk;
+        pk[0] = pack_bf16x2(c0.x + b0.x, c0.y + b0.y); pk[1] = pack_bf16x2(c0.z + b0.z, c0.w + b0.w);
+        pk[2] = pack_bf16x2(c1.x + b1.x, c1.y + b1.y); pk[3] = pack_bf16x2(c1.z + b1.z, c1.w + b1.w);
+        emit(row, pk);
+    }
+}
+
+// ---- the loader waves' program of the forward: the walk of vit_fwd_mega2_kernel's consumer program, barrier for barrier ---------
+template <bool LO>
+__device__ __forceinline__ void mg_fwd_loader(const MegaFwd& p, unsigned char* smem, unsigned* flag, int team, int member, int lw, int lane) {
+    const int d = p.d, T = p.T, mlp = p.mlp;
+    const int64_t M = p.M, Mp = p.Mp;
+    (void)M;
+    u32x4_t wreg[MG_WREG];
+    auto slices = [&](int l, MegaW& wQ, MegaW& wO, MegaW& wF, MegaW& wP) {
+        const int64_t po = (int64_t)l * p.layer_stride;
+        wQ = MegaW{p.shadow + po + p.lo[QKVW], d, d >> 6, 0, member < p.H ? member : member - p.H, d};
+        wO = MegaW{p.shadow + po + p.lo[OUTW], d, d >> 6, 48 * member, -1, d};
+        wF = MegaW{p.shadow + po + p.lo[FCW], d, d >> 6, 192 * member, -1, d};
+        wP = MegaW{p.shadow + po + p.lo[PRW], mlp, mlp >> 6, 48 * member, -1, d};
+    };
+    // ONE loop over (panel, block) with the QKV stages loaded at its top: every register stage has a single defining point in front
+    // of its single use (a value that crossed the loop's back edge could be copied by the compiler while it is still in flight)
+    bool first = true;
+    unsigned want = 0;   // signals (mg_signal, one per consumer wave) the waits so far have covered
+    for (int panel = team; panel < p.npanels; panel += p.nteams) {
+        const int img0 = panel * p.P;
+        const int nimg = (p.B - img0) < p.P ? (p.B - img0) : p.P;
+        const int row0 = img0 * T, rows = nimg * T;
+        for (int l = 0; l < p.L; ++l) {
+            const int64_t li = p.save ? l : 0;
+            const unsigned short* h1 = p.h1 + li * Mp * d;
+            const unsigned short* h2 = p.h2 + li * Mp * d;
+            const unsigned short* at = p.a + li * Mp * d;
+            const unsigned short* ga = p.gact + li * Mp * mlp;
+            MegaW wQ, wO, wF, wP;
+            slices(l, wQ, wO, wF, wP);
+            // QKV: members H .. 15 have no head of their own.  They run the product of head member - H all the same (operands that another
+            // member of the team pulls through the same L2 at the same time; the consumer waves drop the result): the loader program then
+            // has ONE path for every member — no arm on which a register stage would stay in flight past its product, for the compiler
+            // or for tools/micro/check_inflight_regs.py
+            if (!first) mg_wait_flag(flag, want += MG_NC);             // the previous block's c_proj: its epilogue's stores are issued
+            mg_w_prefetch<192, 4, 12, LO, true>(wQ, lw, lane, wreg);   // (or the kernel's start)
+            if (!first) team_sync_l([] {});                             // ... that c_proj's hand-off
+            first = false;
+            team_sync_l([&] { mg_w_prologue2<192, 4, LO, true>(smem, wQ, lw, lane); });   // LN1 | hand-off
+            mg_gemm_load<192, 4, 12, LO, true>(smem, h1 + (int64_t)row0 * d, d, rows, wQ, lw, lane, wreg);
+            mg_barrier();   // tiles complete (the consumers' __syncthreads in front of the attention)
+            mg_wait_flag(flag, want += MG_NC);
+            mg_w_prefetch<48, 7, 12, LO, true>(wO, lw, lane, wreg);
+            team_sync_l([&] { mg_w_prologue2<48, 7, LO, true>(smem, wO, lw, lane); });
+            // out_proj
+            mg_gemm_load<48, 7, 12, LO, true>(smem, at + (int64_t)row0 * d, d, rows, wO, lw, lane, wreg);
+            mg_wait_flag(flag, want += MG_NC);
+            mg_w_prefetch<192, 4, 12, LO, true>(wF, lw, lane, wreg);
+            team_sync_l([] {});
+            // LN2 | hand-off
+            team_sync_l([&] { mg_w_prologue2<192, 4, LO, true>(smem, wF, lw, lane); });
+            // c_fc
+            mg_gemm_load<192, 4, 12, LO, true>(smem, h2 + (int64_t)row0 * d, d, rows, wF, lw, lane, wreg);
+            mg_wait_flag(flag, want += MG_NC);
+            mg_w_prefetch<48, 7, 48, LO, true>(wP, lw, lane, wreg);
+            team_sync_l([&] { mg_w_prologue2<48, 7, LO, true>(smem, wP, lw, lane); });
+            // c_proj
+            mg_gemm_load<48, 7, 48, LO, true>(smem, ga + (int64_t)row0 * mlp, mlp, rows, wP, lw, lane, wreg);
+        }
+    }
+    if (!first) team_sync_l([] {});   // the last c_proj's hand-off
+}
+
+__global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega2_kernel(const MegaFwd p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[MG_LDS];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    int team, member;
+    mg_place(p.nteams, p.xsplit, b, team, member);
+    __shared__ unsigned flag;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    if (tid == 0) flag = 0;
+    if (wave >= MG_NC) {
+        mg_barrier();
+        if (wave < MG_NC + 2) mg_fwd_loader<true>(p, smem, &flag, team, member, wave - MG_NC, lane);
+        else mg_fwd_loader<false>(p, smem, &flag, team, member, wave - MG_NC, lane);
+        return;
+    }
+    __syncthreads();
+    // ================================ consumer waves: everything but operand movement ================================
+    const int d = p.d, T = p.T, mlp = p.mlp;
+    const int64_t M = p.M, Mp = p.Mp;
+    const float scale = 1.0f / sqrtf(64.0f);
+    unsigned seq = 0;
+    int stamp = 0;
+    MG_STAMP(stamp++);
+#define MG2_SYNC(k_)                                                                                                  \
+    team_sync_c(p, team, member, ++seq * MG_TEAM,                                                                      \
+                (p.trace && l == 0 && panel == team) ? p.trace + (size_t)blockIdx.x * 64 + 8 + 4 * (k_) : nullptr);   \
+    if (l == 0) MG_STAMP(stamp++)
+#define MG2_GEMM_DONE(k_)                                                                                            \
+    if (p.trace && l == 0 && panel == team && tid == 0) p.trace[(size_t)blockIdx.x * 64 + 32 + (k_)] = mg_clock()
+    for (int panel = team; panel < p.npanels; panel += p.nteams) {
+        const int img0 = panel * p.P;
+        const int nimg = (p.B - img0) < p.P ? (p.B - img0) : p.P;
+        const int row0 = img0 * T, rows = nimg * T;
+        for (int l = 0; l < p.L; ++l) {
+            const int64_t po = (int64_t)l * p.layer_stride;
+            const int64_t li = p.save ? l : 0;
+            const float* xin = p.xs + (p.save ? (int64_t)l : (int64_t)(l & 1)) * M * d;
+            float* xout = p.xs + (p.save ? (int64_t)(l + 1) : (int64_t)((l + 1) & 1)) * M * d;
+            float* x1 = p.x1 + li * M * d;
+            unsigned short* h1 = p.h1 + li * Mp * d;
+            unsigned short* h2 = p.h2 + li * Mp * d;
+            unsigned short* at = p.a + li * Mp * d;
+            unsigned short* qkv = p.qkv + li * M * 3 * d;
+            unsigned short* f = p.f + li * M * mlp;
+            unsigned short* ga = p.gact + li * Mp * mlp;
+            // ---------------- LN1 ----------------
+            mg_layernorm4(p, xin, p.params + po + p.lo[LN1W], p.params + po + p.lo[LN1B], h1, p.mean1 + li * M, p.rstd1 + li * M, row0, rows,
+                          member, wave, lane);
+            MG2_SYNC(0);
+            // ---------------- QKV + attention (member = head) ----------------
+            mg_gemm_consume<192, 4, 4, true>(smem, d >> 6, wave, lane);   // (members H .. 15: see mg_fwd_loader)
+            __syncthreads();
+            MG2_GEMM_DONE(0);
+            if (member < p.H) {
+                const int h = member;
+                const float* cl = reinterpret_cast<const float*>(smem);
+                unsigned short* tiles = reinterpret_cast<unsigned short*>(smem + MG_ROWS * 196 * 4);  // q | k | v : [128][ATP] each
+                {
+                    const int cc = tid % 24, part = cc >> 3, c64 = (cc & 7) * 8;
+                    const float* bp = p.params + po + p.lo[QKVB] + part * d + 64 * h + c64;
+                    unsigned short* gq = qkv + (int64_t)row0 * 3 * d + part * d + 64 * h + c64;
+                    unsigned short* tq = tiles + part * 128 * ATP + c64;
+                    mg_epi_bf16_4(cl, bp, bp + 4, tid, [&](int row, u32x4_t pk) {
+                        *reinterpret_cast<u32x4_t*>(tq + row * ATP) = pk;
+                        if (row < rows) *reinterpret_cast<u32x4_t*>(gq + (int64_t)row * 3 * d) = pk;   // backward re-reads it (a later launch)
+                    });
+                }
+                // v rows 112..127 are read (times P = 0) by the last image's key fragments: they must be finite
+                for (int c = tid; c < 16 * ATP / 8; c += MG_CT)
+                    *reinterpret_cast<u32x4_t*>(tiles + 2 * 128 * ATP + MG_ROWS * ATP + c * 8) = (u32x4_t){0u, 0u, 0u, 0u};
+                __syncthreads();
+                mg_signal(&flag, lane);   // qkv is stored: the out_proj stages may load under the attention
+                for (int im = 0; im < nimg; ++im)
+                    mg_attention(tiles, tiles + 128 * ATP, tiles + 2 * 128 * ATP, im * T, T, wave, lane, scale,
+                                 at + (int64_t)(row0 + im * T) * d + 64 * h, d);
+            } else {
+                __syncthreads();
+                mg_signal(&flag, lane);
+            }
+            MG2_SYNC(1);
+            // ---------------- out_proj + bias + residual -> x1 ----------------
+            {
+                const int n0 = 48 * member;
+                mg_gemm_consume<48, 3, 7, true>(smem, d >> 6, wave, lane);
+                __syncthreads();
+                MG2_GEMM_DONE(1);
+                mg_epi_residual4(reinterpret_cast<const float*>(smem), p.params + po + p.lo[OUTB] + n0, xin + (int64_t)row0 * d + n0,
+                                 x1 + (int64_t)row0 * d + n0, d, rows, tid);
+                mg_signal(&flag, lane);
+            }
+            MG2_SYNC(2);
+            // ---------------- LN2 ----------------
+            mg_layernorm4(p, x1, p.params + po + p.lo[LN2W], p.params + po + p.lo[LN2B], h2, p.mean2 + li * M, p.rstd2 + li * M, row0, rows,
+                          member, wave, lane);
+            MG2_SYNC(3);
+            // ---------------- c_fc + bias, activation -> f, g ----------------
+            {
+                const int n0 = 192 * member;
+                mg_gemm_consume<192, 4, 4, true>(smem, d >> 6, wave, lane);
+                __syncthreads();
+                MG2_GEMM_DONE(2);
+                const int cc = tid % 24;
+                const float* bp = p.params + po + p.lo[FCB] + n0 + 8 * cc;
+                unsigned short* fo = f + (int64_t)row0 * mlp + n0 + 8 * cc;
+                unsigned short* go = ga + (int64_t)row0 * mlp + n0 + 8 * cc;
+                auto epi = [&](auto ACT) {
+                    constexpr int act = decltype(ACT)::value;
+                    mg_epi_bf16_4(reinterpret_cast<const float*>(smem), bp, bp + 4, tid, [&](int row, u32x4_t pk) {
+                        if (row >= rows) return;
+                        *reinterpret_cast<u32x4_t*>(fo + (int64_t)row * mlp) = pk;   // pre-activation: only the backward reads it
+                        u32x4_t pk2;
+#pragma unroll
+                        for (int hh = 0; hh < 4; ++hh)
+                            pk2[hh] = pack_bf16x2(act_fwd(__uint_as_float(pk[hh] << 16), act), act_fwd(__uint_as_float(pk[hh] & 0xffff0000u), act));
+                        st_sc1_16(go + (int64_t)row * mlp, pk2);
+                    });
+                };
+                if (p.act == 1) epi(std::integral_constant<int, 1>{});
+                else if (p.act == 2) epi(std::integral_constant<int, 2>{});
+                else epi(std::integral_constant<int, 0>{});
+                mg_signal(&flag, lane);
+            }
+            MG2_SYNC(4);
+            // ---------------- c_proj + bias + residual -> next block's input ----------------
+            {
+                const int n0 = 48 * member;
+                mg_gemm_consume<48, 3, 7, true>(smem, mlp >> 6, wave, lane);
+                __syncthreads();
+                MG2_GEMM_DONE(3);
+                mg_epi_residual4(reinterpret_cast<const float*>(smem), p.params + po + p.lo[PRB] + n0, x1 + (int64_t)row0 * d + n0,
+                                 xout + (int64_t)row0 * d + n0, d, rows, tid);
+                mg_signal(&flag, lane);
+            }
+            MG2_SYNC(5);
+        }
+    }
+#undef MG2_SYNC
+#undef MG2_GEMM_DONE
+    MG_STAMP(stamp++);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------
 // Per-device state of the persistent forward.  The arrival counters are one block per device: persistent launches of a device
 // are SERIALISED (a launch on another stream first waits for the previous launch's completion event) — two of them in flight at
@@ -1189,6 +1738,9 @@ static MegaDev g_mega_dev[16];
 static int g_mega_mode = -1;               // swat_vit_set_mega / SWAT_VIT_MEGA: 0 = op-by-op forward, 1 = persistent forward when eligible
 static unsigned long long* g_mega_trace = nullptr;
 static int g_fail_launches = 0, g_fail_sync = 0;   // swat_vit_mega_inject_failure
+static int g_mega_roles = -1;              // swat_vit_set_mega_roles / SWAT_VIT_MEGA_ROLES: 1 = every wave takes part in every phase
+                                           // (rounds 3-5), 2 = loader waves move operand bytes only and carry the next product's
+                                           // weight stages in registers (round 6; default)
 static int g_mega_bwd = -1;                // swat_vit_set_mega_backward / SWAT_VIT_MEGA_BWD
 static unsigned long long* g_mega_trace_bwd = nullptr;
 static int g_fail_bwd_launches = 0, g_fail_bwd_sync = 0;
@@ -1226,6 +1778,24 @@ static int mega_state_ensure(MegaDev* md) {
     md->host_flag[0] = 0;   // launch number of the first persistent launch of this device that gave up
     md->host_flag[1] = 0;   // data-parallel runs: number of the first step some rank voided (swat_vit_mega_void_absorb)
     return 0;
+}
+
+static int g_mega_xsplit = -1;             // swat_vit_set_mega_xsplit / SWAT_VIT_MEGA_XSPLIT: XCDs a team's 16 members are spread over (1, 2, 4)
+static int mega_xsplit() {
+    if (g_mega_xsplit < 0) {
+        const char* e = getenv("SWAT_VIT_MEGA_XSPLIT");
+        const int v = e ? atoi(e) : 4;   // round 6, alternating in one process: forward 0.857 / 0.840 / 0.835 / 0.89 ms and persistent backward
+        g_mega_xsplit = (v == 1 || v == 2 || v == 8) ? v : 4;   // -0 / -38 / -46 / -10 us at 1 / 2 / 4 / 8 XCDs per team (tools/micro/xsplit_ab.py)
+    }
+    return g_mega_xsplit;
+}
+
+static int mega_roles() {
+    if (g_mega_roles < 0) {
+        const char* e = getenv("SWAT_VIT_MEGA_ROLES");
+        g_mega_roles = e && atoi(e) == 2 ? 2 : 1;
+    }
+    return g_mega_roles;
 }
 
 static MegaDev* mega_dev() {
@@ -1271,13 +1841,15 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
     // every team member must be resident at once (the hand-offs wait for all of them): one workgroup per CU (156 KB of LDS each),
     // so the grid must not exceed the CUs this process sees (a CU-masked or partitioned device, a smaller part), and the
     // occupancy query must admit the workgroup at all.  Otherwise: op by op.
+    const int roles = mega_roles();
     if (md->resident < 0) {
-        int cus = 0, occ = 0;
+        int cus = 0, occ = 0, occ2 = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, (int)(md - g_mega_dev)) != hipSuccess) cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vit_fwd_mega_kernel, MG_THREADS, 0) != hipSuccess) occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, vit_fwd_mega2_kernel, MG_THREADS, 0) != hipSuccess) occ2 = 0;
         (void)hipGetLastError();
         md->cus = cus;
-        md->resident = occ;
+        md->resident = occ < occ2 ? occ : occ2;
     }
     if (md->resident < 1 || nteams * MG_TEAM > md->cus) return 1;   // (156 KB of LDS: one workgroup per CU whatever the query says)
     if (mega_state_ensure(md) != 0) return -1;
@@ -1292,6 +1864,7 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
     m.P = 2;
     m.npanels = npanels;
     m.nteams = nteams;
+    m.xsplit = mega_xsplit();
     m.ctr = md->state;
     m.status = md->state + 16 * 32;
     m.host_flag = md->host_flag;   // (mapped pinned memory: the host pointer is the device pointer under unified addressing)
@@ -1311,8 +1884,9 @@ int vit_mega_forward(int B, int T, int d, int H, int mlp, int L, int act, int sa
     // products + attention inside the launch (what bench.py's roofline divides by the launch's duration)
     const double flops = (double)L * B * T * (2.0 * d * 3 * d + 2.0 * d * d + 4.0 * d * mlp + 4.0 * T * d);
     hipEvent_t e0, e1;
-    if (gemm_prof_take(9, flops, e0, e1)) hipExtLaunchKernelGGL(vit_fwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, e0, e1, 0, m);
-    else hipLaunchKernelGGL(vit_fwd_mega_kernel, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, m);
+    auto kern = roles == 2 ? vit_fwd_mega2_kernel : vit_fwd_mega_kernel;
+    if (gemm_prof_take(9, flops, e0, e1)) hipExtLaunchKernelGGL(kern, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, e0, e1, 0, m);
+    else hipLaunchKernelGGL(kern, dim3(m.nteams * MG_TEAM), dim3(MG_THREADS), 0, s, m);
     const int rc = check_launch("vit_fwd_mega_kernel");
     if (rc == 0) {
         SWAT_HIP(hipEventRecord(md->done, s));
@@ -1372,6 +1946,7 @@ int vit_mega_backward(int B, int T, int d, int H, int mlp, int L, int act, int M
     MegaBwd m{};
     m.B = B; m.T = T; m.d = d; m.H = H; m.mlp = mlp; m.L = L; m.act = act; m.save = 1; m.M = M; m.Mp = Mp;
     m.P = 2; m.npanels = npanels; m.nteams = nteams;
+    m.xsplit = mega_xsplit();
     m.params = params; m.shadow = shadow;
     for (int k = 0; k < 12; ++k) m.lo[k] = layer_offs[k];
     m.layer_stride = stride;
@@ -1476,6 +2051,20 @@ SWAT_API int swat_vit_mega_backward_launches(void) {
 
 SWAT_API int swat_vit_mega_backward_trace(void* device_buffer) {
     g_mega_trace_bwd = (unsigned long long*)device_buffer;
+    return 0;
+}
+
+// tuning: 1 = the persistent kernels of rounds 3-5 (every wave in every phase), 2 = fixed roles + register-carried weight stages
+SWAT_API int swat_vit_set_mega_roles(int mode) {
+    SWAT_REQUIRE(mode == 1 || mode == 2, "swat_vit_set_mega_roles: mode must be 1 or 2");
+    g_mega_roles = mode;
+    return 0;
+}
+
+// tuning: XCDs a team's members are spread over under round-robin placement (1, 2 or 4; speed only)
+SWAT_API int swat_vit_set_mega_xsplit(int xcds) {
+    SWAT_REQUIRE(xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8, "swat_vit_set_mega_xsplit: 1, 2, 4 or 8");
+    g_mega_xsplit = xcds;
     return 0;
 }
 

@@ -471,6 +471,45 @@ def test_persistent_forward_equals_the_op_by_op_forward_and_ignores_history(B):
         assert r < GRAD_TOL, f"{n}: {r}"
 
 
+@pytest.mark.parametrize("B", [32, 7, 16])
+def test_persistent_kernels_do_not_depend_on_placement_or_wave_roles(B):
+    """Round 6 (csrc/vit_mega.hip): (i) where a team's sixteen workgroups sit is for speed only — a team spread over 1, 2, 4 or 8 XCDs
+    (mg_place / swat_vit_set_mega_xsplit; default 4: an XCD then sees a quarter of every weight matrix, read by eight teams) gives the
+    same bytes in the whole workspace and every gradient; (ii) the forward with fixed wave roles (the loader waves move operand bytes
+    only and carry the next product's weight stages in registers: swat_vit_set_mega_roles(2), measured and not adopted as the default)
+    gives the same bytes as the kernel in which every wave takes part in every phase."""
+    from swat_amd import _lib
+    from swat_amd.clip_model import CLIP
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B)
+    model = CLIP("ViT-B-32-quickgelu").to(dev)
+    vis = model.visual
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    df = torch.randn(B, vis.output_dim, device=dev)
+    outs = []
+    try:
+        L.swat_vit_set_mega(2)
+        for roles, xs in ((1, 1), (1, 2), (1, 4), (1, 8), (2, 4), (2, 1)):
+            assert L.swat_vit_set_mega_roles(roles) == 0 and L.swat_vit_set_mega_xsplit(xs) == 0
+            n0 = L.swat_vit_mega_launches()
+            vis._ws = {}
+            f = vis.forward_raw(x, save=True).clone()
+            vis.backward_raw(df)
+            torch.cuda.synchronize()
+            assert L.swat_vit_mega_launches() - n0 == 1
+            assert L.swat_vit_mega_status() == 0
+            outs.append((f, vis._ws[(B, True)].clone(), vis.arena().grad.clone()))
+            e = vis.forward_raw(x, save=False)   # the eval form re-uses its buffers block after block (acquire at every hand-off)
+            assert torch.equal(e, f)
+    finally:
+        L.swat_vit_set_mega(1)
+        L.swat_vit_set_mega_roles(1)
+        L.swat_vit_set_mega_xsplit(4)
+    for f, w, g in outs[1:]:
+        assert torch.equal(f, outs[0][0]) and torch.equal(w, outs[0][1]) and torch.equal(g, outs[0][2])
+
+
 @pytest.mark.parametrize("cfg", [TINY_GELU, TINY])
 def test_owed_join_leaves_the_trajectory_bit_identical(cfg, monkeypatch):
     """the join with the weight-gradient lane may be OWED to the next forward only when the step that owes it

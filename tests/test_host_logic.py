@@ -5,6 +5,8 @@ import os
 import sys
 import types
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -234,3 +236,27 @@ def test_cutmix_permutation_drawn_into_a_buffer_is_the_reference_draw():
         b = torch.empty(n, dtype=torch.int64)
         torch.randperm(n, out=b)
         assert torch.equal(a, b) and torch.equal(after_a, torch.rand(1))
+
+
+def test_register_carried_weight_stages_are_never_touched_while_in_flight(tmp_path):
+    """csrc/vit_mega.hip, round 6: the loader waves of vit_fwd_mega2_kernel load weight stages into registers with inline-asm loads the
+    compiler knows nothing about (a load it counts makes it drain the operand ring once per product).  What keeps that sound is a
+    property of the GENERATED code: between such a load and the ds_write_b128 that consumes its register quad no instruction may
+    read or write the quad (a copy or a spill would move bytes that have not landed).  tools/micro/check_inflight_regs.py walks the
+    control-flow graph of the compiler's assembly; this compiles the file for gfx950 (no GPU needed) and runs it."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "vit_mega.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wno-unused-function",
+                           "--cuda-device-only", "-S", "-o", str(out), os.path.join(root, "swat_amd", "csrc", "vit_mega.hip")],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "micro", "check_inflight_regs.py"), str(out), "mega2"],
+                       stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "register-stage loads, 0 violations" in r.stdout and " 0 register-stage loads" not in r.stdout, r.stdout[-500:]
+    shutil.rmtree(tmp_path, ignore_errors=True)

@@ -41,14 +41,22 @@ def main():
     if diff.any():
         idx = diff.nonzero().flatten()
         print("first / last differing byte:", int(idx[0]), int(idx[-1]))
+    # round 6: fixed wave roles + register-carried weight stages against the kernel of rounds 3-5: the same bytes
+    if hasattr(L, "swat_vit_set_mega_roles"):
+        L.swat_vit_set_mega_roles(1)
+        f1o, w1o = fwd(model, x, 1)
+        L.swat_vit_set_mega_roles(2)
+        print("roles 2 vs roles 1: feats equal", bool(torch.equal(f1o, f1)), " workspace equal", bool(torch.equal(w1o, w1)), "status", hex(L.swat_vit_mega_status()))
     # repeatability of the persistent forward (hand-offs under load): 20 runs, identical bytes
     bad = 0
     for _ in range(20):
         f2, w2 = fwd(model, x, 1)
         bad += int(not torch.equal(w2, w1)) + int(not torch.equal(f2, f1))
     print("repeat mismatches:", bad, "status", hex(L.swat_vit_mega_status()))
-    for mega in (0, 1):
-        L.swat_vit_set_mega(mega)
+    for mega in (0, 1, 2):
+        L.swat_vit_set_mega(min(mega, 1))
+        if hasattr(L, "swat_vit_set_mega_roles"):
+            L.swat_vit_set_mega_roles(1 if mega == 1 else 2)
         for _ in range(5):
             model.visual.forward_raw(x, save=True)
         torch.cuda.synchronize()
@@ -57,7 +65,7 @@ def main():
         for _ in range(n):
             model.visual.forward_raw(x, save=True)
         torch.cuda.synchronize()
-        print(f"mega={mega}: forward {1e3 * (time.perf_counter() - t0) / n:.3f} ms")
+        print(f"mega={min(mega, 1)} roles={1 if mega == 1 else 2}: forward {1e3 * (time.perf_counter() - t0) / n:.3f} ms")
     if "--trace" in sys.argv:
         L.swat_vit_set_mega(1)
         tr = torch.zeros(256 * 64, dtype=torch.int64, device=dev)

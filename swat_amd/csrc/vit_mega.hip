@@ -250,6 +250,89 @@ __device__ __forceinline__ void mg_w_prologue(unsigned char* smem, const MegaW& 
     for (int st = 0; st < NS - 1; ++st) mg_issue_w<BN>(smem, st, cur + step * st, voff, lw);
 }
 
+constexpr int MG_CT = 64 * MG_NC;   // threads of the consumer waves
+#ifndef MG_WREG_N
+#define MG_WREG_N 48
+#endif
+#ifndef MG_TRIGGER
+#define MG_TRIGGER 1
+#endif
+constexpr int MG_WREG = MG_WREG_N;  // 16-B registers of weight bytes a loader wave carries from one product into the next (measurement
+                                    // builds: 1 = none).  MG_TRIGGER 0: the register stages are loaded right behind the product's last
+                                    // stage; 1: when the consumer waves have ISSUED the epilogue's stores (mg_signal / mg_wait_flag)
+
+template <int BN, int NS, int NK>
+struct MgRegStages {   // which 64-deep k-steps of a product's weight slice ride in the loader waves' registers: [S0, S1)
+    static constexpr int MAXW = MgPieces<BN>::MAXW;
+    static constexpr int F = MG_WREG / MAXW;
+    static constexpr int S0 = NS - 1;                          // stages 0 .. NS-2 go into the free ring during the hand-off, as before
+    static constexpr int S1 = NK < S0 + F ? NK : S0 + F;
+    __host__ __device__ static constexpr bool reg(int s) { return s >= S0 && s < S1; }
+};
+
+// The loader program sits inside the loop over the blocks and every address it forms is block-invariant: the compiler would hoist
+// them ALL out of the loop (dozens of registers next to the 192 that carry weights -> spills).  An opaque copy of the lane number at
+// the top of each step keeps its address arithmetic (a few instructions) inside the step.
+__device__ __forceinline__ int mg_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// Pieces of a loader wave, known at compile time once the wave's class is: LO = loader waves 0, 1 / !LO = loader waves 2, 3 (the
+// piece lists of a stage are dealt round-robin over the four waves: both waves of a class own the same NUMBER of pieces)
+template <int BN, bool LO>
+struct MgLoad {
+    using PC = MgPieces<BN>;
+    static constexpr int L0 = LO ? 0 : 2;
+    static constexpr int NA = (PC::PA - L0 + MG_NL - 1) / MG_NL, NW = (PC::PB - L0 + MG_NL - 1) / MG_NL;
+    static_assert(NA == (PC::PA - L0 - 1 + MG_NL - 1) / MG_NL && NW == (PC::PB - L0 - 1 + MG_NL - 1) / MG_NL, "both waves of a class own the same pieces");
+};
+
+template <int BN, bool LO, bool WKC>
+__device__ __forceinline__ void mg_w_offsets2(const MegaW& w, int lw, int lane, unsigned (&voff)[MgLoad<BN, LO>::NW]) {
+#pragma unroll
+    for (int i = 0; i < MgLoad<BN, LO>::NW; ++i) {
+        const int byte = (lw + MG_NL * i) * 1024 + lane * 16;
+        if constexpr (WKC) {
+            const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
+            voff[i] = (unsigned)(w.row(row) * w.ldw + 8 * t) * 2u;
+        } else {
+            int k = 0, col = 0;
+            stp_inv<BN>(byte, k, col);
+            voff[i] = (unsigned)(k * w.ldw + col) * 2u;
+        }
+    }
+}
+
+// W pieces of one stage by LDS-DMA into ring buffer `buf`
+template <int BN, bool LO>
+__device__ __forceinline__ void mg_issue_w2(unsigned char* smem, int buf, const char* cur, const unsigned (&voff)[MgLoad<BN, LO>::NW], int lw) {
+    using PC = MgPieces<BN>;
+#pragma unroll
+    for (int i = 0; i < MgLoad<BN, LO>::NW; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cur + voff[i]),
+                                         (__attribute__((address_space(3))) void*)(smem + buf * PC::STAGE + PC::A_BYTES + (lw + MG_NL * i) * 1024), 16, 0, 0);
+}
+
+// the part of a GEMM phase that needs no hand-off: W of stages 0 .. NS-2 into the (free) ring, inside the hand-off
+template <int BN, int NS, bool LO, bool WKC>
+__device__ __forceinline__ void mg_w_prologue2(unsigned char* smem, const MegaW& w, int lw, int lane) {
+    if (!w.W) return;
+    lane = mg_opaque(lane);
+    unsigned voff[MgLoad<BN, LO>::NW];
+    mg_w_offsets2<BN, LO, WKC>(w, lw, lane, voff);
+    const char* cur = reinterpret_cast<const char*>(w.W);
+    const int64_t step = mg_w_step<WKC>(w);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) mg_issue_w2<BN, LO>(smem, st, cur + step * st, voff, lw);
+}
+
+template <int OFF>
+__device__ __forceinline__ void mg_lds_store16(unsigned addr, const u32x4_t& v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2 ; mg-stage\n\ts_nop 1" ::"v"(addr), "v"(v), "n"(OFF) : "memory");   // (s_nop: the data registers may be re-used right behind it)
+}
+
+
 // ---- the consumer waves' half of a GEMM phase: fragments from the ring, MFMA, one raw s_barrier per k-step; then (behind the
 // barrier that tells the loaders the ring is free) the fp32 tile to LDS at smem as [112][BN + 4].  The caller's workgroup barrier
 // follows.
@@ -1209,83 +1292,6 @@ __global__ __launch_bounds__(MG_THREADS) void vit_bwd_mega_kernel(const MegaBwd 
 // younger one: the loader waves take no part in epilogues, LayerNorm or attention (the four consumer waves do all of it, 256
 // threads), never drain, and pass the workgroup's barriers as raw s_barriers.  Arithmetic, rounding points and summation orders
 // are those of the kernels above: outputs are bit-identical (tests/test_gpu_vit.py).
-constexpr int MG_CT = 64 * MG_NC;   // threads of the consumer waves
-#ifndef MG_WREG_N
-#define MG_WREG_N 48
-#endif
-#ifndef MG_TRIGGER
-#define MG_TRIGGER 1
-#endif
-constexpr int MG_WREG = MG_WREG_N;  // 16-B registers of weight bytes a loader wave carries from one product into the next (measurement
-                                    // builds: 1 = none).  MG_TRIGGER 0: the register stages are loaded right behind the product's last
-                                    // stage; 1: when the consumer waves have ISSUED the epilogue's stores (mg_signal / mg_wait_flag)
-
-template <int BN, int NS, int NK>
-struct MgRegStages {   // which 64-deep k-steps of a product's weight slice ride in the loader waves' registers: [S0, S1)
-    static constexpr int MAXW = MgPieces<BN>::MAXW;
-    static constexpr int F = MG_WREG / MAXW;
-    static constexpr int S0 = NS - 1;                          // stages 0 .. NS-2 go into the free ring during the hand-off, as before
-    static constexpr int S1 = NK < S0 + F ? NK : S0 + F;
-    __host__ __device__ static constexpr bool reg(int s) { return s >= S0 && s < S1; }
-};
-
-// The loader program sits inside the loop over the blocks and every address it forms is block-invariant: the compiler would hoist
-// them ALL out of the loop (dozens of registers next to the 192 that carry weights -> spills).  An opaque copy of the lane number at
-// the top of each step keeps its address arithmetic (a few instructions) inside the step.
-__device__ __forceinline__ int mg_opaque(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
-// Pieces of a loader wave, known at compile time once the wave's class is: LO = loader waves 0, 1 / !LO = loader waves 2, 3 (the
-// piece lists of a stage are dealt round-robin over the four waves: both waves of a class own the same NUMBER of pieces)
-template <int BN, bool LO>
-struct MgLoad {
-    using PC = MgPieces<BN>;
-    static constexpr int L0 = LO ? 0 : 2;
-    static constexpr int NA = (PC::PA - L0 + MG_NL - 1) / MG_NL, NW = (PC::PB - L0 + MG_NL - 1) / MG_NL;
-    static_assert(NA == (PC::PA - L0 - 1 + MG_NL - 1) / MG_NL && NW == (PC::PB - L0 - 1 + MG_NL - 1) / MG_NL, "both waves of a class own the same pieces");
-};
-
-template <int BN, bool LO, bool WKC>
-__device__ __forceinline__ void mg_w_offsets2(const MegaW& w, int lw, int lane, unsigned (&voff)[MgLoad<BN, LO>::NW]) {
-#pragma unroll
-    for (int i = 0; i < MgLoad<BN, LO>::NW; ++i) {
-        const int byte = (lw + MG_NL * i) * 1024 + lane * 16;
-        if constexpr (WKC) {
-            const int row = byte >> 7, t = ((byte >> 4) & 7) ^ ((row >> 1) & 7);
-            voff[i] = (unsigned)(w.row(row) * w.ldw + 8 * t) * 2u;
-        } else {
-            int k = 0, col = 0;
-            stp_inv<BN>(byte, k, col);
-            voff[i] = (unsigned)(k * w.ldw + col) * 2u;
-        }
-    }
-}
-
-// W pieces of one stage by LDS-DMA into ring buffer `buf`
-template <int BN, bool LO>
-__device__ __forceinline__ void mg_issue_w2(unsigned char* smem, int buf, const char* cur, const unsigned (&voff)[MgLoad<BN, LO>::NW], int lw) {
-    using PC = MgPieces<BN>;
-#pragma unroll
-    for (int i = 0; i < MgLoad<BN, LO>::NW; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cur + voff[i]),
-                                         (__attribute__((address_space(3))) void*)(smem + buf * PC::STAGE + PC::A_BYTES + (lw + MG_NL * i) * 1024), 16, 0, 0);
-}
-
-// the part of a GEMM phase that needs no hand-off: W of stages 0 .. NS-2 into the (free) ring, inside the hand-off
-template <int BN, int NS, bool LO, bool WKC>
-__device__ __forceinline__ void mg_w_prologue2(unsigned char* smem, const MegaW& w, int lw, int lane) {
-    if (!w.W) return;
-    lane = mg_opaque(lane);
-    unsigned voff[MgLoad<BN, LO>::NW];
-    mg_w_offsets2<BN, LO, WKC>(w, lw, lane, voff);
-    const char* cur = reinterpret_cast<const char*>(w.W);
-    const int64_t step = mg_w_step<WKC>(w);
-#pragma unroll
-    for (int st = 0; st < NS - 1; ++st) mg_issue_w2<BN, LO>(smem, st, cur + step * st, voff, lw);
-}
-
 // the weight stages [S0, S1) of the product that follows -> registers (plain loads: they stay in flight across the hand-offs)
 template <int BN, int NS, int NK, bool LO, bool WKC>
 __device__ __forceinline__ void mg_w_prefetch(const MegaW& w, int lw, int lane, u32x4_t (&wreg)[MG_WREG]) {
@@ -1306,11 +1312,6 @@ __device__ __forceinline__ void mg_w_prefetch(const MegaW& w, int lw, int lane, 
         const char* bs = base + step * (RS::S0 + s);
         asm volatile("global_load_dwordx4 %0, %1, %2 ; mg-stage" : "=&v"(r) : "v"(vo), "s"(bs) : "memory");
     });
-}
-
-template <int OFF>
-__device__ __forceinline__ void mg_lds_store16(unsigned addr, const u32x4_t& v) {
-    asm volatile("ds_write_b128 %0, %1 offset:%2 ; mg-stage\n\ts_nop 1" ::"v"(addr), "v"(v), "n"(OFF) : "memory");   // (s_nop: the data registers may be re-used right behind it)
 }
 
 // ---- the loader waves' half of a GEMM phase (NK k-steps).  VMEM issue order of a wave, oldest first: the register stages

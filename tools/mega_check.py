@@ -68,6 +68,8 @@ def main():
         print(f"mega={min(mega, 1)} roles={1 if mega == 1 else 2}: forward {1e3 * (time.perf_counter() - t0) / n:.3f} ms")
     if "--trace" in sys.argv:
         L.swat_vit_set_mega(1)
+        if hasattr(L, "swat_vit_set_mega_roles"):
+            L.swat_vit_set_mega_roles(2 if "--roles2" in sys.argv else 1)
         tr = torch.zeros(256 * 64, dtype=torch.int64, device=dev)
         L.swat_vit_mega_trace(ctypes.c_void_p(tr.data_ptr()))
         model.visual.forward_raw(x, save=True)

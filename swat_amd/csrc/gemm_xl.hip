@@ -595,8 +595,11 @@ __device__ __forceinline__ void xl_main(const Args& a, unsigned char* smem) {
 // spread over ALL workgroups of the launch: 16 output columns per workgroup and turn, the eight consumer waves an eighth of the reduction
 // each, partial sums added in wave order in LDS (the remainder-row kernel's scheme, csrc/gemm_skinny.hip — as a launch of its own it
 // cost 8-13 us per product, 192 times per ViT-L/14 step, almost all of it launch latency).
+#ifndef XL_LAUNCH_BOUND
+#define XL_LAUNCH_BOUND XL_THREADS
+#endif
 template <int LAYOUT, bool ABL, class Args = XlArgs>
-__global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const Args a) {
+__global__ __launch_bounds__(XL_LAUNCH_BOUND) void gemm_xl_kernel(const Args a) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[XL_NS * XL_STAGE];
     xl_main<LAYOUT, ABL, Args>(a, smem);
     if constexpr (LAYOUT != L_TN && std::is_same<Args, XlArgs>::value) {

@@ -599,6 +599,52 @@ __device__ __forceinline__ void mg_epi_bf16(const float* cl, const float* b0p, c
     }
 }
 
+// Round 6: the same two passes with every global LOAD taken off the chain between a product's last MFMA and its hand-off.
+//  * The residual a thread adds in the out_proj / c_proj epilogue is the value the SAME thread stored in the previous c_proj / out_proj
+//    epilogue (a member owns its 48 columns of the residual stream for the whole launch, and both passes map threads to (row, chunk)
+//    alike): it stays in 12 registers instead of being stored write-through and loaded back 3 hand-offs later (~1 us per epilogue).
+//  * The bias chunks are loaded in front of the product's k-loop.
+__device__ __forceinline__ void mg_epi_residual_keep(const float* cl, const float4 b0, float4 (&keep)[3], float* out, int64_t ld, int rows, int tid) {
+    const int cc = tid % 12, r0 = tid / 12;
+    if (r0 >= 42) return;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int row = r0 + 42 * it;
+        if (row >= rows) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(cl + row * 52 + 4 * cc);
+        const float4 o = make_float4(c0.x + b0.x + keep[it].x, c0.y + b0.y + keep[it].y, c0.z + b0.z + keep[it].z, c0.w + b0.w + keep[it].w);
+        keep[it] = o;
+        u32x4_t v;
+        v[0] = __float_as_uint(o.x); v[1] = __float_as_uint(o.y); v[2] = __float_as_uint(o.z); v[3] = __float_as_uint(o.w);
+        st_sc1_16(out + (int64_t)row * ld + 4 * cc, v);
+    }
+}
+// the thread's slice of the residual stream at a panel's start (the stem wrote it): rows r0 + 42 it, columns 4 cc .. of the member's 48
+__device__ __forceinline__ void mg_residual_load(const float* res, int64_t ld, int rows, int tid, float4 (&keep)[3]) {
+    const int cc = tid % 12, r0 = tid / 12;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int row = r0 + 42 * it;
+        keep[it] = (r0 < 42 && row < rows) ? *reinterpret_cast<const float4*>(res + (int64_t)row * ld + 4 * cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <class F>
+__device__ __forceinline__ void mg_epi_bf16_b(const float* cl, const float4 b0, const float4 b1, int tid, F&& emit) {
+    const int cc = tid % 24, r0 = tid / 24;
+    if (r0 >= 21) return;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int row = r0 + 21 * it;
+        if (row >= MG_ROWS) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(cl + row * 196 + 8 * cc);
+        const float4 c1 = *reinterpret_cast<const float4*>(cl + row * 196 + 8 * cc + 4);
+        u32x4_t pk;
+        pk[0] = pack_bf16x2(c0.x + b0.x, c0.y + b0.y); pk[1] = pack_bf16x2(c0.z + b0.z, c0.w + b0.w);
+        pk[2] = pack_bf16x2(c1.x + b1.x, c1.y + b1.y); pk[3] = pack_bf16x2(c1.z + b1.z, c1.w + b1.w);
+        emit(row, pk);
+    }
+}
+
 // ---- attention of one (image, head) from LDS tiles [128][ATP] of q, k, v (rows = panel rows); wave w of the image's 4 waves
 // takes query rows 16w .. 16w+15.  Same arithmetic and rounding points as attn_fwd_small_kernel (csrc/attention.hip).
 __device__ __forceinline__ void mg_attention(const unsigned short* qt, const unsigned short* kt, const unsigned short* vt, int r0,
@@ -710,6 +756,9 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
         const int img0 = panel * p.P;
         const int nimg = (p.B - img0) < p.P ? (p.B - img0) : p.P;
         const int row0 = img0 * T, rows = nimg * T;
+        // this thread's slice of the residual stream (mg_epi_residual_keep): from the stem at the panel's start, then in registers
+        float4 keep[3];
+        mg_residual_load(p.xs + (int64_t)row0 * d + 48 * member, d, rows, tid, keep);
         for (int l = 0; l < p.L; ++l) {
             const int64_t po = (int64_t)l * p.layer_stride;
             const int64_t li = p.save ? l : 0;
@@ -734,16 +783,17 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
             // ---------------- QKV + attention (member = head) ----------------
             if (member < p.H) {
                 const int h = member;
+                const int cc = tid % 24, part = cc >> 3, c64 = (cc & 7) * 8;
+                const float* bp = p.params + po + p.lo[QKVB] + part * d + 64 * h + c64;
+                const float4 bq0 = *reinterpret_cast<const float4*>(bp), bq1 = *reinterpret_cast<const float4*>(bp + 4);   // in front of the k-loop
                 mg_gemm_nt<192, 4, 4>(smem, h1 + (int64_t)row0 * d, d, rows, wQ);
                 const float* cl = reinterpret_cast<const float*>(smem);
                 MG_GEMM_DONE(0);
                 unsigned short* tiles = reinterpret_cast<unsigned short*>(smem + MG_ROWS * 196 * 4);  // q | k | v : [128][ATP] each
                 {
-                    const int cc = tid % 24, part = cc >> 3, c64 = (cc & 7) * 8;
-                    const float* bp = p.params + po + p.lo[QKVB] + part * d + 64 * h + c64;
                     unsigned short* gq = qkv + (int64_t)row0 * 3 * d + part * d + 64 * h + c64;
                     unsigned short* tq = tiles + part * 128 * ATP + c64;
-                    mg_epi_bf16(cl, bp, bp + 4, tid, [&](int row, u32x4_t pk) {
+                    mg_epi_bf16_b(cl, bq0, bq1, tid, [&](int row, u32x4_t pk) {
                         *reinterpret_cast<u32x4_t*>(tq + row * ATP) = pk;
                         if (row < rows) *reinterpret_cast<u32x4_t*>(gq + (int64_t)row * 3 * d) = pk;   // backward re-reads it (a later launch)
                     });
@@ -761,10 +811,10 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
             // ---------------- out_proj + bias + residual -> x1 ----------------
             {
                 const int n0 = 48 * member;
+                const float4 bo = *reinterpret_cast<const float4*>(p.params + po + p.lo[OUTB] + n0 + 4 * (tid % 12));   // in front of the k-loop
                 mg_gemm_nt<48, 3, 7>(smem, at + (int64_t)row0 * d, d, rows, wO);
                 MG_GEMM_DONE(1);
-                mg_epi_residual(reinterpret_cast<const float*>(smem), p.params + po + p.lo[OUTB] + n0, xin + (int64_t)row0 * d + n0,
-                                x1 + (int64_t)row0 * d + n0, d, rows, tid);
+                mg_epi_residual_keep(reinterpret_cast<const float*>(smem), bo, keep, x1 + (int64_t)row0 * d + n0, d, rows, tid);   // keep: x -> x1
             }
             MG_SYNC0(2);
             // ---------------- LN2 ----------------
@@ -774,15 +824,16 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
             // ---------------- c_fc + bias, activation -> f, g ----------------
             {
                 const int n0 = 192 * member;
-                mg_gemm_nt<192, 4, 4>(smem, h2 + (int64_t)row0 * d, d, rows, wF);
-                MG_GEMM_DONE(2);
                 const int cc = tid % 24;
                 const float* bp = p.params + po + p.lo[FCB] + n0 + 8 * cc;
+                const float4 bf0 = *reinterpret_cast<const float4*>(bp), bf1 = *reinterpret_cast<const float4*>(bp + 4);   // in front of the k-loop
+                mg_gemm_nt<192, 4, 4>(smem, h2 + (int64_t)row0 * d, d, rows, wF);
+                MG_GEMM_DONE(2);
                 unsigned short* fo = f + (int64_t)row0 * mlp + n0 + 8 * cc;
                 unsigned short* go = ga + (int64_t)row0 * mlp + n0 + 8 * cc;
                 auto epi = [&](auto ACT) {
                     constexpr int act = decltype(ACT)::value;
-                    mg_epi_bf16(reinterpret_cast<const float*>(smem), bp, bp + 4, tid, [&](int row, u32x4_t pk) {
+                    mg_epi_bf16_b(reinterpret_cast<const float*>(smem), bf0, bf1, tid, [&](int row, u32x4_t pk) {
                         if (row >= rows) return;
                         *reinterpret_cast<u32x4_t*>(fo + (int64_t)row * mlp) = pk;   // pre-activation: only the backward reads it
                         u32x4_t pk2;
@@ -800,10 +851,10 @@ __global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd 
             // ---------------- c_proj + bias + residual -> next block's input ----------------
             {
                 const int n0 = 48 * member;
+                const float4 bpj = *reinterpret_cast<const float4*>(p.params + po + p.lo[PRB] + n0 + 4 * (tid % 12));   // in front of the k-loop
                 mg_gemm_nt<48, 3, 7>(smem, ga + (int64_t)row0 * mlp, mlp, rows, wP);
                 MG_GEMM_DONE(3);
-                mg_epi_residual(reinterpret_cast<const float*>(smem), p.params + po + p.lo[PRB] + n0, x1 + (int64_t)row0 * d + n0,
-                                xout + (int64_t)row0 * d + n0, d, rows, tid);
+                mg_epi_residual_keep(reinterpret_cast<const float*>(smem), bpj, keep, xout + (int64_t)row0 * d + n0, d, rows, tid);   // keep: x1 -> next x
             }
             MG_SYNC0(5);
         }

@@ -7,6 +7,6 @@ name=$1; src=$2; shift 2
 mkdir -p $R/tools/micro/_ab/libs /tmp/_variant_$name
 o=/tmp/_variant_$name/${src%.hip}.o
 (cd $R/swat_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -Wno-unused-function "$@" -c $src -o $o)
-objs=$(ls $R/swat_amd/csrc/_obj/*.o | grep -v "/${src%.hip}.o")
+objs=$(ls $R/swat_amd/csrc/_obj/*.o | grep -v "/${src%.hip}.o" | grep -v "/${REPLACES:-__none__}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/micro/_ab/libs/lib_$name.so $objs $o
 echo "built tools/micro/_ab/libs/lib_$name.so"

@@ -928,7 +928,6 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                    }()) {
             // lane: per block the four weight gradients as one launch; the 2 L LayerNorm reductions as one launch behind them
             to_lane();
-            TRY(flush_pending_dproj(s, ws));   // (behind the persistent backward, beside the lane)
             const int nblk = ((D.B + 1) / 2) * 16;
             const int64_t lnp = vit_mega_backward_lnp_bytes(D.B, d) / 4;
             std::vector<const float*> parts;
@@ -964,6 +963,16 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
             if (g_block_adamw < 0) g_block_adamw = getenv("SWAT_BLOCK_ADAMW") ? atoi(getenv("SWAT_BLOCK_ADAMW")) : 1;
             if (g_block_adamw == 0) adam = nullptr;
             const int adam_pipe = g_block_adamw == 1 ? 1 : 0;
+            // Piped form on one GPU (round 6): the LayerNorm reductions (ln_post's column sums, then the 2 L sets of the blocks: 12 + 18 us)
+            // used to open the LANE, in front of the top block's weight gradients — and the optimizer chain, which bounds this phase,
+            // starts behind those.  They run on the optimizer's stream instead (idle until the first block's gradients are there), beside
+            // the top block's weight gradients: the first AdamW of the blocks starts ~30 us earlier.
+            const bool piped = adam && adam_pipe && fork && !(g_dp.n > 0);
+            if (piped) {
+                hipEvent_t e = g_side.next();
+                if (!e || hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(g_side.aux[0], e, 0) != hipSuccess) lane_ok = false;
+            }
+            TRY(flush_pending_dproj(s, piped ? g_side.aux[0] : ws));   // (behind the persistent backward, beside the lane)
             if (g_dp.n > 0 && fork) {
                 // data-parallel: LayerNorm reductions of every block first (their vectors ride in the blocks' buckets), then one
                 // weight-gradient launch + event per bucket, top of the tower first; the last bucket takes whatever blocks remain
@@ -998,8 +1007,8 @@ SWAT_API int swat_vit_backward(const int32_t* dims, const int64_t* offs, const f
                 // SIMD's 512 registers: one 52-register wave of the HBM-bound AdamW fits beside its three (measured: 12 x (33 + 36) us
                 // one after the other -> 12 x ~51 us; the epilogue form below — AdamW on the accumulators — spares the gradient's
                 // round trip through memory but leaves its IEEE divisions and square roots to 8 waves per CU: no faster than apart)
-                TRY(ln_bwd_finish_sets(parts.data(), dgs.data(), dbs_.data(), dcs.data(), (int)parts.size(), nblk, d, ws));
                 hipStream_t os = g_side.aux[0];
+                TRY(ln_bwd_finish_sets(parts.data(), dgs.data(), dbs_.data(), dcs.data(), (int)parts.size(), nblk, d, os));
                 const int64_t stride = D.L > 1 ? O.layer[12] - O.layer[0] : 0;
                 const int64_t zero = 0;
                 static const int pipe_grp = getenv("SWAT_PIPE_GROUP") ? atoi(getenv("SWAT_PIPE_GROUP")) : 1;

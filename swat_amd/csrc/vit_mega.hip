@@ -712,6 +712,9 @@ __device__ __forceinline__ void mg_place(int nteams, int xsplit, int b, int& tea
         const int per = MG_TEAM / xsplit;             // members of a team on one XCD
         const int tg = x / xsplit, mg = x % xsplit;   // XCD group (hosts nteams * xsplit / 8 teams), member group inside it
         team = tg * (nteams * xsplit / 8) + s / per;
+        // (member groups are CONTIGUOUS: members 4 g .. 4 g + 3 on one XCD.  Interleaved groups — g, g + 4, g + 8, g + 12, which would
+        // spread the four members without a head over four XCDs — measured slower: forward +7 us, backward +40 us, whose FC' / IN'
+        // members 4 g .. 4 g + 3 share one K-quarter of the panel)
         member = mg * per + s % per;
     } else if (nteams % 8 == 0) {
         const int q = nteams / 8, s = b >> 3;
@@ -728,7 +731,13 @@ __device__ __forceinline__ void mg_place(int nteams, int xsplit, int b, int& tea
         if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 64 + ((i) & 63)] = mg_clock();  \
     } while (0)
 
-__global__ __launch_bounds__(MG_THREADS) void vit_fwd_mega_kernel(const MegaFwd p) {
+// MG_FWD_VGPR (a build-time knob): arch-VGPR budget of the persistent forward.  NOTE the toolchain's quirk on gfx90a+ (unified
+// VGPR / AGPR file): the value `amdgpu_num_vgpr` takes is HALF the allocation it results in — 112 gives a 224-register kernel, 224 is
+// out of range and silently ignored (rounds 3-5 concluded the attribute had no effect).
+#ifndef MG_FWD_VGPR
+#define MG_FWD_VGPR 128
+#endif
+__global__ __launch_bounds__(MG_THREADS) __attribute__((amdgpu_num_vgpr(MG_FWD_VGPR))) void vit_fwd_mega_kernel(const MegaFwd p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[MG_LDS];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;

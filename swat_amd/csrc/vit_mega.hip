@@ -24,11 +24,17 @@
 // seven kernel boundaries + launch fixed costs.
 //
 // Hand-off protocol (MI355X guide, Guideline 16 recipe R1, counter form; placement-independent — the team <-> XCD
-// mapping below is for speed only): every byte another workgroup will read is stored write-through (sc1); each storing
+// mapping below — mg_place, round 6: a team's members spread over four XCDs, so that an XCD's L2 sees a quarter of every weight
+// matrix — is for speed only): every byte another workgroup will read is stored write-through (sc1); each storing
 // wave drains its stores (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane adds 1 to the team's arrival counter (agent
 // scope) and polls it relaxed until all 16 members of the phase have arrived; then ONE agent-scope acquire
 // (buffer_inv sc1), its wait, workgroup barrier, and only then the next phase's loads.  Counters are zeroed by a
 // hipMemsetAsync in front of every launch; every spin is bounded (give-up code in the status block).
+//
+// Round 6 (DESIGN.md sections 4 and 8): what bounds these kernels was measured — the k-loops by the CU's vector-memory byte rate
+// (~50 GB/s per CU), the chain between them by memory round trips that cannot share the pipe with bulk traffic.  Live from that round:
+// the placement above, and epilogues without a global load (mg_epi_residual_keep: the residual slice stays in the thread's registers).
+// Kept as a tested switch, not the default: vit_fwd_mega2_kernel (fixed wave roles, weight stages carried in loader registers).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdlib.h>

@@ -471,7 +471,7 @@ def test_persistent_forward_equals_the_op_by_op_forward_and_ignores_history(B):
         assert r < GRAD_TOL, f"{n}: {r}"
 
 
-@pytest.mark.parametrize("B", [32, 7, 16])
+@pytest.mark.parametrize("B", [32, 7, 16, 40])   # 40: twenty panels on sixteen teams — a second, ragged round
 def test_persistent_kernels_do_not_depend_on_placement_or_wave_roles(B):
     """Round 6 (csrc/vit_mega.hip): (i) where a team's sixteen workgroups sit is for speed only — a team spread over 1, 2, 4 or 8 XCDs
     (mg_place / swat_vit_set_mega_xsplit; default 4: an XCD then sees a quarter of every weight matrix, read by eight teams) gives the

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """tools/micro/adamw_beside.py — swat_adamw over the ViT-B/32 arena (88 M parameters) alone, and beside a kernel that only occupies
-every CU the way the weight-gradient launch does (tools/micro/_hog/hog.hip: 12 waves, 144 KB LDS, 152 / 128 / 104 registers)."""
+every CU the way the weight-gradient launch does (tools/micro/_hog/hog.hip: 12 waves, 144 KB LDS, 152 / 128 / 104 registers).
+Build the occupant first (here, it travels to the GPU box):
+    (cd tools/micro/_hog && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -shared -o libhog.so hog.hip)"""
 import ctypes
 import os
 import sys
